@@ -1,0 +1,455 @@
+"""Functional CPU restatement of the DecoderTracker per-frame inference path.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Every function cites the reference lines it
+follows (paths relative to /root/reference).  Inputs are the reference `state_dict` (key names
+of mo_yolo_amd.config.param_shapes) and plain tensors; there are no nn.Modules here.
+
+Parity status: pinned by tests/golden/*.npz (reference outputs generated in the build
+container) in tests/test_oracle_vs_golden.py.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3          # ultralytics/utils/torch_utils.py:262 (initialize_weights)
+LN_EPS = 1e-5          # torch default
+SCORE_THRESH = 0.4     # head.py:1146
+FILTER_SCORE_THRESH = 0.5
+MISS_TOLERANCE = 5
+
+
+# ----------------------------------------------------------------------------- backbone / neck
+def conv_bn_act(x, sd, p, k, s, act=True):
+    """Conv.forward, nn/modules/conv.py:36-38: SiLU(BN_eval(conv2d(x, W, stride s, pad k//2)))."""
+    y = F.conv2d(x, sd[p + ".conv.weight"], None, s, k // 2)
+    y = F.batch_norm(y, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"],
+                     sd[p + ".bn.weight"], sd[p + ".bn.bias"], False, 0.0, BN_EPS)
+    return F.silu(y) if act else y
+
+
+def c2f(x, sd, p, n, shortcut):
+    """C2f.forward block.py:178-182 with Bottleneck.forward block.py:281-283 (two 3x3, e=1.0)."""
+    y = conv_bn_act(x, sd, p + ".cv1", 1, 1)
+    c = y.shape[1] // 2
+    ys = [y[:, :c], y[:, c:]]
+    for j in range(n):
+        t = conv_bn_act(ys[-1], sd, f"{p}.m.{j}.cv1", 3, 1)
+        t = conv_bn_act(t, sd, f"{p}.m.{j}.cv2", 3, 1)
+        ys.append(ys[-1] + t if shortcut else t)
+    return conv_bn_act(torch.cat(ys, 1), sd, p + ".cv2", 1, 1)
+
+
+def sppf(x, sd, p, k=5):
+    """SPPF.forward block.py:129-134: 1x1 -> three cascaded maxpool(k, 1, k//2) -> cat -> 1x1."""
+    x = conv_bn_act(x, sd, p + ".cv1", 1, 1)
+    y1 = F.max_pool2d(x, k, 1, k // 2)
+    y2 = F.max_pool2d(y1, k, 1, k // 2)
+    y3 = F.max_pool2d(y2, k, 1, k // 2)
+    return conv_bn_act(torch.cat((x, y1, y2, y3), 1), sd, p + ".cv2", 1, 1)
+
+
+def backbone_neck(x, sd, arch, return_all=False):
+    """TrackingModel.predict layer walk, nn/tasks.py:503-511 (save-list semantics)."""
+    outs: List[torch.Tensor] = []
+    for L in arch.layers:
+        src = [x if j < 0 else outs[j] for j in L.src]    # j == -1: the network input (layer 0)
+        p = f"model.{L.i}"
+        if L.kind == "Conv":
+            y = conv_bn_act(src[0], sd, p, L.k, L.s)
+        elif L.kind == "C2f":
+            y = c2f(src[0], sd, p, L.n, L.shortcut)
+        elif L.kind == "SPPF":
+            y = sppf(src[0], sd, p, L.k)
+        elif L.kind == "Upsample":
+            y = F.interpolate(src[0], scale_factor=2.0, mode="nearest")      # yolo_track.yaml:29
+        elif L.kind == "Concat":
+            y = torch.cat(src, 1)                                              # conv.py:295-297
+        else:
+            raise ValueError(L.kind)
+        outs.append(y)
+    feats = [outs[j] for j in (15, 18, 21)]
+    return (feats, outs) if return_all else feats
+
+
+# ----------------------------------------------------------------------------- head: encoder side
+def encoder_input(feats_in, sd, d):
+    """MYDecoder._get_encoder_input head.py:1012-1029: Conv1x1(no bias)+BN per level, flatten, cat."""
+    toks, shapes = [], []
+    for li, f in enumerate(feats_in):
+        y = F.conv2d(f, sd[f"{d}.input_proj.{li}.0.weight"])
+        q = f"{d}.input_proj.{li}.1"
+        y = F.batch_norm(y, sd[q + ".running_mean"], sd[q + ".running_var"], sd[q + ".weight"], sd[q + ".bias"],
+                         False, 0.0, BN_EPS)
+        shapes.append((y.shape[2], y.shape[3]))
+        toks.append(y.flatten(2).permute(0, 2, 1))
+    return torch.cat(toks, 1), shapes
+
+
+def generate_anchors(shapes, grid_size=0.05, eps=1e-2, dtype=torch.float32):
+    """MYDecoder._generate_anchors head.py:993-1010.  NOTE the reference divides (x, y) by (H, W)
+    -- axes swapped (head.py:999-1002) -- which is restated verbatim here."""
+    out = []
+    for i, (h, w) in enumerate(shapes):
+        gy, gx = torch.meshgrid(torch.arange(h, dtype=dtype), torch.arange(w, dtype=dtype), indexing="ij")
+        xy = torch.stack([gx, gy], -1)
+        xy = (xy.unsqueeze(0) + 0.5) / torch.tensor([h, w], dtype=dtype)
+        wh = torch.ones_like(xy) * grid_size * (2.0 ** i)
+        out.append(torch.cat([xy, wh], -1).view(-1, h * w, 4))
+    a = torch.cat(out, 1)
+    valid = ((a > eps) * (a < 1 - eps)).all(-1, keepdim=True)
+    a = torch.log(a / (1 - a))
+    a = a.masked_fill(~valid, float("inf"))
+    return a, valid
+
+
+def linear(x, sd, p):
+    return F.linear(x, sd[p + ".weight"], sd[p + ".bias"])
+
+
+def mlp3(x, sd, p):
+    """MLP.forward transformer.py:158-161 (num_layers=3)."""
+    x = F.relu(linear(x, sd, p + ".layers.0"))
+    x = F.relu(linear(x, sd, p + ".layers.1"))
+    return linear(x, sd, p + ".layers.2")
+
+
+def pos2posemb(pos, num_pos_feats=64, temperature=10000):
+    """transformer.py:183-190: applied to box *logits*; (sin, cos) interleaved per coordinate."""
+    pos = pos * (2 * math.pi)
+    dim_t = torch.arange(num_pos_feats, dtype=pos.dtype)
+    dim_t = temperature ** (2 * (dim_t // 2) / num_pos_feats)
+    pe = pos[..., None] / dim_t
+    return torch.stack((pe[..., 0::2].sin(), pe[..., 1::2].cos()), dim=-1).flatten(-3)
+
+
+def decoder_input(feats, shapes, sd, d, nq, topk_ind=None):
+    """MYDecoder._get_decoder_input head.py:1031-1113, is_first branch (:1052-1054), eval mode."""
+    bs = feats.shape[0]
+    anchors, valid = generate_anchors(shapes, dtype=feats.dtype)
+    x = linear(valid * feats, sd, d + ".enc_output.0")
+    features = F.layer_norm(x, (x.shape[-1],), sd[d + ".enc_output.1.weight"], sd[d + ".enc_output.1.bias"], LN_EPS)
+    scores_all = linear(features, sd, d + ".enc_score_head")
+    bboxes_all = mlp3(features, sd, d + ".enc_bbox_head") + anchors
+    if topk_ind is None:
+        topk_ind = torch.topk(scores_all.max(-1).values, nq, dim=1).indices
+    bi = torch.arange(bs).unsqueeze(-1)
+    refer_logit = bboxes_all[bi, topk_ind]
+    out = dict(features=features, enc_scores_all=scores_all, enc_bboxes_all=bboxes_all, topk_ind=topk_ind,
+               refer_bbox_logit=refer_logit, query_pos=pos2posemb(refer_logit),
+               enc_bboxes=refer_logit.sigmoid(), enc_scores=scores_all[bi, topk_ind],
+               embed=features[bi, topk_ind], valid=valid, anchors=anchors)
+    return out
+
+
+# ----------------------------------------------------------------------------- decoder
+def inverse_sigmoid(x, eps=1e-5):
+    """nn/modules/utils.py:34-38 (== MOTR/util/misc.py:532-536)."""
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+def mha(q_in, k_in, v_in, sd, p, nh):
+    """nn.MultiheadAttention explicit path: separate Q/K/V projections from
+    in_proj_weight.chunk(3); q scaled by head_dim**-0.5 BEFORE QK^T; softmax over keys; out_proj.
+    Inputs [B, L, E] (the reference transposes to [L, B, E]; per-batch math is identical)."""
+    E = q_in.shape[-1]
+    hd = E // nh
+    W, bias = sd[p + ".in_proj_weight"], sd[p + ".in_proj_bias"]
+    q = F.linear(q_in, W[:E], bias[:E])
+    k = F.linear(k_in, W[E:2 * E], bias[E:2 * E])
+    v = F.linear(v_in, W[2 * E:], bias[2 * E:])
+    B, Lq, _ = q.shape
+    Lk = k.shape[1]
+    q = q.view(B, Lq, nh, hd).transpose(1, 2) * (1.0 / math.sqrt(hd))
+    k = k.view(B, Lk, nh, hd).transpose(1, 2)
+    v = v.view(B, Lk, nh, hd).transpose(1, 2)
+    a = torch.softmax(q @ k.transpose(-1, -2), -1)
+    o = (a @ v).transpose(1, 2).reshape(B, Lq, E)
+    return linear(o, sd, p + ".out_proj")
+
+
+def msda_core(value, shapes, loc, aw):
+    """Multi-scale deformable attention core.
+    Spec: nn/modules/utils.py:41-78 (grid_sample bilinear, zeros padding, align_corners=False)
+    == CUDA kernel MOTR/models/ops/src/cuda/ms_deform_im2col_cuda.cuh:237-299: pixel coords
+    h_im = loc_y*H - 0.5, w_im = loc_x*W - 0.5; taps outside the map contribute 0.
+    value [B,S,M,D], loc [B,Lq,M,L,P,2] (x,y), aw [B,Lq,M,L,P] -> [B,Lq,M*D]."""
+    B, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    out = value.new_zeros(B, Lq, M, D)
+    start = 0
+    bidx = torch.arange(B).view(B, 1, 1, 1)
+    midx = torch.arange(M).view(1, 1, M, 1)
+    for l, (H, W) in enumerate(shapes):
+        v = value[:, start:start + H * W]                       # [B, HW, M, D]
+        x = loc[:, :, :, l, :, 0] * W - 0.5                     # [B, Lq, M, P]
+        y = loc[:, :, :, l, :, 1] * H - 0.5
+        x0 = torch.floor(x); y0 = torch.floor(y)
+        lx = x - x0; ly = y - y0
+        x0 = x0.long(); y0 = y0.long()
+        acc = value.new_zeros(B, Lq, M, P, D)
+        for dy, wy in ((0, 1 - ly), (1, ly)):
+            for dx, wx in ((0, 1 - lx), (1, lx)):
+                xi = x0 + dx; yi = y0 + dy
+                ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+                idx = (yi.clamp(0, H - 1) * W + xi.clamp(0, W - 1))
+                g = v[bidx, idx, midx]                           # [B, Lq, M, P, D]
+                acc = acc + g * (wy * wx * ok)[..., None]
+        out = out + (acc * aw[:, :, :, l, :, None]).sum(3)
+        start += H * W
+    return out.reshape(B, Lq, M * D)
+
+
+def msda(query, refer_bbox, feats, shapes, sd, p, nh, npnt, value=None):
+    """MSDeformAttn.forward transformer.py:246-287, 4-d reference boxes (:280-282)."""
+    B, Lq, C = query.shape
+    L = len(shapes)
+    if value is None:
+        value = linear(feats, sd, p + ".value_proj")
+    value = value.view(B, -1, nh, C // nh)
+    off = linear(query, sd, p + ".sampling_offsets").view(B, Lq, nh, L, npnt, 2)
+    aw = linear(query, sd, p + ".attention_weights").view(B, Lq, nh, L * npnt)
+    aw = torch.softmax(aw, -1).view(B, Lq, nh, L, npnt)
+    rb = refer_bbox[:, :, None, None, None, :]                   # same box for every level (:644)
+    loc = rb[..., :2] + off / npnt * rb[..., 2:] * 0.5
+    o = msda_core(value, shapes, loc, aw)
+    return linear(o, sd, p + ".output_proj"), dict(loc=loc, aw=aw, core=o, value=value)
+
+
+def layer_norm(x, sd, p):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], LN_EPS)
+
+
+def decoder_layer(embed, refer_bbox, feats, shapes, query_pos, sd, p, nh, npnt, trace=None):
+    """MOTRDecoderLayer.forward transformer.py:627-652 (dropouts are identity in eval)."""
+    qk = embed + query_pos
+    sa = mha(qk, qk, embed, sd, p + ".self_attn", nh)
+    embed = layer_norm(embed + sa, sd, p + ".norm1")
+    ca, aux = msda(embed + query_pos, refer_bbox, feats, shapes, sd, p + ".cross_attn", nh, npnt)
+    embed2 = layer_norm(embed + ca, sd, p + ".norm2")
+    ff = linear(F.relu(linear(embed2, sd, p + ".linear1")), sd, p + ".linear2")
+    out = layer_norm(embed2 + ff, sd, p + ".norm3")
+    if trace is not None:
+        trace.update(sa=sa, n1=embed, ca=ca, n2=embed2, out=out, **{"msda_" + k: v for k, v in aux.items()})
+    return out
+
+
+def decoder(embed, refer_logit, feats, shapes, query_pos, sd, d, arch, trace=None):
+    """MOTRTransformerDecoder.forward transformer.py:676-728, eval: iterative refinement
+    sigmoid(bbox_head[i](out) + inverse_sigmoid(ref)); scores only from the last layer."""
+    ref = refer_logit.sigmoid()
+    out = embed
+    for i in range(arch.ndl):
+        tr = {} if trace is not None else None
+        out = decoder_layer(out, ref, feats, shapes, query_pos, sd, f"{d}.decoder.layers.{i}", arch.nh, arch.ndp, tr)
+        delta = mlp3(out, sd, f"{d}.dec_bbox_head.{i}")
+        ref = torch.sigmoid(delta + inverse_sigmoid(ref))
+        if trace is not None:
+            tr.update(bbox_delta=delta, refined=ref)
+            trace[i] = tr
+    logits = linear(out, sd, f"{d}.dec_score_head.{arch.ndl - 1}")
+    return ref, logits, out
+
+
+def head_forward(feats_in, sd, arch, topk_ind=None, trace=None):
+    """MOTRTrack.forward head.py:191-239 numeric part (the decoder call :223-229 and `y` :235)."""
+    d = f"model.{len(arch.layers)}.decoder"
+    feats, shapes = encoder_input(feats_in, sd, d)
+    di = decoder_input(feats, shapes, sd, d, arch.nq, topk_ind)
+    boxes, logits, hs = decoder(di["embed"], di["refer_bbox_logit"], feats, shapes, di["query_pos"], sd, d, arch, trace)
+    y = torch.cat((boxes, logits.sigmoid()), -1)
+    return dict(y=y, dec_bboxes=boxes, dec_scores=logits, hs=hs, feats=feats, shapes=shapes, **di)
+
+
+def forward(x, sd, arch, topk_ind=None):
+    """Whole numeric path for network-resolution input x [B,3,H,W] in [0,1]."""
+    return head_forward(backbone_neck(x, sd, arch), sd, arch, topk_ind)
+
+
+# ----------------------------------------------------------------------------- state machine
+def assign_ids(scores: torch.Tensor, thresh: float = SCORE_THRESH) -> torch.Tensor:
+    """Shipped per-frame ID allocation (head.py:199-205 resets state every frame,
+    RuntimeTrackerBase.update head.py:1232-1237): walk rows in query order, every row with
+    score >= 0.4 receives the running counter starting at 0; others stay -1.  scores [..., nq]."""
+    born = scores >= thresh
+    ids = torch.cumsum(born.long(), -1) - 1
+    return torch.where(born, ids, torch.full_like(ids, -1))
+
+
+def assign_ids_loop(scores, obj_idxes=None, disappear=None, max_obj_id=0):
+    """Literal restatement of the loop head.py:1232-1243 for one frame incl. the miss branch;
+    used to pin assign_ids and for the (dead in the shipped path) carried-state semantics."""
+    n = len(scores)
+    ids = [-1] * n if obj_idxes is None else [int(v) for v in obj_idxes]
+    dis = [0] * n if disappear is None else [int(v) for v in disappear]
+    for i in range(n):
+        s = float(scores[i])
+        if ids[i] == -1 and s >= SCORE_THRESH:
+            ids[i] = max_obj_id
+            max_obj_id += 1
+        elif ids[i] >= 0 and s < FILTER_SCORE_THRESH:
+            dis[i] += 1
+            if dis[i] >= MISS_TOLERANCE:
+                ids[i] = -1
+    return ids, dis, max_obj_id
+
+
+def _iou_xywh_shortcut(b1, b2):
+    """RuntimeTrackerBase._calculate_iou head.py:1173-1196: treats (cx,cy,w,h) rows as (x,y,w,h)
+    and short-circuits to 0 when the corners are far apart.  Plain floats (fp32 inputs)."""
+    import numpy as np
+    f = np.float32
+    if abs(b1[0] - b2[0]) > f(0.5) * min(b1[0], b2[0]):
+        return f(0)
+    if abs(b1[1] - b2[1]) > f(0.5) * min(b1[1], b2[1]):
+        return f(0)
+    ix1, iy1 = max(b1[0], b2[0]), max(b1[1], b2[1])
+    ix2, iy2 = min(b1[0] + b1[2], b2[0] + b2[2]), min(b1[1] + b1[3], b2[1] + b2[3])
+    inter = max(f(0), ix2 - ix1) * max(f(0), iy2 - iy1)
+    return inter / (b1[2] * b1[3] + b2[2] * b2[3] - inter)
+
+
+def filter_tracks(boxes) -> "list[bool]":
+    """RuntimeTrackerBase._filter_tracks head.py:1155-1171: greedy O(K^2) suppression, IoU > 0.8."""
+    import numpy as np
+    b = np.asarray(boxes, dtype=np.float32)
+    n = len(b)
+    keep = [True] * n
+    for i in range(n):
+        if keep[i]:
+            for j in range(i + 1, n):
+                if keep[j] and _iou_xywh_shortcut(b[i], b[j]) > 0.8:
+                    keep[j] = False
+    return keep
+
+
+def tracker_update_copy(scores, boxes, ids):
+    """The *copy* half of RuntimeTrackerBase.update head.py:1245-1283 (only FSQM ever sees it):
+    active rows -> filter -> renumber ids above max_obj_id_pre(=0 in the shipped per-frame reset).
+    Returns (row indices kept, renumbered ids)."""
+    act = [i for i, v in enumerate(ids) if v >= 0]
+    if not act:
+        return [], []
+    keep = filter_tracks([boxes[i] for i in act])
+    rows = [i for i, k in zip(act, keep) if k]
+    new_ids, tmp, pre = [], 0, 0
+    for i in rows:
+        v = int(ids[i])
+        if v > pre:
+            v = pre + tmp + 1
+            tmp += 1
+        new_ids.append(v)
+    return rows, new_ids
+
+
+class FSQMOracle:
+    """Fixed-size query memory, MOTR/models/fsqm.py:7-190, restated on numpy.  Output-invisible in
+    the shipped path (online_update returns its second argument, fsqm.py:170-180)."""
+
+    def __init__(self, n=300, dim=256, in_thr=0.7, out_thr=0.3, consecutive=3):
+        import numpy as np
+        self.n, self.dim, self.in_thr, self.out_thr, self.cons = n, dim, in_thr, out_thr, consecutive
+        self.reset()
+
+    def reset(self):
+        import numpy as np
+        self.mem = np.zeros((self.n, self.dim), np.float32)
+        self.conf = np.zeros(self.n, np.float32)
+        self.ids = -np.ones(self.n, np.int64)
+        self.boxes = np.zeros((self.n, 4), np.float32)
+        self.low = np.zeros(self.n, np.int32)
+        self.pool = list(range(self.n))
+
+    def online_update(self, det_scores, det_boxes, det_emb, trk_scores, trk_boxes, trk_ids):
+        import numpy as np
+        # 1. update_confidence fsqm.py:117-132 -- indexes memory BY ID value
+        for s, b, i in zip(trk_scores, trk_boxes, trk_ids):
+            i = int(i)
+            if 0 <= i < self.n:
+                self.conf[i] = s; self.boxes[i] = b; self.low[i] = 0
+        # 2. inject_new_queries fsqm.py:51-100 (score > in_threshold, first free slot, FIFO id pool)
+        for s, b, e in zip(det_scores, det_boxes, det_emb):
+            if not (s > self.in_thr):
+                continue
+            free = np.nonzero(self.ids == -1)[0]
+            if len(free) == 0:
+                break
+            j = int(free[0])
+            self.ids[j] = self.pool.pop(0)
+            self.mem[j] = e; self.conf[j] = s; self.boxes[j] = b; self.low[j] = 0
+        # 3. remove_inactive_queries fsqm.py:102-115 (also ages never-used slots: conf 0 < 0.3, and
+        #    recycles their id -1 into the pool -- restated as shipped)
+        for j in np.nonzero(self.conf < self.out_thr)[0]:
+            self.low[j] += 1
+            if self.low[j] >= self.cons:
+                self.mem[j] = 0; self.conf[j] = 0
+                self.pool.append(int(self.ids[j]))
+                self.ids[j] = -1; self.boxes[j] = 0; self.low[j] = 0
+
+
+def qim_update_track_embedding(ref_pts, out_embed, query_pos_in, pred_boxes, sd, t, nh=8):
+    """QueryInteractionModule._update_track_embedding MOTR/models/qim.py:251-301
+    (update_query_pos=False, MOTR/main.py:170; dropouts identity).  Returns (query_pos, ref_pts)."""
+    qp = pos2posemb(ref_pts)
+    qk = (qp + out_embed)[None]                      # attention over the N tracks (batch of 1)
+    tgt = out_embed
+    tgt2 = mha(qk, qk, tgt[None], sd, t + ".self_attn", nh)[0]
+    tgt = layer_norm(tgt + tgt2, sd, t + ".norm1")
+    tgt2 = linear(F.relu(linear(tgt, sd, t + ".linear1")), sd, t + ".linear2")
+    tgt = layer_norm(tgt + tgt2, sd, t + ".norm2")
+    qf2 = linear(F.relu(linear(tgt, sd, t + ".linear_feat1")), sd, t + ".linear_feat2")
+    qf = layer_norm(query_pos_in + qf2, sd, t + ".norm_feat")
+    return qf, inverse_sigmoid(pred_boxes[:, :4])
+
+
+# ----------------------------------------------------------------------------- predictor I/O
+def xywh2xyxy(b):
+    """utils/ops.py:378-393."""
+    y = b.clone()
+    y[..., 0] = b[..., 0] - b[..., 2] / 2
+    y[..., 1] = b[..., 1] - b[..., 3] / 2
+    y[..., 2] = b[..., 0] + b[..., 2] / 2
+    y[..., 3] = b[..., 1] + b[..., 3] / 2
+    return y
+
+
+def postprocess(y, logits, ids, conf=0.25, orig_hw=None):
+    """TrackPredictor.postprocess models/MOTRtrack/predict.py:13-94 for ONE frame.
+    y [nq, 4+nc], logits [nq, nc], ids [nq].  Active branch (:43-76): rows with id >= 0 in query
+    order, boxes filtered by score > conf (track ids are NOT filtered, :61-76), scaled by the
+    original (w, h) unless the source was a tensor.  Fallback (:79-94) when nothing is active.
+    Returns (rows[K,6], track_id[K'] | None)."""
+    boxes, probs = y[:, :4], y[:, 4:]
+    act = ids >= 0
+    if bool(act.any()):
+        b = xywh2xyxy(boxes[act])
+        score = logits[act].sigmoid().max(-1).values
+        cls = logits[act].max(-1, keepdim=True).indices
+        rows = torch.cat([b, score[:, None], cls.to(b.dtype)], -1)[score > conf]
+        tid = ids[act]
+    else:
+        b = xywh2xyxy(boxes)
+        score, cls = probs.max(-1, keepdim=True)
+        rows = torch.cat([b, score, cls.to(b.dtype)], -1)[score.squeeze(-1) > conf]
+        tid = None
+    if orig_hw is not None:
+        rows[:, [0, 2]] *= orig_hw[1]
+        rows[:, [1, 3]] *= orig_hw[0]
+    return rows, tid
+
+
+def txt_lines(rows, tid, orig_hw, save_conf=False):
+    """TrackResults.save_txt engine/results.py:475-512: 'track_id cls cx cy w h [conf]' with
+    xywh normalised by the original shape, formatted with %g."""
+    out = []
+    for j in range(rows.shape[0]):
+        x1, y1, x2, y2, cf, c = [rows[j, k] for k in range(6)]
+        xywhn = torch.stack([(x1 + x2) / 2 / orig_hw[1], (y1 + y2) / 2 / orig_hw[0],
+                             (x2 - x1) / orig_hw[1], (y2 - y1) / orig_hw[0]])
+        line = (int(tid[j]), int(c), *xywhn) + ((float(cf),) if save_conf else ())
+        out.append(("%g " * len(line)).rstrip() % line)
+    return out

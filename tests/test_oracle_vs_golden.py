@@ -1,0 +1,127 @@
+"""Pin the CPU oracle (oracle/track_oracle.py) against golden vectors produced by the imported
+reference (tests/golden/make_golden.py).  CPU only; this is what makes the oracle trustworthy as
+the parity arbiter for the `-m gpu` tests."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import track_oracle as O
+from tests._util import check_close, fixture, golden, net_input, frames_u8
+
+TOL = 2e-5   # fp32 CPU vs fp32 CPU, different op decomposition only
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny3", "c2"])
+def test_seams_frame0(name):
+    g = golden(name)
+    cfg, arch, sd = fixture(name)
+    x = net_input(cfg, 0, 1)
+    with torch.no_grad():
+        feats_in, outs = O.backbone_neck(x, sd, arch, return_all=True)
+        for i, o in enumerate(outs):
+            check_close(o, g, f"t0.L{i}", atol=TOL, rtol=1e-5)
+        trace = {}
+        r = O.head_forward(feats_in, sd, arch, trace=trace)
+    d = f"model.{len(arch.layers)}.decoder"
+    assert [tuple(s) for s in g["shapes"]] == [tuple(s) for s in r["shapes"]]
+    assert np.array_equal(g["valid_mask"], r["valid"][0, :, 0].numpy())
+    check_close(r["features"], g, "t0.enc_features", atol=TOL)
+    check_close(r["enc_scores_all"], g, "t0.enc_scores_all", atol=TOL)
+    fin = torch.isfinite(r["anchors"])
+    assert torch.equal(r["anchors"][fin], torch.from_numpy(g["t0.anchors"])[fin]) if "t0.anchors" in g else True
+    assert np.array_equal(r["topk_ind"].numpy().reshape(-1), g["t0.topk_ind"].reshape(-1)), "top-k order"
+    check_close(r["embed"], g, "t0.embed0", atol=TOL)
+    check_close(r["refer_bbox_logit"], g, "t0.refer_bbox_logit", atol=TOL)
+    check_close(r["query_pos"], g, "t0.query_pos", atol=5e-5)
+    check_close(r["enc_bboxes"], g, "t0.enc_bboxes", atol=TOL)
+    check_close(r["enc_scores"], g, "t0.enc_scores", atol=TOL)
+    for li in range(arch.ndl):
+        t = trace[li]
+        check_close(t["sa"].transpose(0, 1), g, f"t0.dec{li}.sa", atol=TOL)   # reference MHA is [L, B, E]
+        check_close(t["n1"], g, f"t0.dec{li}.n1", atol=TOL)
+        check_close(t["msda_loc"], g, f"t0.dec{li}.msda_loc", atol=TOL)
+        check_close(t["msda_aw"], g, f"t0.dec{li}.msda_aw", atol=TOL)
+        check_close(t["msda_core"], g, f"t0.dec{li}.msda_out", atol=TOL)
+        check_close(t["ca"], g, f"t0.dec{li}.ca", atol=TOL)
+        check_close(t["n2"], g, f"t0.dec{li}.n2", atol=TOL)
+        check_close(t["out"], g, f"t0.dec{li}.out", atol=TOL)
+        check_close(t["bbox_delta"], g, f"t0.dec{li}.bbox_delta", atol=TOL)
+    assert torch.allclose(r["y"][0], torch.from_numpy(g["y"][0]), atol=TOL)
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny3", "c2"])
+def test_stream_y_and_ids(name):
+    """Per-frame reset semantics: ids restart at 0 in every frame, in query order."""
+    g = golden(name)
+    cfg, arch, sd = fixture(name)
+    nfr = cfg["frames"] if name != "c2" else 3
+    for t in range(nfr):
+        with torch.no_grad():
+            r = O.forward(net_input(cfg, t, 1), sd, arch)
+        y = r["y"][0]
+        assert torch.allclose(y, torch.from_numpy(g["y"][t]), atol=5e-5), t
+        scores = r["dec_scores"][0].sigmoid().max(-1).values
+        assert torch.allclose(scores, torch.from_numpy(g["scores"][t]), atol=5e-5)
+        ids = O.assign_ids(scores)
+        assert np.array_equal(ids.numpy(), g["obj_idxes"][t]), (t, ids, g["obj_idxes"][t])
+        ids2, _, _ = O.assign_ids_loop(scores)
+        assert ids2 == ids.tolist()
+        # predictor rows (a20)
+        fr = frames_u8(cfg, t, 1)
+        rows, tid = O.postprocess(y, r["dec_scores"][0], ids, conf=0.25, orig_hw=fr.shape[1:3])
+        assert bool(g[f"post.{t}.is_track"]) == (tid is not None)
+        assert np.allclose(rows.numpy(), g[f"post.{t}.boxes"], atol=2e-2, rtol=1e-5)   # pixels
+        if tid is not None:
+            assert np.array_equal(tid.numpy(), g[f"post.{t}.track_id"].reshape(-1))
+            lines = O.txt_lines(rows, tid, fr.shape[1:3])
+            want = str(g[f"post.{t}.txt"]).strip().split("\n")
+            assert len(lines) == len(want)
+            for a, b in zip(lines, want):
+                fa, fb = a.split(), b.split()
+                assert fa[:2] == fb[:2]
+                assert np.allclose([float(v) for v in fa[2:]], [float(v) for v in fb[2:]], atol=2e-5)
+        rows_n, _ = O.postprocess(y, r["dec_scores"][0], ids, conf=0.25, orig_hw=None)
+        assert np.allclose(rows_n.numpy(), g[f"post.{t}.boxes_tensor_src"], atol=5e-5)
+
+
+@pytest.mark.slow
+def test_c4_frame0():
+    g = golden("c4")
+    cfg, arch, sd = fixture("c4")
+    with torch.no_grad():
+        r = O.forward(net_input(cfg, 0, 1), sd, arch)
+    assert np.array_equal(r["topk_ind"].numpy().reshape(-1), g["t0.topk_ind"].reshape(-1))
+    assert torch.allclose(r["y"][0], torch.from_numpy(g["y"][0]), atol=5e-5)
+    ids = O.assign_ids(r["dec_scores"][0].sigmoid().max(-1).values)
+    assert np.array_equal(ids.numpy(), g["obj_idxes"][0])
+
+
+def test_msda_core_kats():
+    """MSDA core vs the reference op (grid_sample formulation) incl. zero-padding edge taps;
+    construction follows MOTR/models/ops/test.py:21-30."""
+    g = golden("msda_kat")
+    for name in ("kat_tiny", "kat_heads8", "kat_odd"):
+        v = torch.from_numpy(g[name + ".value"]); loc = torch.from_numpy(g[name + ".loc"])
+        aw = torch.from_numpy(g[name + ".aw"]); shapes = [tuple(s) for s in g[name + ".shapes"]]
+        o = O.msda_core(v, shapes, loc, aw)
+        assert torch.allclose(o, torch.from_numpy(g[name + ".out"]), atol=1e-7, rtol=1e-5), name
+        o64 = O.msda_core(v.double(), shapes, loc.double(), aw.double())
+        assert torch.allclose(o64, torch.from_numpy(g[name + ".out_f64"]), atol=1e-12, rtol=1e-9), name
+
+
+def test_qim_isolated():
+    g = golden("qim")
+    _, arch, sd = fixture("tiny")
+    t = f"model.{len(arch.layers)}.track_embed"
+    for n in (1, 7, 64):
+        i = {k: torch.from_numpy(g[f"n{n}.in.{k}"]) for k in ("ref_pts", "output_embedding", "query_pos", "pred_boxes")}
+        qp, rp = O.qim_update_track_embedding(i["ref_pts"], i["output_embedding"], i["query_pos"], i["pred_boxes"], sd, t)
+        assert torch.allclose(qp, torch.from_numpy(g[f"n{n}.out.query_pos"]), atol=2e-5)
+        assert torch.allclose(rp, torch.from_numpy(g[f"n{n}.out.ref_pts"]), atol=1e-6)
+
+
+def test_filter_and_copy_semantics():
+    b = np.array([[.5, .5, .2, .2], [.5, .5, .2, .21], [.1, .1, .05, .05], [.5, .5, .2, .2]], np.float32)
+    assert O.filter_tracks(b) == [True, False, True, False]
+    rows, ids = O.tracker_update_copy([.9, .9, .9, .9], b, [0, 1, 2, 3])
+    assert rows == [0, 2] and ids == [0, 1]
