@@ -1,0 +1,206 @@
+/*
+ * moyolo.h -- C ABI of libmoyolo.so: MI355X (gfx950) kernels for the DecoderTracker per-frame
+ * tracking inference path.  Plain C: raw device pointers, integer shapes,
+ * a hipStream_t passed as void*.  No torch types.
+ *
+ * Conventions ("Native op" row):
+ *   - every entry point only ENQUEUES work on the caller's stream; no allocation, no sync, no
+ *     global state (graph-capturable, re-entrant);
+ *   - the caller owns every buffer; outputs need not be zero-initialised;
+ *   - return value 0 on success, a negative MOY_E* code otherwise (shape/argument errors are
+ *     detected on the host BEFORE anything is launched);
+ *   - dtype codes: MOY_F32 = 0, MOY_BF16 = 1.  "T" below means the dtype selected by `dtype`.
+ *   - activations are channels-last: an image tensor is [B, H, W, C] with a row (pixel) stride
+ *     `ld` in elements, so channel slices of wider (concat) buffers are addressed in place.
+ *
+ * Each entry cites the reference interface it replaces (paths relative to the reference root).
+ */
+#ifndef MOYOLO_H
+#define MOYOLO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOY_F32 0
+#define MOY_BF16 1
+
+#define MOY_OK 0
+#define MOY_EINVAL (-22)   /* bad shape / argument */
+#define MOY_ENOSYS (-38)   /* combination not implemented */
+#define MOY_ELAUNCH (-5)   /* hipLaunch error */
+
+#define MOY_ACT_NONE 0
+#define MOY_ACT_SILU 1
+#define MOY_ACT_RELU 2
+#define MOY_ACT_SIGMOID 3
+
+/* ABI/version probe. */
+int moy_version(void);
+/* Human-readable text for a MOY_E* code. */
+const char* moy_strerror(int code);
+
+/* --------------------------------------------------------------------------------------------
+ * Fused implicit-GEMM:  C[m, n] = epilogue( sum_k A(m, k) * W[n, k] )
+ *
+ * Replaces, on the hot path: Conv.forward (ultralytics/nn/modules/conv.py:36-38, Conv2d+BN+SiLU),
+ * the 1x1/3x3 convs inside C2f/Bottleneck/SPPF (nn/modules/block.py:129-134,178-182,281-283),
+ * MYDecoder.input_proj (nn/modules/head.py:838-839,1012-1029) and every nn.Linear of
+ * MYDecoder / MOTRDecoderLayer / MSDeformAttn / MLP (head.py:1031-1113, transformer.py:149-161,
+ * 246-287, 627-652), each with its BN / bias / activation / residual / LayerNorm fused.
+ *
+ * A operand (channels-last activations, dtype T):
+ *   ksize == 1: row m of A is A[arow(m) * lda + k];  arow(m) = a_rows ? a_rows[m] : m
+ *   ksize == 3: m = (b, oy, ox) over [B, Hout, Wout]; k = (ky*3+kx)*Cin + c; the element is
+ *               A[((b*Hin + oy*stride+ky-1)*Win + ox*stride+kx-1) * lda + c], 0 outside the image
+ *               (pad = 1).  Cin must be a power of two >= 8 (bf16) / 4 (f32).
+ *   A2 (optional, ksize 1 only): added element-wise to A before the product (q = k = x + pos).
+ *   a_mask (optional, ksize 1 only): rows with a_mask[m % mask_period] == 0 read as zero
+ *               (valid_mask * feats, head.py:1039).
+ * W: [N, Kpad] dtype T, K contiguous, Kpad = K rounded up to 64 (bf16) / 32 (f32), zero padded.
+ * Epilogue, in this order (all optional, fp32 math):
+ *   v = acc * scale[n] + shift[n]   (BN folded to scale/shift, or bias with scale == NULL)
+ *   v = act(v)
+ *   v += R[m * ldr + n]             (residual, dtype T)
+ *   v = LayerNorm_n(v) * ln_g[n] + ln_b[n]   (eps 1e-5; requires N == 256)
+ *   C[m * ldc + n] = v              (dtype T, or fp32 when out_f32 != 0)
+ * -------------------------------------------------------------------------------------------- */
+typedef struct moy_gemm_args {
+  const void* A;
+  const void* A2;
+  const int32_t* a_rows;
+  const uint8_t* a_mask;
+  int32_t mask_period;
+  int64_t lda;
+  const void* W;
+  int32_t M, N, K;        /* K = ksize*ksize*Cin (unpadded) */
+  int32_t ksize, stride;  /* ksize 1 or 3; stride 1 or 2 */
+  int32_t B, Hin, Win, Hout, Wout, Cin; /* used when ksize == 3 */
+  const float* scale;
+  const float* shift;
+  int32_t act;
+  const void* R;
+  int64_t ldr;
+  const float* ln_g;
+  const float* ln_b;
+  void* C;
+  int64_t ldc;
+  int32_t out_f32;
+  int32_t dtype;
+  /* optional output row remap (0 = off): row m is stored at C row
+   * (m / c_rows_per_batch) * c_batch_stride + m % c_rows_per_batch -- lets one launch scatter the
+   * [B, h*w] rows of a pyramid level into the level-major [B, S] token buffer (head.py:1023-1028). */
+  int32_t c_rows_per_batch;
+  int32_t c_batch_stride;
+} moy_gemm_args;
+
+int moy_gemm(const moy_gemm_args* args, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Stem: fused preprocess + first Conv (3x3, stride 2, Cin = 3) + BN + SiLU.
+ * Replaces BasePredictor.preprocess (ultralytics/engine/predictor.py:117-134: BGR->RGB, HWC->CHW,
+ * float, /255) fused into layer 0 Conv.forward (conv.py:36-38; yolo_track.yaml:17).
+ *   in_fmt 0: uint8  [B, H, W, 3] BGR   (value/255 computed in fp32 exactly as the reference)
+ *   in_fmt 1: float32 [B, 3, H, W] RGB in [0, 1] (LoadTensor source, data/loaders.py:316-332)
+ *   w: fp32 [27, Cout] (k = (ky*3+kx)*3 + c_rgb, Cout contiguous); scale/shift fp32 [Cout]
+ *   out: T [B, H/2, W/2, Cout] with pixel stride ldc.   Cout multiple of 8, <= 64.
+ * -------------------------------------------------------------------------------------------- */
+int moy_stem_conv(const void* in, int in_fmt, int B, int H, int W, const float* w, const float* scale,
+                  const float* shift, int Cout, void* out, int64_t ldc, int dtype, void* stream);
+
+/* SPPF pooling: y1 = maxpool5(x), y2 = maxpool5(y1), y3 = maxpool5(y2) (stride 1, pad 2, -inf
+ * padding) == windows 5/9/13 of x.  Replaces the three nn.MaxPool2d calls of SPPF.forward
+ * (nn/modules/block.py:129-134).  x: T [B,H,W,C] stride ldx; y1..y3: stride ldy. C % 8 == 0. */
+int moy_sppf_pool(const void* x, int64_t ldx, int B, int H, int W, int C, void* y1, void* y2, void* y3,
+                  int64_t ldy, int dtype, void* stream);
+
+/* Nearest 2x upsample into a channel slice: nn.Upsample(None, 2, 'nearest') + Concat
+ * (yolo_track.yaml:28-33; conv.py:295-297).  x [B,H,W,C] -> y [B,2H,2W,C]. C % 8 == 0. */
+int moy_upsample2x(const void* x, int64_t ldx, int B, int H, int W, int C, void* y, int64_t ldy, int dtype,
+                   void* stream);
+
+/* Narrow linear heads, N <= 8 outputs per row, one wavefront per row (K % 64 == 0, K <= 1024):
+ *   y[m, j] = sum_k X[xrow(m)*ldx + k] * Wt[j*K + k] + bias[j]      (X dtype T; Wt, bias, y fp32)
+ * mode 0: plain                     (enc_score_head / dec_score_head, head.py:852,856)
+ * mode 1: y = sigmoid(y + inverse_sigmoid(ref[m, j])), N == 4
+ *         (box refinement, transformer.py:709; inverse_sigmoid eps 1e-5, nn/modules/utils.py:34-38)
+ * mode 2: y = y + aux[aux_rows[m], j], N == 4           (enc_bbox_head + anchors, head.py:1045)
+ * x_rows (optional) gathers input rows (top-k selected tokens). */
+int moy_rowdot(const void* X, int64_t ldx, const int32_t* x_rows, int M, int K, const float* Wt,
+               const float* bias, int N, int mode, const float* aux, const int32_t* aux_rows, float* y, int dtype,
+               void* stream);
+
+/* Query selection: per frame b, indices of the nq largest max_c scores[b, s, c], sorted
+ * descending (torch.topk(enc_outputs_scores.max(-1).values, nq), head.py:1048).  Ties: lower
+ * token index first.  scores fp32 [B, S, nc].  valid (optional) uint8 [S]: n_masked[b] receives
+ * the number of selected tokens with valid == 0 (the +inf-anchor / NaN hazard of SURVEY 0.6).
+ * idx_local int32 [B, nq] in [0, S); idx_global int32 [B, nq] = b*S + idx_local. */
+int moy_topk(const float* scores, int B, int S, int nc, int nq, const uint8_t* valid, int32_t* idx_local,
+             int32_t* idx_global, int32_t* n_masked, void* stream);
+
+/* pos2posemb (nn/modules/transformer.py:183-190): boxes fp32 [M, 4] (logits) -> T [M, 256]. */
+int moy_pos2posemb(const float* pos, int M, void* out, int64_t ldo, int dtype, void* stream);
+
+/* Multi-head self-attention core of nn.MultiheadAttention(256, 8) as used by
+ * MOTRDecoderLayer.forward (transformer.py:637-640) and QIM (MOTR/models/qim.py:275):
+ * qkv T [B, L, 3*E] (q | k | v projections incl. bias), out T [B, L, E];
+ * softmax_j(q_i . k_j / sqrt(E/nh)) v_j per head.  E/nh must be 32. */
+int moy_mha_core(const void* qkv, int64_t ld_qkv, int B, int L, int nh, int E, void* out, int64_t ldo, int dtype,
+                 void* stream);
+
+/* Fused deformable-attention sampling for the decoder (MSDeformAttn.forward transformer.py:267-285
+ * after the three projections): softmax over the L*P attention logits, sampling locations
+ * loc = ref_xy + off / P * ref_wh * 0.5, bilinear gather (zeros padding, align_corners=False),
+ * weighted sum.  M = 8 heads x D = 32, L <= 4 levels, P = 4 points.
+ *   value T [B, S, ldv] (head-major channels m*32+d), offaw fp32 [B*Lq, ld_oa]: columns
+ *   [0, M*L*P*2) = offsets ([m][l][p][xy]) then [.., + M*L*P) = attention logits ([m][l*p]);
+ *   ref fp32 [B*Lq, 4] (cx, cy, w, h in [0,1]); shapes int32 [L][2] = (H, W) on the HOST.
+ *   out T [B*Lq, ldo]. */
+int moy_msda_fused(const void* value, int64_t ldv, int B, int S, const int32_t* shapes_hw, int L, const float* offaw,
+                   int64_t ld_oa, const float* ref, int Lq, void* out, int64_t ldo, int dtype, void* stream);
+
+/* The reference's own native operator, MultiScaleDeformableAttention.ms_deform_attn_forward
+ * (MOTR/models/ops/src/vision.cpp:13-16, src/ms_deform_attn.h:21-40, CUDA kernel
+ * src/cuda/ms_deform_im2col_cuda.cuh:237-299), same argument meaning:
+ *   value [N, S, M, D], spatial_shapes int64 [L, 2] (H, W) and level_start_index int64 [L] in
+ *   DEVICE memory, sampling_loc [N, Lq, M, L, P, 2], attn_weight [N, Lq, M, L, P] -> out [N, Lq, M*D].
+ * The reference dispatches fp32/fp64 only (ms_deform_attn_cuda.cu:64); bf16 is added here. */
+int moy_msda_fwd_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                     const float* sampling_loc, const float* attn_weight, int N, int S, int M, int D, int L, int Lq,
+                     int P, float* out, void* stream);
+int moy_msda_fwd_bf16(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                      const void* sampling_loc, const void* attn_weight, int N, int S, int M, int D, int L, int Lq,
+                      int P, void* out, void* stream);
+
+/* Per-frame ID assignment + predictor rows.  Replaces the host state machine
+ * MOTRTrack._post_process_single_image / RuntimeTrackerBase.update (head.py:300-323,1232-1237) in
+ * its shipped per-frame-reset semantics and TrackPredictor.postprocess
+ * (ultralytics/models/MOTRtrack/predict.py:43-76) + ops.xywh2xyxy (utils/ops.py:378-393).
+ *   logits fp32 [B, nq, nc], boxes fp32 [B, nq, 4] (cx, cy, w, h normalised)
+ *   y fp32 [B, nq, 4+nc]   = cat(boxes, sigmoid(logits))              (head.py:235)
+ *   scores fp32 [B, nq]     = max_c sigmoid(logits)                    (head.py:310)
+ *   obj_idxes int64 [B, nq] = running counter over rows with score >= score_thresh, else -1
+ *   rows fp32 [B, nq, 6], track_id int64 [B, nq], n_rows/n_ids int32 [B]:
+ *     active rows (id >= 0) in query order; rows keeps those with score > conf as
+ *     (x1, y1, x2, y2, score, cls) scaled by (img_w, img_h) (pass 1,1 for the tensor-source
+ *     branch); track_id keeps ALL active ids (not conf-filtered, predict.py:61-76).
+ *     If no row is active the detection fallback (predict.py:79-94) is produced and n_ids = -1. */
+int moy_assign_post(const float* logits, const float* boxes, int B, int nq, int nc, float score_thresh, float conf,
+                    float img_w, float img_h, float* y, float* scores, int64_t* obj_idxes, float* rows,
+                    int64_t* track_id, int32_t* n_rows, int32_t* n_ids, void* stream);
+
+/* Elementwise helpers. */
+/* dst T [M, N] (ldd) = src T [rows[m], :] (lds): row gather (features[batch_ind, topk_ind], head.py:1096). N % 8 == 0. */
+int moy_gather_rows(const void* src, int64_t lds, const int32_t* rows, int M, int N, void* dst, int64_t ldd, int dtype,
+                    void* stream);
+/* dst T [M, N] (ldd) = src fp32 [M, N] (lds): cast, used at fp32->bf16 seams. */
+int moy_cast_f32_to(const float* src, int64_t lds, int M, int N, void* dst, int64_t ldd, int dtype, void* stream);
+/* out fp32 [M, 4] = sigmoid(in fp32 [M, 4])  (refer_bbox.sigmoid(), transformer.py:694; enc_bboxes head.py:1080) */
+int moy_sigmoid_f32(const float* in, int n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOYOLO_H */

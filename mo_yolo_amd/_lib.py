@@ -1,0 +1,80 @@
+"""ctypes binding of libmoyolo.so (the C ABI declared in include/moyolo.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent the import of any
+compute entry point raises.  (The CPU oracle lives in /oracle and is test infrastructure only.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmoyolo.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class GemmArgs(C.Structure):
+    """Mirror of `moy_gemm_args` (include/moyolo.h)."""
+    _fields_ = [
+        ("A", vp), ("A2", vp), ("a_rows", vp), ("a_mask", vp), ("mask_period", i32), ("lda", i64),
+        ("W", vp), ("M", i32), ("N", i32), ("K", i32), ("ksize", i32), ("stride", i32),
+        ("B", i32), ("Hin", i32), ("Win", i32), ("Hout", i32), ("Wout", i32), ("Cin", i32),
+        ("scale", vp), ("shift", vp), ("act", i32), ("R", vp), ("ldr", i64), ("ln_g", vp), ("ln_b", vp),
+        ("C", vp), ("ldc", i64), ("out_f32", i32), ("dtype", i32),
+        ("c_rows_per_batch", i32), ("c_batch_stride", i32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/moyolo.h
+SIGNATURES = {
+    "moy_version": (C.c_int, []),
+    "moy_strerror": (C.c_char_p, [C.c_int]),
+    "moy_gemm": (C.c_int, [C.POINTER(GemmArgs), vp]),
+    "moy_stem_conv": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, i64, C.c_int, vp]),
+    "moy_sppf_pool": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, i64, C.c_int, vp]),
+    "moy_upsample2x": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
+    "moy_rowdot": (C.c_int, [vp, i64, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]),
+    "moy_topk": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    "moy_pos2posemb": (C.c_int, [vp, C.c_int, vp, i64, C.c_int, vp]),
+    "moy_mha_core": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
+    "moy_msda_fused": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, C.c_int, vp, i64, vp, C.c_int, vp, i64, C.c_int, vp]),
+    "moy_msda_fwd_f32": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp, vp]),
+    "moy_msda_fwd_bf16": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp, vp]),
+    "moy_assign_post": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, f32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "moy_gather_rows": (C.c_int, [vp, i64, vp, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
+    "moy_cast_f32_to": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
+    "moy_sigmoid_f32": (C.c_int, [vp, C.c_int, vp, vp]),
+}
+
+_lib = None
+
+
+class MoyoloError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libmoyolo.so (once).  Raises if it has not been built -- no silent fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MoyoloError(
+                f"{LIB_PATH} is missing: build it with `python -m mo_yolo_amd.build` (hipcc, gfx950). "
+                "mo_yolo_amd has no CPU or eager fallback for its compute path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the ABI drifted
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().moy_strerror(rc).decode()
+        raise MoyoloError(f"{what or 'libmoyolo'} failed: {msg} (code {rc})")

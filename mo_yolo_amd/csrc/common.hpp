@@ -1,0 +1,84 @@
+// Shared device helpers for the gfx950 kernels of libmoyolo.so (wave64 everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/moyolo.h"
+
+namespace moy {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct bf16_t {
+  uint16_t v;
+};
+
+__device__ __forceinline__ float bf2f(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+// plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN preserving) on gfx950
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bflo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bfhi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+template <typename T>
+struct DT;  // elements per 16-byte chunk, load/store of 4 consecutive elements as fp32
+template <>
+struct DT<float> {
+  static constexpr int KPB = 4;
+  static constexpr int code = MOY_F32;
+  static __device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+  static __device__ __forceinline__ float load1(const float* p) { return *p; }
+  static __device__ __forceinline__ void store1(float* p, float v) { *p = v; }
+};
+template <>
+struct DT<bf16_t> {
+  static constexpr int KPB = 8;
+  static constexpr int code = MOY_BF16;
+  static __device__ __forceinline__ f32x4 load4(const bf16_t* p) {
+    u32x2 w = *reinterpret_cast<const u32x2*>(p);
+    return f32x4{bflo(w.x), bfhi(w.x), bflo(w.y), bfhi(w.y)};
+  }
+  static __device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
+    *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
+  }
+  static __device__ __forceinline__ float load1(const bf16_t* p) { return bf2f(p->v); }
+  static __device__ __forceinline__ void store1(bf16_t* p, float v) { p->v = f2bf(v); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case MOY_ACT_SILU: return siluf_(v);
+    case MOY_ACT_RELU: return fmaxf(v, 0.0f);
+    case MOY_ACT_SIGMOID: return sigmoidf_(v);
+    default: return v;
+  }
+}
+
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MOY_OK : MOY_ELAUNCH;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace moy

@@ -1,0 +1,789 @@
+// Non-GEMM kernels of the tracking path for gfx950 (wave64): stem conv with fused preprocess,
+// SPPF pooling, nearest upsample, narrow row-dot heads, query top-k, positional embedding,
+// self-attention core, deformable-attention sampling, ID assignment + predictor rows.
+// All HBM-side accesses are 8/16-byte vectors over channels-last rows; reductions and softmax use
+// wave shuffles; nothing here allocates or synchronises.
+#include "common.hpp"
+
+namespace moy {
+
+// ------------------------------------------------------------------------------------------------
+// Stem: preprocess (uint8 BGR HWC -> RGB /255, predictor.py:125-133) fused into the first
+// 3x3 stride-2 conv + BN + SiLU (conv.py:36-38).  One thread = one output pixel, all COUT channels;
+// the 27 x COUT weights live in LDS and are read as wave-uniform broadcasts.
+template <typename T, int COUT, int FMT>
+__global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ in, int B, int H, int W,
+                                                   const float* __restrict__ w, const float* __restrict__ scale,
+                                                   const float* __restrict__ shift, T* __restrict__ out, int64_t ldc) {
+  __shared__ float ws[27 * COUT];
+  __shared__ float ss[2 * COUT];
+  for (int i = threadIdx.x; i < 27 * COUT; i += 256) ws[i] = w[i];
+  for (int i = threadIdx.x; i < COUT; i += 256) { ss[i] = scale[i]; ss[COUT + i] = shift[i]; }
+  __syncthreads();
+  const int Ho = H >> 1, Wo = W >> 1;
+  const long total = (long)B * Ho * Wo;
+  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= total) return;
+  const int b = (int)(pix / ((long)Ho * Wo));
+  const int rem = (int)(pix - (long)b * Ho * Wo);
+  const int oy = rem / Wo, ox = rem - oy * Wo;
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+#pragma unroll 1
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * 2 + ky - 1;
+#pragma unroll 1
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox * 2 + kx - 1;
+      float v[3] = {0.f, 0.f, 0.f};   // RGB
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+        if (FMT == 0) {
+          const uint8_t* p = static_cast<const uint8_t*>(in) + (((long)b * H + iy) * W + ix) * 3;
+          v[0] = (float)p[2] / 255.0f; v[1] = (float)p[1] / 255.0f; v[2] = (float)p[0] / 255.0f;
+        } else {
+          const float* p = static_cast<const float*>(in) + ((long)b * 3 * H + iy) * W + ix;
+          v[0] = p[0]; v[1] = p[(long)H * W]; v[2] = p[2L * H * W];
+        }
+      }
+#pragma unroll 1
+      for (int ci = 0; ci < 3; ++ci) {
+        const float* wr = ws + ((ky * 3 + kx) * 3 + ci) * COUT;
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v[ci], wr[c], acc[c]);
+      }
+    }
+  }
+  T* o = out + pix * ldc;
+#pragma unroll
+  for (int c = 0; c < COUT; c += 4) {
+    f32x4 y;
+    y.x = siluf_(acc[c] * ss[c] + ss[COUT + c]);
+    y.y = siluf_(acc[c + 1] * ss[c + 1] + ss[COUT + c + 1]);
+    y.z = siluf_(acc[c + 2] * ss[c + 2] + ss[COUT + c + 2]);
+    y.w = siluf_(acc[c + 3] * ss[c + 3] + ss[COUT + c + 3]);
+    DT<T>::store4(o + c, y);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SPPF: windows 5 / 9 / 13 (== three cascaded 5x5 stride-1 max pools with -inf padding).
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_pool_kernel(const T* __restrict__ x, int64_t ldx, int B, int H, int W, int C,
+                                                        T* __restrict__ y1, T* __restrict__ y2, T* __restrict__ y3,
+                                                        int64_t ldy) {
+  const int cpr = C >> 2;
+  const long total = (long)B * H * W * cpr;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int cc = (int)(t % cpr);
+  const long pix = t / cpr;
+  const int b = (int)(pix / ((long)H * W));
+  const int rem = (int)(pix - (long)b * H * W);
+  const int y = rem / W, xx = rem - y * W;
+  const float ninf = -INFINITY;
+  f32x4 m5 = {ninf, ninf, ninf, ninf}, m9 = m5, m13 = m5;
+  for (int dy = -6; dy <= 6; ++dy) {
+    const int iy = y + dy;
+    if ((unsigned)iy >= (unsigned)H) continue;
+    const int ady = dy < 0 ? -dy : dy;
+    for (int dx = -6; dx <= 6; ++dx) {
+      const int ix = xx + dx;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      const int adx = dx < 0 ? -dx : dx;
+      const int rad = ady > adx ? ady : adx;
+      const f32x4 v = DT<T>::load4(x + (((long)b * H + iy) * W + ix) * ldx + cc * 4);
+      m13 = __builtin_elementwise_max(m13, v);
+      if (rad <= 4) m9 = __builtin_elementwise_max(m9, v);
+      if (rad <= 2) m5 = __builtin_elementwise_max(m5, v);
+    }
+  }
+  DT<T>::store4(y1 + pix * ldy + cc * 4, m5);
+  DT<T>::store4(y2 + pix * ldy + cc * 4, m9);
+  DT<T>::store4(y3 + pix * ldy + cc * 4, m13);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ x, int64_t ldx, int B, int H, int W, int C,
+                                                         T* __restrict__ y, int64_t ldy) {
+  constexpr int KPB = DT<T>::KPB;
+  const int cpr = C / KPB;
+  const long total = (long)B * 4 * H * W * cpr;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int cc = (int)(t % cpr);
+  const long pix = t / cpr;
+  const int Wo = 2 * W, Ho = 2 * H;
+  const int b = (int)(pix / ((long)Ho * Wo));
+  const int rem = (int)(pix - (long)b * Ho * Wo);
+  const int oy = rem / Wo, ox = rem - oy * Wo;
+  const u32x4 v = *reinterpret_cast<const u32x4*>(x + (((long)b * H + (oy >> 1)) * W + (ox >> 1)) * ldx + cc * KPB);
+  *reinterpret_cast<u32x4*>(y + pix * ldy + cc * KPB) = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Narrow heads: one wave per row, N <= 8 dot products reduced with shuffles.
+__device__ __forceinline__ float inv_sigmoid(float x) {   // nn/modules/utils.py:34-38, eps 1e-5
+  x = fminf(fmaxf(x, 0.f), 1.f);
+  return logf(fmaxf(x, 1e-5f) / fmaxf(1.f - x, 1e-5f));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ X, int64_t ldx, const int32_t* __restrict__ x_rows,
+                                                     int M, int K, const float* __restrict__ Wt,
+                                                     const float* __restrict__ bias, int N, int mode,
+                                                     const float* __restrict__ aux, const int32_t* __restrict__ aux_rows,
+                                                     float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const long row = x_rows ? (long)x_rows[m] : (long)m;
+  const T* xr = X + row * ldx;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {
+    const f32x4 xv = DT<T>::load4(xr + k);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < N) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(Wt + (long)j * K + k);
+        acc[j] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (j < N) acc[j] = wave_sum(acc[j]);
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < N) {
+        float v = acc[j] + (bias ? bias[j] : 0.f);
+        if (mode == 1) v = sigmoidf_(v + inv_sigmoid(aux[(long)m * N + j]));
+        else if (mode == 2) v = v + aux[(long)aux_rows[m] * N + j];
+        y[(long)m * N + j] = v;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Query selection: exact radix select of the nq largest scores + bitonic sort of the selection.
+__device__ __forceinline__ uint32_t order_key(float f) {   // monotone: larger float -> larger key
+  const uint32_t u = __builtin_bit_cast(uint32_t, f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float score_max(const float* __restrict__ s, int nc) {
+  float v = s[0];
+  for (int c = 1; c < nc; ++c) v = fmaxf(v, s[c]);   // torch .max(-1): NaN-free fixtures
+  return v;
+}
+
+constexpr int TOPK_THREADS = 1024;
+
+__global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restrict__ scores, int S, int nc, int nq, int P2,
+                                                            const uint8_t* __restrict__ valid,
+                                                            int32_t* __restrict__ idx_local, int32_t* __restrict__ idx_global,
+                                                            int32_t* __restrict__ n_masked) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sh_prefix, sh_remaining, sh_cnt, sh_masked;
+  __shared__ uint32_t scan[TOPK_THREADS];
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(dyn);   // [P2]
+
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* sc = scores + (long)b * S * nc;
+
+  if (tid == 0) { sh_prefix = 0; sh_remaining = nq; sh_cnt = 0; sh_masked = 0; }
+  uint32_t mask = 0;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const uint32_t prefix = sh_prefix;
+    for (int i = tid; i < S; i += TOPK_THREADS) {
+      const uint32_t u = order_key(score_max(sc + (long)i * nc, nc));
+      if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t rem = sh_remaining, cum = 0;
+      int d = 255;
+      for (; d > 0; --d) {
+        if (cum + hist[d] >= rem) break;
+        cum += hist[d];
+      }
+      sh_remaining = rem - cum;         // still needed from bucket d
+      sh_prefix = prefix | ((uint32_t)d << shift);
+    }
+    mask |= 255u << shift;
+    __syncthreads();
+  }
+  const uint32_t thr = sh_prefix;        // key of the nq-th largest value
+  const uint32_t need_eq = sh_remaining; // how many elements equal to thr are taken (lowest index first)
+
+  // ties: ordered ranks over contiguous index ranges
+  const int per = (S + TOPK_THREADS - 1) / TOPK_THREADS;
+  const int i0 = tid * per, i1 = min(S, i0 + per);
+  uint32_t my_eq = 0;
+  for (int i = i0; i < i1; ++i) my_eq += order_key(score_max(sc + (long)i * nc, nc)) == thr;
+  scan[tid] = my_eq;
+  __syncthreads();
+  for (int off = 1; off < TOPK_THREADS; off <<= 1) {   // Hillis-Steele inclusive scan
+    const uint32_t v = tid >= off ? scan[tid - off] : 0;
+    __syncthreads();
+    scan[tid] += v;
+    __syncthreads();
+  }
+  uint32_t eq_rank = scan[tid] - my_eq;
+  for (int i = tid; i < P2; i += TOPK_THREADS) keys[i] = ~0ull;   // padding sorts last
+  __syncthreads();
+  for (int i = i0; i < i1; ++i) {
+    const uint32_t u = order_key(score_max(sc + (long)i * nc, nc));
+    bool take = u > thr;
+    if (u == thr) { take = eq_rank < need_eq; ++eq_rank; }
+    if (take) {
+      const uint32_t pos = atomicAdd(&sh_cnt, 1u);
+      keys[pos] = ((unsigned long long)(~u) << 32) | (uint32_t)i;   // ascending = value desc, index asc
+    }
+  }
+  __syncthreads();
+  // bitonic sort of P2 64-bit keys
+  for (int k = 2; k <= P2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P2; i += TOPK_THREADS) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = keys[i], c = keys[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > c) == up) { keys[i] = c; keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < nq; i += TOPK_THREADS) {
+    const int id = (int)(keys[i] & 0xffffffffu);
+    idx_local[(long)b * nq + i] = id;
+    idx_global[(long)b * nq + i] = b * S + id;
+    if (valid && valid[id] == 0) atomicAdd(&sh_masked, 1u);
+  }
+  __syncthreads();
+  if (tid == 0 && n_masked) n_masked[b] = (int)sh_masked;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pos2posemb (transformer.py:183-190): out[m, c*64 + 2i] = sin(p / t_i), [.. + 2i+1] = cos(p / t_i),
+// p = pos[m, c] * 2*pi, t_i = 10000^(2i/64).
+template <typename T>
+__global__ __launch_bounds__(256) void posemb_kernel(const float* __restrict__ pos, int M, T* __restrict__ out, int64_t ldo) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;   // one thread per (m, c, i): 128 per row
+  if (t >= (long)M * 128) return;
+  const int m = (int)(t >> 7), ci = (int)(t & 127), c = ci >> 5, i = ci & 31;
+  const float p = pos[(long)m * 4 + c] * 6.283185307179586f;
+  const float dim_t = powf(10000.0f, (float)(2 * i) / 64.0f);
+  const float a = p / dim_t;
+  T* o = out + (long)m * ldo + c * 64 + 2 * i;
+  DT<T>::store1(o, sinf(a));
+  DT<T>::store1(o + 1, cosf(a));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Self-attention core, head dim 32.  Block = (b, head, 64-query tile); K (padded rows) and V of the
+// (b, head) pair staged in LDS as fp32; per query: lane-parallel q.k over keys, wave-shuffle
+// softmax, probabilities through a wave-private LDS row, PV with lanes = 2 key halves x 32 dims.
+constexpr int MHA_QT = 64;
+
+template <typename T>
+__global__ __launch_bounds__(256) void mha_kernel(const T* __restrict__ qkv, int64_t ld, int L, int nh, int E,
+                                                  T* __restrict__ out, int64_t ldo) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  float* Ks = reinterpret_cast<float*>(dyn);          // [L][33]
+  float* Vs = Ks + (long)L * 33;                      // [L][32]
+  float* Ps = Vs + (long)L * 32;                      // [4][Lp]
+  const int Lp = (L + 63) & ~63;
+  const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const T* base = qkv + (long)b * L * ld;
+  // stage K, V: 8 threads per key row, 4 elements each
+  for (int i = tid; i < L * 8; i += 256) {
+    const int j = i >> 3, d4 = (i & 7) * 4;
+    const f32x4 kv = DT<T>::load4(base + (long)j * ld + E + h * 32 + d4);
+    const f32x4 vv = DT<T>::load4(base + (long)j * ld + 2 * E + h * 32 + d4);
+    float* kd = Ks + j * 33 + d4;
+    kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+    *reinterpret_cast<f32x4*>(Vs + j * 32 + d4) = vv;
+  }
+  __syncthreads();
+  float* P = Ps + wave * Lp;
+  const float scaling = 0.17677669529663687f;   // 32^-0.5, applied to q before QK^T (torch MHA)
+  const int q_begin = blockIdx.y * MHA_QT;
+  const int nkeys = (L + 63) >> 6;
+  for (int qi = q_begin + wave; qi < min(L, q_begin + MHA_QT); qi += 4) {
+    float qv[32];
+    const T* qp = base + (long)qi * ld + h * 32;
+#pragma unroll
+    for (int d = 0; d < 32; d += 4) {
+      const f32x4 t4 = DT<T>::load4(qp + d);
+      qv[d] = t4.x * scaling; qv[d + 1] = t4.y * scaling; qv[d + 2] = t4.z * scaling; qv[d + 3] = t4.w * scaling;
+    }
+    float s[8];
+    float mx = -INFINITY;
+    for (int t = 0; t < nkeys; ++t) {
+      const int j = lane + t * 64;
+      float a = -INFINITY;
+      if (j < L) {
+        const float* kr = Ks + j * 33;
+        a = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) a = fmaf(qv[d], kr[d], a);
+      }
+      s[t] = a;
+      mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int t = 0; t < nkeys; ++t) {
+      const int j = lane + t * 64;
+      const float e = j < L ? expf(s[t] - mx) : 0.f;
+      sum += e;
+      P[j] = e;
+    }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    const int d = lane & 31, half = lane >> 5;
+    const int jh = (L + 1) >> 1;
+    const int j0 = half * jh, j1 = min(L, j0 + jh);
+    float o = 0.f;
+    for (int j = j0; j < j1; ++j) o = fmaf(P[j], Vs[j * 32 + d], o);
+    o += __shfl_xor(o, 32, 64);
+    if (half == 0) DT<T>::store1(out + ((long)b * L + qi) * ldo + h * 32 + d, o / sum);
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Deformable attention, decoder form (M = 8 heads x D = 32, P = 4, L <= 4): one wave per query;
+// lane = head*8 + sub owns channels sub*4..+3 of its head.  Softmax over the L*P logits and the
+// sampling locations are recomputed per lane (12 exps), taps are 8/16-byte loads of contiguous
+// channels, accumulation in fp32.
+struct LevelInfo {
+  int H[4], W[4], start[4];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void msda_fused_kernel(const T* __restrict__ value, int64_t ldv, int S, LevelInfo lv, int L,
+                                                         const float* __restrict__ offaw, int64_t ld_oa,
+                                                         const float* __restrict__ ref, int Lq, int nrows,
+                                                         T* __restrict__ out, int64_t ldo) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int b = row / Lq;
+  const int m = lane >> 3, sub = lane & 7;
+  const int LP = L * 4;
+  const float* oa = offaw + (long)row * ld_oa;
+  const float* offp = oa + m * LP * 2;
+  const float* awp = oa + 8 * LP * 2 + m * LP;
+  float logit[16], offx[16], offy[16];
+#pragma unroll
+  for (int i = 0; i < 16; i += 4)
+    if (i < LP) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(awp + i);
+      logit[i] = a.x; logit[i + 1] = a.y; logit[i + 2] = a.z; logit[i + 3] = a.w;
+      const f32x4 o0 = *reinterpret_cast<const f32x4*>(offp + 2 * i), o1 = *reinterpret_cast<const f32x4*>(offp + 2 * i + 4);
+      offx[i] = o0.x; offy[i] = o0.y; offx[i + 1] = o0.z; offy[i + 1] = o0.w;
+      offx[i + 2] = o1.x; offy[i + 2] = o1.y; offx[i + 3] = o1.z; offy[i + 3] = o1.w;
+    }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (i < LP) mx = fmaxf(mx, logit[i]);
+  float den = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (i < LP) { logit[i] = expf(logit[i] - mx); den += logit[i]; }
+  const float inv_den = 1.0f / den;
+  const f32x4 rb = *reinterpret_cast<const f32x4*>(ref + (long)row * 4);
+  const T* vb = value + (long)b * S * ldv + m * 32 + sub * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+    if (l < L) {
+      const int H = lv.H[l], W = lv.W[l];
+      const T* vl = vb + (long)lv.start[l] * ldv;
+#pragma unroll
+      for (int pnt = 0; pnt < 4; ++pnt) {
+        const int i = l * 4 + pnt;
+        // loc = ref_xy + off / n_points * ref_wh * 0.5   (transformer.py:280-282)
+        const float lx = rb.x + offx[i] / 4.0f * rb.z * 0.5f;
+        const float ly = rb.y + offy[i] / 4.0f * rb.w * 0.5f;
+        const float x = lx * W - 0.5f, y = ly * H - 0.5f;
+        const float aw = logit[i] * inv_den;
+        const float xf = floorf(x), yf = floorf(y);
+        const float fx = x - xf, fy = y - yf;
+        const int x0 = (int)xf, y0 = (int)yf;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
+          const float wgt = ((t & 1) ? fx : 1.f - fx) * ((t >> 1) ? fy : 1.f - fy) * aw;
+          if ((unsigned)xi < (unsigned)W && (unsigned)yi < (unsigned)H)
+            acc += DT<T>::load4(vl + ((long)yi * W + xi) * ldv) * wgt;
+        }
+      }
+    }
+  DT<T>::store4(out + (long)row * ldo + m * 32 + sub * 4, acc);
+}
+
+// Generic operator form (reference plugin API): one thread per output scalar, d fastest.
+template <typename T>
+__global__ __launch_bounds__(256) void msda_generic_kernel(const T* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                           const int64_t* __restrict__ lstart, const T* __restrict__ loc,
+                                                           const T* __restrict__ aw, int N, int S, int M, int D, int L,
+                                                           int Lq, int P, T* __restrict__ out) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)N * Lq * M * D;
+  if (t >= total) return;
+  const int d = (int)(t % D);
+  long r = t / D;
+  const int m = (int)(r % M); r /= M;
+  const int q = (int)(r % Lq);
+  const int n = (int)(r / Lq);
+  const T* lp = loc + ((((long)n * Lq + q) * M + m) * L) * P * 2;
+  const T* ap = aw + ((((long)n * Lq + q) * M + m) * L) * P;
+  float acc = 0.f;
+  for (int l = 0; l < L; ++l) {
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const T* vl = value + (((long)n * S + lstart[l]) * M + m) * D + d;
+    for (int p = 0; p < P; ++p) {
+      const float x = DT<T>::load1(lp + (l * P + p) * 2) * W - 0.5f;
+      const float y = DT<T>::load1(lp + (l * P + p) * 2 + 1) * H - 0.5f;
+      const float w = DT<T>::load1(ap + l * P + p);
+      const float xf = floorf(x), yf = floorf(y);
+      const float fx = x - xf, fy = y - yf;
+      const int x0 = (int)xf, y0 = (int)yf;
+      float s = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int xi = x0 + (tt & 1), yi = y0 + (tt >> 1);
+        if ((unsigned)xi < (unsigned)W && (unsigned)yi < (unsigned)H)
+          s += ((tt & 1) ? fx : 1.f - fx) * ((tt >> 1) ? fy : 1.f - fy) *
+               DT<T>::load1(vl + ((long)yi * W + xi) * (long)M * D);
+      }
+      acc += w * s;
+    }
+  }
+  DT<T>::store1(out + t, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ID assignment (per-frame reset semantics) + predictor rows.
+__device__ __forceinline__ int block_excl_scan(int v, int* wsum, int tid, int nthreads, int* total) {
+  const int lane = tid & 63, wave = tid >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+  const int nw = nthreads >> 6;
+  for (int w = 0; w < nw; ++w) {
+    if (w < wave) base += wsum[w];
+    tot += wsum[w];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(1024) void assign_post_kernel(const float* __restrict__ logits, const float* __restrict__ boxes,
+                                                           int nq, int nc, float score_thresh, float conf, float img_w,
+                                                           float img_h, float* __restrict__ y, float* __restrict__ scores,
+                                                           int64_t* __restrict__ obj_idxes, float* __restrict__ rows,
+                                                           int64_t* __restrict__ track_id, int32_t* __restrict__ n_rows,
+                                                           int32_t* __restrict__ n_ids) {
+  __shared__ int wsum[16];
+  const int b = blockIdx.x, i = threadIdx.x;
+  const bool in = i < nq;
+  float score = 0.f, cx = 0.f, cy = 0.f, w = 0.f, h = 0.f;
+  int cls = 0;
+  if (in) {
+    const float* lg = logits + ((long)b * nq + i) * nc;
+    const float* bx = boxes + ((long)b * nq + i) * 4;
+    float* yr = y + ((long)b * nq + i) * (4 + nc);
+    cx = bx[0]; cy = bx[1]; w = bx[2]; h = bx[3];
+    yr[0] = cx; yr[1] = cy; yr[2] = w; yr[3] = h;
+    float best_l = -INFINITY;
+    score = -INFINITY;
+    for (int c = 0; c < nc; ++c) {
+      const float pr = sigmoidf_(lg[c]);
+      yr[4 + c] = pr;
+      score = fmaxf(score, pr);
+      if (lg[c] > best_l) { best_l = lg[c]; cls = c; }
+    }
+    scores[(long)b * nq + i] = score;
+  }
+  const int born = in && score >= score_thresh;
+  int K;
+  const int id = block_excl_scan(born, wsum, i, 1024, &K);
+  if (in) obj_idxes[(long)b * nq + i] = born ? (int64_t)id : (int64_t)-1;
+  // predictor rows: active branch if K > 0 else detection fallback (predict.py:43-94)
+  const bool cand = in && (K > 0 ? born : true);
+  const int keep = cand && score > conf;
+  int nkeep;
+  const int pos = block_excl_scan(keep, wsum, i, 1024, &nkeep);
+  if (keep) {
+    float* r = rows + ((long)b * nq + pos) * 6;
+    // ops.xywh2xyxy then scale (predict.py:58-72)
+    r[0] = (cx - w / 2) * img_w; r[1] = (cy - h / 2) * img_h;
+    r[2] = (cx + w / 2) * img_w; r[3] = (cy + h / 2) * img_h;
+    r[4] = score; r[5] = (float)cls;
+  }
+  if (K > 0 && born) track_id[(long)b * nq + id] = (int64_t)id;
+  if (i == 0) { n_rows[b] = nkeep; n_ids[b] = K > 0 ? K : -1; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, int64_t lds_, int M, int N4, T* __restrict__ dst,
+                                                   int64_t ldd) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)M * N4) return;
+  const int m = (int)(t / N4), c = (int)(t % N4) * 4;
+  DT<T>::store4(dst + (long)m * ldd + c, *reinterpret_cast<const f32x4*>(src + (long)m * lds_ + c));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ src, int64_t lds_, const int32_t* __restrict__ rows,
+                                                          int M, int NC, T* __restrict__ dst, int64_t ldd) {
+  constexpr int KPB = DT<T>::KPB;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)M * NC) return;
+  const int m = (int)(t / NC), c = (int)(t % NC) * KPB;
+  *reinterpret_cast<u32x4*>(dst + (long)m * ldd + c) = *reinterpret_cast<const u32x4*>(src + (long)rows[m] * lds_ + c);
+}
+
+__global__ __launch_bounds__(256) void sigmoid_kernel(const float* __restrict__ in, int n, float* __restrict__ out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < n) out[t] = sigmoidf_(in[t]);
+}
+
+inline unsigned nblk(long total, int per = 256) { return (unsigned)((total + per - 1) / per); }
+
+}  // namespace moy
+
+using namespace moy;
+
+#define MOY_DISPATCH_T(dtype, ...)                          \
+  if ((dtype) == MOY_F32) { using T = float; __VA_ARGS__ }  \
+  else if ((dtype) == MOY_BF16) { using T = bf16_t; __VA_ARGS__ } \
+  else return MOY_EINVAL;
+
+extern "C" int moy_version(void) { return 100; }
+
+extern "C" const char* moy_strerror(int code) {
+  switch (code) {
+    case MOY_OK: return "ok";
+    case MOY_EINVAL: return "invalid shape or argument";
+    case MOY_ENOSYS: return "combination not implemented";
+    case MOY_ELAUNCH: return "HIP launch error";
+    default: return "unknown error";
+  }
+}
+
+template <typename T, int FMT>
+static int stem_launch(const void* in, int B, int H, int W, const float* w, const float* scale, const float* shift,
+                       int Cout, void* out, int64_t ldc, hipStream_t st) {
+  const long total = (long)B * (H / 2) * (W / 2);
+  T* o = static_cast<T*>(out);
+  switch (Cout) {
+    case 8: hipLaunchKernelGGL((stem_kernel<T, 8, FMT>), dim3(nblk(total)), dim3(256), 0, st, in, B, H, W, w, scale, shift, o, ldc); break;
+    case 16: hipLaunchKernelGGL((stem_kernel<T, 16, FMT>), dim3(nblk(total)), dim3(256), 0, st, in, B, H, W, w, scale, shift, o, ldc); break;
+    case 32: hipLaunchKernelGGL((stem_kernel<T, 32, FMT>), dim3(nblk(total)), dim3(256), 0, st, in, B, H, W, w, scale, shift, o, ldc); break;
+    case 64: hipLaunchKernelGGL((stem_kernel<T, 64, FMT>), dim3(nblk(total)), dim3(256), 0, st, in, B, H, W, w, scale, shift, o, ldc); break;
+    default: return MOY_ENOSYS;
+  }
+  return launch_status();
+}
+
+extern "C" int moy_stem_conv(const void* in, int in_fmt, int B, int H, int W, const float* w, const float* scale,
+                             const float* shift, int Cout, void* out, int64_t ldc, int dtype, void* stream) {
+  if (!in || !w || !scale || !shift || !out || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return MOY_EINVAL;
+  if (ldc < Cout || (ldc % 4) || (in_fmt != 0 && in_fmt != 1)) return MOY_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MOY_DISPATCH_T(dtype, {
+    if (reinterpret_cast<uintptr_t>(out) % (4 * sizeof(T))) return MOY_EINVAL;
+    return in_fmt == 0 ? stem_launch<T, 0>(in, B, H, W, w, scale, shift, Cout, out, ldc, st)
+                       : stem_launch<T, 1>(in, B, H, W, w, scale, shift, Cout, out, ldc, st);
+  })
+}
+
+extern "C" int moy_sppf_pool(const void* x, int64_t ldx, int B, int H, int W, int C, void* y1, void* y2, void* y3,
+                             int64_t ldy, int dtype, void* stream) {
+  if (!x || !y1 || !y2 || !y3 || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldx % 4) || (ldy % 4)) return MOY_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long total = (long)B * H * W * (C / 4);
+  MOY_DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((sppf_pool_kernel<T>), dim3(nblk(total)), dim3(256), 0, st, static_cast<const T*>(x), ldx, B, H, W, C,
+                       static_cast<T*>(y1), static_cast<T*>(y2), static_cast<T*>(y3), ldy);
+    return launch_status();
+  })
+}
+
+extern "C" int moy_upsample2x(const void* x, int64_t ldx, int B, int H, int W, int C, void* y, int64_t ldy, int dtype,
+                              void* stream) {
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (ldy % 8)) return MOY_EINVAL;
+  if (!aligned16(x) || !aligned16(y)) return MOY_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MOY_DISPATCH_T(dtype, {
+    const long total = (long)B * 4 * H * W * (C / DT<T>::KPB);
+    hipLaunchKernelGGL((upsample2x_kernel<T>), dim3(nblk(total)), dim3(256), 0, st, static_cast<const T*>(x), ldx, B, H, W, C,
+                       static_cast<T*>(y), ldy);
+    return launch_status();
+  })
+}
+
+extern "C" int moy_rowdot(const void* X, int64_t ldx, const int32_t* x_rows, int M, int K, const float* Wt,
+                          const float* bias, int N, int mode, const float* aux, const int32_t* aux_rows, float* y, int dtype,
+                          void* stream) {
+  if (!X || !Wt || !y || M <= 0 || K <= 0 || (K % 4) || N <= 0 || N > 8 || (ldx % 4)) return MOY_EINVAL;
+  if (mode < 0 || mode > 2 || (mode != 0 && (!aux || N != 4)) || (mode == 2 && !aux_rows)) return MOY_EINVAL;
+  if (!aligned16(Wt)) return MOY_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MOY_DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((rowdot_kernel<T>), dim3((M + 3) / 4), dim3(256), 0, st, static_cast<const T*>(X), ldx, x_rows, M, K, Wt,
+                       bias, N, mode, aux, aux_rows, y);
+    return launch_status();
+  })
+}
+
+extern "C" int moy_topk(const float* scores, int B, int S, int nc, int nq, const uint8_t* valid, int32_t* idx_local,
+                        int32_t* idx_global, int32_t* n_masked, void* stream) {
+  if (!scores || !idx_local || !idx_global || B <= 0 || S <= 0 || nc <= 0 || nq <= 0 || nq > S || nq > 4096) return MOY_EINVAL;
+  int P2 = 1;
+  while (P2 < nq) P2 <<= 1;
+  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TOPK_THREADS), P2 * 8, static_cast<hipStream_t>(stream), scores, S, nc, nq, P2,
+                     valid, idx_local, idx_global, n_masked);
+  return launch_status();
+}
+
+extern "C" int moy_pos2posemb(const float* pos, int M, void* out, int64_t ldo, int dtype, void* stream) {
+  if (!pos || !out || M <= 0 || ldo < 256) return MOY_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MOY_DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((posemb_kernel<T>), dim3(nblk((long)M * 128)), dim3(256), 0, st, pos, M, static_cast<T*>(out), ldo);
+    return launch_status();
+  })
+}
+
+extern "C" int moy_mha_core(const void* qkv, int64_t ld_qkv, int B, int L, int nh, int E, void* out, int64_t ldo, int dtype,
+                            void* stream) {
+  if (!qkv || !out || B <= 0 || L <= 0 || nh <= 0 || E != nh * 32 || ld_qkv < 3 * E || (ld_qkv % 4) || (ldo % 4)) return MOY_EINVAL;
+  const int Lp = (L + 63) & ~63;
+  if (Lp > 512) return MOY_ENOSYS;   // per-lane score registers s[8]
+  const size_t lds = ((size_t)L * 33 + (size_t)L * 32 + 4 * (size_t)Lp) * 4;
+  if (lds > 160 * 1024) return MOY_ENOSYS;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MOY_DISPATCH_T(dtype, {
+    auto kern = mha_kernel<T>;
+    static bool attr_set = false;   // opt in to the full 160 KiB of LDS once per kernel symbol
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return MOY_ELAUNCH;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(B * nh, (L + MHA_QT - 1) / MHA_QT), dim3(256), lds, st, static_cast<const T*>(qkv), ld_qkv, L,
+                       nh, E, static_cast<T*>(out), ldo);
+    return launch_status();
+  })
+}
+
+extern "C" int moy_msda_fused(const void* value, int64_t ldv, int B, int S, const int32_t* shapes_hw, int L, const float* offaw,
+                              int64_t ld_oa, const float* ref, int Lq, void* out, int64_t ldo, int dtype, void* stream) {
+  if (!value || !shapes_hw || !offaw || !ref || !out || B <= 0 || S <= 0 || L <= 0 || L > 4 || Lq <= 0) return MOY_EINVAL;
+  if (ldv < 256 || (ldv % 4) || ld_oa < 8 * L * 4 * 3 || (ld_oa % 4) || ldo < 256 || (ldo % 4) || !aligned16(ref)) return MOY_EINVAL;
+  LevelInfo lv{};
+  int s = 0;
+  for (int l = 0; l < L; ++l) {
+    lv.H[l] = shapes_hw[2 * l]; lv.W[l] = shapes_hw[2 * l + 1]; lv.start[l] = s;
+    if (lv.H[l] <= 0 || lv.W[l] <= 0) return MOY_EINVAL;
+    s += lv.H[l] * lv.W[l];
+  }
+  if (s != S) return MOY_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nrows = B * Lq;
+  MOY_DISPATCH_T(dtype, {
+    if (reinterpret_cast<uintptr_t>(value) % (4 * sizeof(T)) || !aligned16(offaw) ||
+        reinterpret_cast<uintptr_t>(out) % (4 * sizeof(T)))
+      return MOY_EINVAL;
+    hipLaunchKernelGGL((msda_fused_kernel<T>), dim3((nrows + 3) / 4), dim3(256), 0, st, static_cast<const T*>(value), ldv, S, lv, L,
+                       offaw, ld_oa, ref, Lq, nrows, static_cast<T*>(out), ldo);
+    return launch_status();
+  })
+}
+
+template <typename T>
+static int msda_generic(const void* value, const int64_t* shapes, const int64_t* lstart, const void* loc, const void* aw, int N,
+                        int S, int M, int D, int L, int Lq, int P, void* out, void* stream) {
+  if (!value || !shapes || !lstart || !loc || !aw || !out) return MOY_EINVAL;
+  if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return MOY_EINVAL;
+  const long total = (long)N * Lq * M * D;
+  hipLaunchKernelGGL((msda_generic_kernel<T>), dim3(nblk(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const T*>(value), shapes, lstart, static_cast<const T*>(loc), static_cast<const T*>(aw), N, S, M,
+                     D, L, Lq, P, static_cast<T*>(out));
+  return launch_status();
+}
+
+extern "C" int moy_msda_fwd_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                const float* sampling_loc, const float* attn_weight, int N, int S, int M, int D, int L, int Lq,
+                                int P, float* out, void* stream) {
+  return msda_generic<float>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, stream);
+}
+
+extern "C" int moy_msda_fwd_bf16(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                 const void* sampling_loc, const void* attn_weight, int N, int S, int M, int D, int L, int Lq,
+                                 int P, void* out, void* stream) {
+  return msda_generic<bf16_t>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, stream);
+}
+
+extern "C" int moy_assign_post(const float* logits, const float* boxes, int B, int nq, int nc, float score_thresh, float conf,
+                               float img_w, float img_h, float* y, float* scores, int64_t* obj_idxes, float* rows,
+                               int64_t* track_id, int32_t* n_rows, int32_t* n_ids, void* stream) {
+  if (!logits || !boxes || !y || !scores || !obj_idxes || !rows || !track_id || !n_rows || !n_ids) return MOY_EINVAL;
+  if (B <= 0 || nq <= 0 || nq > 1024 || nc <= 0) return MOY_EINVAL;
+  hipLaunchKernelGGL(assign_post_kernel, dim3(B), dim3(1024), 0, static_cast<hipStream_t>(stream), logits, boxes, nq, nc,
+                     score_thresh, conf, img_w, img_h, y, scores, obj_idxes, rows, track_id, n_rows, n_ids);
+  return launch_status();
+}
+
+extern "C" int moy_cast_f32_to(const float* src, int64_t lds_, int M, int N, void* dst, int64_t ldd, int dtype, void* stream) {
+  if (!src || !dst || M <= 0 || N <= 0 || (N % 4) || (lds_ % 4) || (ldd % 4) || !aligned16(src)) return MOY_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MOY_DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((cast_kernel<T>), dim3(nblk((long)M * (N / 4))), dim3(256), 0, st, src, lds_, M, N / 4, static_cast<T*>(dst), ldd);
+    return launch_status();
+  })
+}
+
+extern "C" int moy_gather_rows(const void* src, int64_t lds_, const int32_t* rows, int M, int N, void* dst, int64_t ldd, int dtype,
+                               void* stream) {
+  if (!src || !rows || !dst || M <= 0 || N <= 0 || (N % 8) || (lds_ % 8) || (ldd % 8) || !aligned16(src) || !aligned16(dst))
+    return MOY_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MOY_DISPATCH_T(dtype, {
+    const int NC = N / DT<T>::KPB;
+    hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(nblk((long)M * NC)), dim3(256), 0, st, static_cast<const T*>(src), lds_, rows,
+                       M, NC, static_cast<T*>(dst), ldd);
+    return launch_status();
+  })
+}
+
+extern "C" int moy_sigmoid_f32(const float* in, int n, float* out, void* stream) {
+  if (!in || !out || n <= 0) return MOY_EINVAL;
+  hipLaunchKernelGGL(sigmoid_kernel, dim3(nblk(n)), dim3(256), 0, static_cast<hipStream_t>(stream), in, n, out);
+  return launch_status();
+}

@@ -1,0 +1,459 @@
+"""TrackEngine: the per-frame tracking step as a static launch plan over libmoyolo.so.
+
+One engine = one (architecture, weights, B frames, H x W, dtype) plan: every activation buffer is
+allocated once (channels-last, concat buffers shared by their producers), every weight is
+re-laid-out once ([N, Kpad] rows, BN folded to fp32 scale/shift), and the step is a fixed list of
+C-ABI launches with pre-built argument blocks.  `forward` only enqueues that list on the current
+HIP stream (no host sync, no allocation), so it can be captured into a hipGraph (`capture`).
+
+Reference path restated: preprocess a1 (fused into the stem), backbone/neck a3-a6,
+MYDecoder a8-a14, per-frame ID assignment + predictor rows a15/a16/a20.
+PyTorch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List
+
+import torch
+
+from . import _lib as L
+from .config import TrackArch, level_shapes
+
+BN_EPS = 1e-3   # ultralytics/utils/torch_utils.py:262
+
+
+class View:
+    """A [rows, cols] window of a row-major 2-D device buffer (channel slice of a concat buffer)."""
+
+    def __init__(self, buf: torch.Tensor, off: int = 0, cols: int | None = None):
+        assert buf.dim() == 2 and buf.is_contiguous()
+        self.buf, self.off = buf, off
+        self.cols = buf.shape[1] - off if cols is None else cols
+        assert 0 <= off and off + self.cols <= buf.shape[1]
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + self.off * self.buf.element_size()
+
+    @property
+    def ld(self):
+        return self.buf.shape[1]
+
+    @property
+    def rows(self):
+        return self.buf.shape[0]
+
+    def slice(self, off, cols):
+        return View(self.buf, self.off + off, cols)
+
+    def tensor(self):
+        return self.buf[:, self.off:self.off + self.cols]
+
+
+def _code(dtype):
+    return {torch.float32: L.F32, torch.bfloat16: L.BF16}[dtype]
+
+
+class TrackEngine:
+    def __init__(self, arch: TrackArch, state_dict: Dict[str, torch.Tensor], H: int, W: int, batch: int = 1,
+                 dtype: torch.dtype = torch.float32, device="cuda", input_format: str = "u8", conf: float = 0.25,
+                 score_thresh: float = 0.4, scale_boxes: bool = True):
+        if not torch.cuda.is_available():
+            raise L.MoyoloError("TrackEngine needs a HIP device (no CPU path)")
+        self.lib = L.lib()
+        self.arch, self.H, self.W, self.B = arch, H, W, batch
+        self.dtype, self.code, self.dev = dtype, _code(dtype), torch.device(device)
+        self.input_format = input_format
+        self.conf, self.score_thresh = conf, score_thresh
+        self.img_wh = (float(W), float(H)) if scale_boxes else (1.0, 1.0)
+        self.shapes = level_shapes(H, W)
+        self.S = sum(h * w for h, w in self.shapes)
+        self._keep: List[torch.Tensor] = []          # device tensors referenced by raw pointers
+        self._steps: List = []                       # (fn, args tuple) launches
+        self.sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
+        self._graph = None
+        with torch.no_grad():
+            self._build()
+
+    # ------------------------------------------------------------------ helpers
+    def _dev(self, t, dtype=None):
+        t = t.to(device=self.dev, dtype=dtype or t.dtype).contiguous()
+        self._keep.append(t)
+        return t
+
+    def _buf(self, rows, cols, dtype=None):
+        t = torch.zeros(rows, cols, device=self.dev, dtype=dtype or self.dtype)
+        self._keep.append(t)
+        return t
+
+    def _kpad(self, K):
+        bk = 64 if self.dtype == torch.bfloat16 else 32
+        return (K + bk - 1) // bk * bk
+
+    def _weight(self, w2d):
+        """[N, K] fp32 -> device [N, Kpad] in the engine dtype (zero padded)."""
+        N, K = w2d.shape
+        out = torch.zeros(N, self._kpad(K), dtype=torch.float32)
+        out[:, :K] = w2d
+        return self._dev(out, self.dtype)
+
+    def _bn(self, p):
+        sd = self.sd
+        scale = sd[p + ".weight"] / torch.sqrt(sd[p + ".running_var"] + BN_EPS)
+        shift = sd[p + ".bias"] - sd[p + ".running_mean"] * scale
+        return self._dev(scale), self._dev(shift)
+
+    def _add(self, fn, *args):
+        self._steps.append((fn, args))
+
+    def _gemm(self, A: View, Wt, N, K, C_: View, M, *, ksize=1, stride=1, geom=None, scale=None, shift=None, act=0,
+              A2: View | None = None, a_rows=None, a_mask=None, mask_period=0, R: View | None = None, ln=None,
+              out_f32=False, c_rpb=0, c_bstride=0):
+        a = L.GemmArgs()
+        a.A, a.lda = A.ptr, A.ld
+        a.A2 = A2.ptr if A2 is not None else None
+        if A2 is not None:
+            assert A2.ld == A.ld
+        a.a_rows = a_rows.data_ptr() if a_rows is not None else None
+        a.a_mask = a_mask.data_ptr() if a_mask is not None else None
+        a.mask_period = mask_period
+        a.W, a.M, a.N, a.K = Wt.data_ptr(), M, N, K
+        a.ksize, a.stride = ksize, stride
+        if geom is not None:
+            a.B, a.Hin, a.Win, a.Hout, a.Wout, a.Cin = geom
+        a.scale = scale.data_ptr() if scale is not None else None
+        a.shift = shift.data_ptr() if shift is not None else None
+        a.act = act
+        if R is not None:
+            a.R, a.ldr = R.ptr, R.ld
+        if ln is not None:
+            a.ln_g, a.ln_b = ln[0].data_ptr(), ln[1].data_ptr()
+        a.C, a.ldc, a.out_f32, a.dtype = C_.ptr, C_.ld, int(out_f32), self.code
+        a.c_rows_per_batch, a.c_batch_stride = c_rpb, c_bstride
+        self._keep.append(a)
+        self._add(self.lib.moy_gemm, C.byref(a))
+
+    # conv + BN + SiLU on channels-last views
+    def _conv(self, p, x: View, hw_in, cin, cout, k, s, out: View, R: View | None = None, act=L.ACT_SILU):
+        sd = self.sd
+        w = sd[p + ".conv.weight"]
+        scale, shift = self._bn(p + ".bn")
+        Hin, Win = hw_in
+        if k == 1:
+            Wt = self._weight(w.reshape(cout, cin))
+            self._gemm(x, Wt, cout, cin, out, self.B * Hin * Win, scale=scale, shift=shift, act=act, R=R)
+            return hw_in
+        Hout, Wout = (Hin + 2 - 3) // s + 1, (Win + 2 - 3) // s + 1
+        Wt = self._weight(w.permute(0, 2, 3, 1).reshape(cout, 9 * cin))
+        self._gemm(x, Wt, cout, 9 * cin, out, self.B * Hout * Wout, ksize=3, stride=s,
+                   geom=(self.B, Hin, Win, Hout, Wout, cin), scale=scale, shift=shift, act=act, R=R)
+        return (Hout, Wout)
+
+    def _linear_w(self, p, rows=None):
+        w, b = self.sd[p + ".weight"], self.sd[p + ".bias"]
+        if rows is not None:
+            w, b = w[rows], b[rows]
+        return self._weight(w), self._dev(b)
+
+    # ------------------------------------------------------------------ plan
+    def _build(self):
+        arch, B, H, W, sd, lib, code = self.arch, self.B, self.H, self.W, self.sd, self.lib, self.code
+        nlayers = len(arch.layers)
+        if self.input_format == "u8":
+            self.input = torch.zeros(B, H, W, 3, device=self.dev, dtype=torch.uint8)
+        elif self.input_format == "f32":
+            self.input = torch.zeros(B, 3, H, W, device=self.dev, dtype=torch.float32)
+        else:
+            raise ValueError(self.input_format)
+
+        # spatial size per layer output
+        hw = {}
+        cur = (H, W)
+        for Ls in arch.layers:
+            src_hw = hw[Ls.src[0]] if Ls.src[0] >= 0 else (H, W)
+            if Ls.kind == "Conv":
+                cur = ((src_hw[0] + 2 * (Ls.k // 2) - Ls.k) // Ls.s + 1, (src_hw[1] + 2 * (Ls.k // 2) - Ls.k) // Ls.s + 1)
+            elif Ls.kind == "Upsample":
+                cur = (src_hw[0] * 2, src_hw[1] * 2)
+            else:
+                cur = src_hw
+            hw[Ls.i] = cur
+
+        # homes: outputs that feed a Concat live inside the concat buffer
+        home: Dict[int, View] = {}
+        for Ls in arch.layers:
+            if Ls.kind == "Concat":
+                h_, w_ = hw[Ls.i]
+                buf = self._buf(B * h_ * w_, Ls.c2)
+                off = 0
+                for j in Ls.src:
+                    cj = arch.layers[j].c2
+                    assert j not in home, "a tensor may live in one concat buffer only"
+                    home[j] = View(buf, off, cj)
+                    off += cj
+                home[Ls.i] = View(buf)
+        outv: Dict[int, View] = {}
+
+        def out_view(i, c):
+            if i in home:
+                return home[i]
+            h_, w_ = hw[i]
+            return View(self._buf(B * h_ * w_, c))
+
+        for Ls in arch.layers:
+            p = f"model.{Ls.i}"
+            x = outv[Ls.src[0]] if Ls.src[0] >= 0 else None
+            hin = hw[Ls.src[0]] if Ls.src[0] >= 0 else (H, W)
+            if Ls.kind == "Conv" and Ls.i == 0:
+                assert Ls.k == 3 and Ls.s == 2 and Ls.c1 == 3
+                o = out_view(0, Ls.c2)
+                wst = self._dev(sd[p + ".conv.weight"].permute(2, 3, 1, 0).reshape(27, Ls.c2))
+                scale, shift = self._bn(p + ".bn")
+                self._add(lib.moy_stem_conv, self.input.data_ptr(), 0 if self.input_format == "u8" else 1, B, H, W,
+                          wst.data_ptr(), scale.data_ptr(), shift.data_ptr(), Ls.c2, o.ptr, o.ld, code)
+                outv[0] = o
+            elif Ls.kind == "Conv":
+                o = out_view(Ls.i, Ls.c2)
+                self._conv(p, x, hin, Ls.c1, Ls.c2, Ls.k, Ls.s, o)
+                outv[Ls.i] = o
+            elif Ls.kind == "C2f":
+                c = Ls.c2 // 2
+                h_, w_ = hin
+                cat = View(self._buf(B * h_ * w_, (2 + Ls.n) * c))
+                tmp = View(self._buf(B * h_ * w_, c))
+                self._conv(p + ".cv1", x, hin, Ls.c1, 2 * c, 1, 1, cat.slice(0, 2 * c))
+                for j in range(Ls.n):
+                    src = cat.slice((1 + j) * c, c)
+                    self._conv(f"{p}.m.{j}.cv1", src, hin, c, c, 3, 1, tmp)
+                    self._conv(f"{p}.m.{j}.cv2", tmp, hin, c, c, 3, 1, cat.slice((2 + j) * c, c),
+                               R=src if Ls.shortcut else None)
+                o = out_view(Ls.i, Ls.c2)
+                self._conv(p + ".cv2", cat, hin, (2 + Ls.n) * c, Ls.c2, 1, 1, o)
+                outv[Ls.i] = o
+            elif Ls.kind == "SPPF":
+                c_ = Ls.c1 // 2
+                h_, w_ = hin
+                cat = View(self._buf(B * h_ * w_, 4 * c_))
+                self._conv(p + ".cv1", x, hin, Ls.c1, c_, 1, 1, cat.slice(0, c_))
+                s0, s1, s2, s3 = (cat.slice(i * c_, c_) for i in range(4))
+                self._add(lib.moy_sppf_pool, s0.ptr, s0.ld, B, h_, w_, c_, s1.ptr, s2.ptr, s3.ptr, cat.ld, code)
+                o = out_view(Ls.i, Ls.c2)
+                self._conv(p + ".cv2", cat, hin, 4 * c_, Ls.c2, 1, 1, o)
+                outv[Ls.i] = o
+            elif Ls.kind == "Upsample":
+                o = out_view(Ls.i, Ls.c2)
+                self._add(lib.moy_upsample2x, x.ptr, x.ld, B, hin[0], hin[1], Ls.c1, o.ptr, o.ld, code)
+                outv[Ls.i] = o
+            elif Ls.kind == "Concat":
+                outv[Ls.i] = home[Ls.i]
+            else:
+                raise ValueError(Ls.kind)
+        self.layer_views, self.layer_hw = outv, hw
+
+        # ---------------- head (MYDecoder)
+        d = f"model.{nlayers}.decoder"
+        hd, nq, nc, S, nl = arch.hd, arch.nq, arch.nc, self.S, arch.nl
+        assert hd == 256 and arch.nh == 8 and arch.ndp == 4, "kernels are specialised to hd 256 / 8 heads / 4 points"
+        feats = View(self._buf(B * S, hd))
+        off = 0
+        for li, (j, (h_, w_)) in enumerate(zip((15, 18, 21), self.shapes)):
+            assert hw[j] == (h_, w_)
+            cin = arch.head_ch[li]
+            Wt = self._weight(sd[f"{d}.input_proj.{li}.0.weight"].reshape(hd, cin))
+            scale, shift = self._bn(f"{d}.input_proj.{li}.1")
+            dst = View(feats.buf[off:], 0, hd) if off else feats
+            self._gemm(outv[j], Wt, hd, cin, dst, B * h_ * w_, scale=scale, shift=shift, c_rpb=h_ * w_, c_bstride=S)
+            off += h_ * w_
+        self.feats = feats
+
+        # anchors / valid mask are input independent: host precompute with the reference formula
+        anchors, valid = _generate_anchors(self.shapes)
+        self.anchors = self._dev(anchors[0])                        # [S, 4] (+inf at masked tokens)
+        self.valid = self._dev(valid[0, :, 0].to(torch.uint8))     # [S]
+
+        features = View(self._buf(B * S, hd))
+        Wt, bias = self._linear_w(d + ".enc_output.0")
+        ln = (self._dev(sd[d + ".enc_output.1.weight"]), self._dev(sd[d + ".enc_output.1.bias"]))
+        self._gemm(feats, Wt, hd, hd, features, B * S, shift=bias, a_mask=self.valid, mask_period=S, ln=ln)
+        self.features = features
+
+        self.scores_all = self._buf(B * S, nc, torch.float32)
+        wsc, bsc = self._dev(sd[d + ".enc_score_head.weight"]), self._dev(sd[d + ".enc_score_head.bias"])
+        self._add(lib.moy_rowdot, features.ptr, features.ld, None, B * S, hd, wsc.data_ptr(), bsc.data_ptr(), nc, 0,
+                  None, None, self.scores_all.data_ptr(), code)
+
+        self.topk_local = torch.zeros(B, nq, device=self.dev, dtype=torch.int32)
+        self.topk_global = torch.zeros(B, nq, device=self.dev, dtype=torch.int32)
+        self.n_masked = torch.zeros(B, device=self.dev, dtype=torch.int32)
+        self._topk_step = len(self._steps)
+        self._add(lib.moy_topk, self.scores_all.data_ptr(), B, S, nc, nq, self.valid.data_ptr(),
+                  self.topk_local.data_ptr(), self.topk_global.data_ptr(), self.n_masked.data_ptr())
+
+        M = B * nq
+        t1, t2 = View(self._buf(M, hd)), View(self._buf(M, hd))
+
+        def bbox_mlp(prefix, x: View, a_rows, mode, aux, aux_rows, out_t):
+            W0, b0 = self._linear_w(prefix + ".layers.0")
+            W1, b1 = self._linear_w(prefix + ".layers.1")
+            w2, b2 = self._dev(sd[prefix + ".layers.2.weight"]), self._dev(sd[prefix + ".layers.2.bias"])
+            self._gemm(x, W0, hd, hd, t1, M, shift=b0, act=L.ACT_RELU, a_rows=a_rows)
+            self._gemm(t1, W1, hd, hd, t2, M, shift=b1, act=L.ACT_RELU)
+            self._add(lib.moy_rowdot, t2.ptr, t2.ld, None, M, hd, w2.data_ptr(), b2.data_ptr(), 4, mode,
+                      aux.data_ptr(), aux_rows.data_ptr() if aux_rows is not None else None, out_t.data_ptr(), code)
+
+        self.refer_logit = self._buf(M, 4, torch.float32)
+        bbox_mlp(d + ".enc_bbox_head", features, self.topk_global, 2, self.anchors, self.topk_local, self.refer_logit)
+
+        embed = [View(self._buf(M, hd)) for _ in range(2)]
+        self._add(lib.moy_gather_rows, features.ptr, features.ld, self.topk_global.data_ptr(), M, hd, embed[0].ptr,
+                  embed[0].ld, code)
+        qpos = View(self._buf(M, hd))
+        self._add(lib.moy_pos2posemb, self.refer_logit.data_ptr(), M, qpos.ptr, qpos.ld, code)
+        self.query_pos = qpos
+        refs = [self._buf(M, 4, torch.float32) for _ in range(2)]
+        self._add(lib.moy_sigmoid_f32, self.refer_logit.data_ptr(), M * 4, refs[0].data_ptr())
+
+        # value projections of all decoder layers in ONE GEMM over the S tokens: feats is layer
+        # invariant (transformer.py:700-706 passes the same `feats` to every layer)
+        ndl = arch.ndl
+        Wv = torch.cat([sd[f"{d}.decoder.layers.{i}.cross_attn.value_proj.weight"] for i in range(ndl)], 0)
+        bv = torch.cat([sd[f"{d}.decoder.layers.{i}.cross_attn.value_proj.bias"] for i in range(ndl)], 0)
+        value = View(self._buf(B * S, ndl * hd))
+        self._gemm(feats, self._weight(Wv), ndl * hd, hd, value, B * S, shift=self._dev(bv))
+        self.value = value
+
+        qkv = View(self._buf(M, 3 * hd))
+        attn = View(self._buf(M, hd))
+        e1, e2 = View(self._buf(M, hd)), View(self._buf(M, hd))
+        offaw = self._buf(M, 8 * nl * 4 * 3, torch.float32)
+        samp = View(self._buf(M, hd))
+        ffn = View(self._buf(M, arch.d_ffn))
+        shapes_c = (C.c_int32 * (2 * nl))(*[v for hw_ in self.shapes for v in hw_])
+        self._keep.append(shapes_c)
+        self.layer_out = []
+        cur, nxt = 0, 1
+        for i in range(ndl):
+            q = f"{d}.decoder.layers.{i}"
+            Wqk, bqk = self._linear_w_raw(sd[q + ".self_attn.in_proj_weight"][:2 * hd], sd[q + ".self_attn.in_proj_bias"][:2 * hd])
+            Wvv, bvv = self._linear_w_raw(sd[q + ".self_attn.in_proj_weight"][2 * hd:], sd[q + ".self_attn.in_proj_bias"][2 * hd:])
+            x = embed[cur]
+            self._gemm(x, Wqk, 2 * hd, hd, qkv.slice(0, 2 * hd), M, shift=bqk, A2=qpos)
+            self._gemm(x, Wvv, hd, hd, qkv.slice(2 * hd, hd), M, shift=bvv)
+            self._add(lib.moy_mha_core, qkv.ptr, qkv.ld, B, nq, arch.nh, hd, attn.ptr, attn.ld, code)
+            Wo, bo = self._linear_w(q + ".self_attn.out_proj")
+            self._gemm(attn, Wo, hd, hd, e1, M, shift=bo, R=x, ln=self._ln(q + ".norm1"))
+            Woa = torch.cat([sd[q + ".cross_attn.sampling_offsets.weight"], sd[q + ".cross_attn.attention_weights.weight"]], 0)
+            boa = torch.cat([sd[q + ".cross_attn.sampling_offsets.bias"], sd[q + ".cross_attn.attention_weights.bias"]], 0)
+            Woa_d, boa_d = self._linear_w_raw(Woa, boa)
+            self._gemm(e1, Woa_d, Woa.shape[0], hd, View(offaw), M, shift=boa_d, A2=qpos, out_f32=True)
+            vslice = value.slice(i * hd, hd)
+            self._add(lib.moy_msda_fused, vslice.ptr, vslice.ld, B, S, shapes_c, nl, offaw.data_ptr(), offaw.shape[1],
+                      refs[cur].data_ptr(), nq, samp.ptr, samp.ld, code)
+            Wp, bp = self._linear_w(q + ".cross_attn.output_proj")
+            self._gemm(samp, Wp, hd, hd, e2, M, shift=bp, R=e1, ln=self._ln(q + ".norm2"))
+            W1, b1 = self._linear_w(q + ".linear1")
+            W2, b2 = self._linear_w(q + ".linear2")
+            self._gemm(e2, W1, arch.d_ffn, hd, ffn, M, shift=b1, act=L.ACT_RELU)
+            self._gemm(ffn, W2, hd, arch.d_ffn, embed[nxt], M, shift=b2, R=e2, ln=self._ln(q + ".norm3"))
+            bbox_mlp(f"{d}.dec_bbox_head.{i}", embed[nxt], None, 1, refs[cur], None, refs[nxt])
+            self.layer_out.append((embed[nxt], refs[nxt]))
+            cur, nxt = nxt, cur
+        self.hs = embed[cur]
+        self.boxes = refs[cur]
+        self.logits = self._buf(M, nc, torch.float32)
+        wd = self._dev(sd[f"{d}.dec_score_head.{ndl - 1}.weight"])
+        bd = self._dev(sd[f"{d}.dec_score_head.{ndl - 1}.bias"])
+        self._add(lib.moy_rowdot, self.hs.ptr, self.hs.ld, None, M, hd, wd.data_ptr(), bd.data_ptr(), nc, 0, None, None,
+                  self.logits.data_ptr(), code)
+
+        self.y = torch.zeros(B, nq, 4 + nc, device=self.dev)
+        self.scores = torch.zeros(B, nq, device=self.dev)
+        self.obj_idxes = torch.zeros(B, nq, device=self.dev, dtype=torch.int64)
+        self.rows = torch.zeros(B, nq, 6, device=self.dev)
+        self.track_id = torch.zeros(B, nq, device=self.dev, dtype=torch.int64)
+        self.n_rows = torch.zeros(B, device=self.dev, dtype=torch.int32)
+        self.n_ids = torch.zeros(B, device=self.dev, dtype=torch.int32)
+        self._add(lib.moy_assign_post, self.logits.data_ptr(), self.boxes.data_ptr(), B, nq, nc,
+                  C.c_float(self.score_thresh), C.c_float(self.conf), C.c_float(self.img_wh[0]), C.c_float(self.img_wh[1]),
+                  self.y.data_ptr(), self.scores.data_ptr(), self.obj_idxes.data_ptr(), self.rows.data_ptr(),
+                  self.track_id.data_ptr(), self.n_rows.data_ptr(), self.n_ids.data_ptr())
+
+    def _linear_w_raw(self, w, b):
+        return self._weight(w), self._dev(b)
+
+    def _ln(self, p):
+        return (self._dev(self.sd[p + ".weight"]), self._dev(self.sd[p + ".bias"]))
+
+    # ------------------------------------------------------------------ run
+    def run_steps(self, start=0, stop=None):
+        """Enqueue launches [start, stop) on the current stream."""
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for fn, args in self._steps[start:stop]:
+            rc = fn(*args, st)
+            if rc != 0:
+                L.check(rc, fn.__name__)
+
+    def forward(self, frames: torch.Tensor | None = None):
+        """frames: uint8 [B,H,W,3] BGR (input_format 'u8') or float32 [B,3,H,W] RGB in [0,1] ('f32'),
+        already on the device; copied into the engine's static input.  Returns `outputs()`."""
+        if frames is not None:
+            self.input.copy_(frames, non_blocking=True)
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self.run_steps()
+        return self.outputs()
+
+    def forward_with_topk(self, frames, topk_local: torch.Tensor):
+        """Test hook: run with an injected query selection [B, nq] (int) instead of moy_topk."""
+        self.input.copy_(frames)
+        self.run_steps(0, self._topk_step)
+        tl = topk_local.to(self.dev, torch.int32).reshape(self.B, -1)
+        self.topk_local.copy_(tl)
+        self.topk_global.copy_(tl + torch.arange(self.B, device=self.dev, dtype=torch.int32)[:, None] * self.S)
+        self.n_masked.zero_()
+        self.run_steps(self._topk_step + 1)
+        return self.outputs()
+
+    def capture(self, warmup: int = 2):
+        """Capture the step into a hipGraph (HIP streams + graphs instead of a tracing compiler)."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.run_steps()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.run_steps()
+        self._graph = g
+        return g
+
+    def outputs(self):
+        B, nq = self.B, self.arch.nq
+        return dict(y=self.y, scores=self.scores, obj_idxes=self.obj_idxes, rows=self.rows, track_id=self.track_id,
+                    n_rows=self.n_rows, n_ids=self.n_ids, logits=self.logits.view(B, nq, -1),
+                    boxes=self.boxes.view(B, nq, 4), hs=self.hs.tensor().view(B, nq, -1),
+                    topk_ind=self.topk_local, n_masked=self.n_masked, refer_bbox_logit=self.refer_logit.view(B, nq, 4))
+
+    @property
+    def num_launches(self):
+        return len(self._steps)
+
+
+def _generate_anchors(shapes, grid_size=0.05, eps=1e-2):
+    """Input-independent anchors + validity mask, computed once on the host with the formula the
+    reference ships (nn/modules/head.py:993-1010) INCLUDING its swapped normalisation
+    cx=(x+.5)/H, cy=(y+.5)/W: the mask is part of the parity target."""
+    anchors = []
+    for i, (h, w) in enumerate(shapes):
+        gy, gx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+        xy = (torch.stack([gx, gy], -1).unsqueeze(0) + 0.5) / torch.tensor([h, w], dtype=torch.float32)
+        wh = torch.ones_like(xy) * grid_size * (2.0 ** i)
+        anchors.append(torch.cat([xy, wh], -1).view(-1, h * w, 4))
+    a = torch.cat(anchors, 1)
+    valid = ((a > eps) * (a < 1 - eps)).all(-1, keepdim=True)
+    a = torch.log(a / (1 - a)).masked_fill(~valid, float("inf"))
+    return a, valid

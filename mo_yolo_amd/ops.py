@@ -1,0 +1,225 @@
+"""Functional tensor-level wrappers over the C ABI (shape checks on the host, outputs allocated
+with torch).  These are what the drop-in module classes (mo_yolo_amd.modules) and the parity tests
+call; the TrackEngine pre-builds the same calls into a static plan instead."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _code(t: torch.Tensor):
+    if t.dtype == torch.float32:
+        return L.F32
+    if t.dtype == torch.bfloat16:
+        return L.BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            # same convention as the reference op: ms_deform_attn.h:39 AT_ERROR("Not implemented on the CPU")
+            raise RuntimeError("Not implemented on the CPU")
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D view expected"
+    return t.stride(0)
+
+
+def pad_weight(w2d: torch.Tensor, dtype) -> torch.Tensor:
+    """[N, K] -> [N, Kpad] (Kpad multiple of 64 for bf16 / 32 for f32), zero padded, in `dtype`."""
+    bk = 64 if dtype == torch.bfloat16 else 32
+    N, K = w2d.shape
+    out = torch.zeros(N, (K + bk - 1) // bk * bk, device=w2d.device, dtype=torch.float32)
+    out[:, :K] = w2d.float()
+    return out.to(dtype).contiguous()
+
+
+def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shift=None, act=L.ACT_NONE, A2=None,
+         a_rows=None, a_mask=None, mask_period=0, R=None, ln=None, out_f32=False, M=None, c_rpb=0, c_bstride=0):
+    """See moy_gemm.  A: 2-D row-major view [rows, >=Cin] (channels-last pixels or tokens)."""
+    _need_gpu(A, Wp)
+    a = L.GemmArgs()
+    a.A, a.lda = A.data_ptr(), _ld(A)
+    if A2 is not None:
+        assert _ld(A2) == _ld(A)
+        a.A2 = A2.data_ptr()
+    if a_rows is not None:
+        assert a_rows.dtype == torch.int32
+        a.a_rows = a_rows.data_ptr()
+    if a_mask is not None:
+        assert a_mask.dtype == torch.uint8
+        a.a_mask, a.mask_period = a_mask.data_ptr(), mask_period
+    if ksize == 3:
+        B, Hin, Win, Hout, Wout, Cin = geom
+        a.B, a.Hin, a.Win, a.Hout, a.Wout, a.Cin = geom
+        M = B * Hout * Wout
+    elif M is None:
+        M = a_rows.numel() if a_rows is not None else A.shape[0]
+    a.W, a.M, a.N, a.K, a.ksize, a.stride = Wp.data_ptr(), M, N, K, ksize, stride
+    if scale is not None:
+        a.scale = scale.data_ptr()
+    if shift is not None:
+        a.shift = shift.data_ptr()
+    a.act = act
+    if R is not None:
+        a.R, a.ldr = R.data_ptr(), _ld(R)
+    if ln is not None:
+        a.ln_g, a.ln_b = ln[0].data_ptr(), ln[1].data_ptr()
+    if out is None:
+        rows = M if not c_rpb else (M // c_rpb) * c_bstride
+        out = torch.empty(rows, N, device=A.device, dtype=torch.float32 if out_f32 else A.dtype)
+    a.C, a.ldc, a.out_f32, a.dtype = out.data_ptr(), _ld(out), int(out_f32), _code(A)
+    a.c_rows_per_batch, a.c_batch_stride = c_rpb, c_bstride
+    L.check(L.lib().moy_gemm(C.byref(a), _st()), "moy_gemm")
+    return out
+
+
+def stem_conv(x, w27, scale, shift, dtype):
+    _need_gpu(x)
+    if x.dtype == torch.uint8:
+        B, H, W, _ = x.shape
+        fmt = 0
+    else:
+        B, _, H, W = x.shape
+        fmt = 1
+    cout = w27.shape[1]
+    out = torch.empty(B * (H // 2) * (W // 2), cout, device=x.device, dtype=dtype)
+    L.check(L.lib().moy_stem_conv(x.data_ptr(), fmt, B, H, W, w27.data_ptr(), scale.data_ptr(), shift.data_ptr(), cout,
+                                  out.data_ptr(), cout, _code(out), _st()), "moy_stem_conv")
+    return out
+
+
+def sppf_pool(x, B, H, W):
+    _need_gpu(x)
+    Cc = x.shape[1]
+    ys = [torch.empty(B * H * W, Cc, device=x.device, dtype=x.dtype) for _ in range(3)]
+    L.check(L.lib().moy_sppf_pool(x.data_ptr(), _ld(x), B, H, W, Cc, ys[0].data_ptr(), ys[1].data_ptr(), ys[2].data_ptr(),
+                                  Cc, _code(x), _st()), "moy_sppf_pool")
+    return ys
+
+
+def upsample2x(x, B, H, W):
+    _need_gpu(x)
+    Cc = x.shape[1]
+    y = torch.empty(B * 4 * H * W, Cc, device=x.device, dtype=x.dtype)
+    L.check(L.lib().moy_upsample2x(x.data_ptr(), _ld(x), B, H, W, Cc, y.data_ptr(), Cc, _code(x), _st()), "moy_upsample2x")
+    return y
+
+
+def rowdot(X, Wt, bias, mode=0, aux=None, aux_rows=None, x_rows=None):
+    _need_gpu(X)
+    N, K = Wt.shape
+    M = x_rows.numel() if x_rows is not None else X.shape[0]
+    y = torch.empty(M, N, device=X.device, dtype=torch.float32)
+    L.check(L.lib().moy_rowdot(X.data_ptr(), _ld(X), x_rows.data_ptr() if x_rows is not None else None, M, K,
+                               Wt.data_ptr(), bias.data_ptr() if bias is not None else None, N, mode,
+                               aux.data_ptr() if aux is not None else None,
+                               aux_rows.data_ptr() if aux_rows is not None else None, y.data_ptr(), _code(X), _st()),
+            "moy_rowdot")
+    return y
+
+
+def topk(scores, nq, valid=None):
+    """scores fp32 [B, S, nc] -> (idx_local int32 [B, nq], idx_global, n_masked int32 [B])."""
+    _need_gpu(scores)
+    B, S, nc = scores.shape
+    il = torch.empty(B, nq, device=scores.device, dtype=torch.int32)
+    ig = torch.empty_like(il)
+    nm = torch.zeros(B, device=scores.device, dtype=torch.int32)
+    L.check(L.lib().moy_topk(scores.data_ptr(), B, S, nc, nq, valid.data_ptr() if valid is not None else None,
+                             il.data_ptr(), ig.data_ptr(), nm.data_ptr(), _st()), "moy_topk")
+    return il, ig, nm
+
+
+def pos2posemb(pos, dtype):
+    _need_gpu(pos)
+    M = pos.shape[0]
+    out = torch.empty(M, 256, device=pos.device, dtype=dtype)
+    L.check(L.lib().moy_pos2posemb(pos.data_ptr(), M, out.data_ptr(), 256, _code(out), _st()), "moy_pos2posemb")
+    return out
+
+
+def mha_core(qkv, B, Lq, nh):
+    _need_gpu(qkv)
+    E = qkv.shape[1] // 3
+    out = torch.empty(B * Lq, E, device=qkv.device, dtype=qkv.dtype)
+    L.check(L.lib().moy_mha_core(qkv.data_ptr(), _ld(qkv), B, Lq, nh, E, out.data_ptr(), E, _code(qkv), _st()), "moy_mha_core")
+    return out
+
+
+def msda_fused(value, B, S, shapes, offaw, ref, Lq):
+    _need_gpu(value, offaw, ref)
+    nl = len(shapes)
+    sh = (C.c_int32 * (2 * nl))(*[int(v) for hw in shapes for v in hw])
+    out = torch.empty(B * Lq, 256, device=value.device, dtype=value.dtype)
+    L.check(L.lib().moy_msda_fused(value.data_ptr(), _ld(value), B, S, sh, nl, offaw.data_ptr(), _ld(offaw), ref.data_ptr(),
+                                   Lq, out.data_ptr(), 256, _code(value), _st()), "moy_msda_fused")
+    return out
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
+    """Same call as MultiScaleDeformableAttention.ms_deform_attn_forward (MOTR/models/ops/src/vision.cpp:13-16,
+    ms_deform_attn.h:21-40).  `im2col_step` is accepted for signature compatibility (no chunking needed)."""
+    for t in (value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
+        if not t.is_cuda:
+            raise RuntimeError("Not implemented on the CPU")
+        if not t.is_contiguous():
+            raise RuntimeError("tensor has to be contiguous")     # ms_deform_attn_cuda.cu:28-32
+    N, S, M, D = value.shape
+    _, Lq, _, Lv, P, _ = sampling_loc.shape
+    assert spatial_shapes.dtype == torch.int64 and level_start_index.dtype == torch.int64
+    out = torch.empty(N, Lq, M * D, device=value.device, dtype=value.dtype)
+    fn = L.lib().moy_msda_fwd_f32 if value.dtype == torch.float32 else L.lib().moy_msda_fwd_bf16
+    if value.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("ms_deform_attn_forward: float32 / bfloat16 only")
+    L.check(fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+               attn_weight.data_ptr(), N, S, M, D, Lv, Lq, P, out.data_ptr(), _st()), "moy_msda_fwd")
+    return out
+
+
+def assign_post(logits, boxes, score_thresh=0.4, conf=0.25, img_wh=(1.0, 1.0)):
+    _need_gpu(logits, boxes)
+    B, nq, nc = logits.shape
+    dev = logits.device
+    out = dict(y=torch.empty(B, nq, 4 + nc, device=dev), scores=torch.empty(B, nq, device=dev),
+               obj_idxes=torch.empty(B, nq, device=dev, dtype=torch.int64), rows=torch.zeros(B, nq, 6, device=dev),
+               track_id=torch.full((B, nq), -1, device=dev, dtype=torch.int64),
+               n_rows=torch.zeros(B, device=dev, dtype=torch.int32), n_ids=torch.zeros(B, device=dev, dtype=torch.int32))
+    L.check(L.lib().moy_assign_post(logits.data_ptr(), boxes.data_ptr(), B, nq, nc, score_thresh, conf, img_wh[0], img_wh[1],
+                                    out["y"].data_ptr(), out["scores"].data_ptr(), out["obj_idxes"].data_ptr(),
+                                    out["rows"].data_ptr(), out["track_id"].data_ptr(), out["n_rows"].data_ptr(),
+                                    out["n_ids"].data_ptr(), _st()), "moy_assign_post")
+    return out
+
+
+def gather_rows(src, rows):
+    _need_gpu(src, rows)
+    M, N = rows.numel(), src.shape[1]
+    out = torch.empty(M, N, device=src.device, dtype=src.dtype)
+    L.check(L.lib().moy_gather_rows(src.data_ptr(), _ld(src), rows.data_ptr(), M, N, out.data_ptr(), N, _code(src), _st()),
+            "moy_gather_rows")
+    return out
+
+
+def cast_f32_to(src, dtype):
+    _need_gpu(src)
+    M, N = src.shape
+    out = torch.empty(M, N, device=src.device, dtype=dtype)
+    L.check(L.lib().moy_cast_f32_to(src.data_ptr(), _ld(src), M, N, out.data_ptr(), N, _code(out), _st()), "moy_cast_f32_to")
+    return out
+
+
+def sigmoid_f32(x):
+    _need_gpu(x)
+    out = torch.empty_like(x)
+    L.check(L.lib().moy_sigmoid_f32(x.data_ptr(), x.numel(), out.data_ptr(), _st()), "moy_sigmoid_f32")
+    return out

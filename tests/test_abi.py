@@ -1,0 +1,72 @@
+"""CPU: the C-ABI library builds/loads and exports every symbol include/moyolo.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from mo_yolo_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "moyolo.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(moy_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    build.build(verbose=False)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in moyolo.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes SIGNATURES drifted from the header"
+
+
+def test_gemm_args_layout_matches_header():
+    """Field order of the ctypes mirror == field order of struct moy_gemm_args."""
+    txt = open(os.path.join(ROOT, "include", "moyolo.h")).read()
+    body = txt[txt.index("typedef struct moy_gemm_args {"):txt.index("} moy_gemm_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        parts = decl.replace("*", " ").split()
+        first = parts[-1] if "," not in decl else None
+        if "," in decl:
+            head, *rest = decl.split(",")
+            names.append(head.replace("*", " ").split()[-1])
+            names += [r.strip().lstrip("*") for r in rest]
+        else:
+            names.append(first)
+    assert names == [f[0] for f in _lib.GemmArgs._fields_]
+
+
+def test_version_and_errors_no_gpu_needed():
+    lib = _lib.lib()
+    assert lib.moy_version() == 100
+    assert b"invalid" in lib.moy_strerror(-22)
+    # argument validation happens on the host before any launch: NULL args -> EINVAL
+    assert lib.moy_gemm(None, None) == -22
+    assert lib.moy_sigmoid_f32(None, 0, None, None) == -22
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.MoyoloError):
+        _lib.lib()
+
+
+def test_cpu_tensors_are_rejected_like_the_reference_op():
+    import torch
+    from mo_yolo_amd import ops
+    v = torch.zeros(1, 4, 1, 4)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        ops.ms_deform_attn_forward(v, torch.tensor([[2, 2]]), torch.tensor([0]), torch.zeros(1, 1, 1, 1, 1, 2),
+                                   torch.zeros(1, 1, 1, 1, 1))

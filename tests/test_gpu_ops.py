@@ -1,0 +1,281 @@
+"""GPU parity of every C-ABI entry point against the CPU oracle / a plain torch fp32 reference of
+the same op, on seeded inputs.  fp32 kernels: tight tolerance; bf16: tolerance stated per test.
+Edge cases: ragged M/N (tile tails), K tails, stride 2, image borders, out-of-range sampling
+taps, ties and masked tokens in top-k, empty / full ID assignment."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from mo_yolo_amd import _lib as L
+from mo_yolo_amd import ops
+from oracle import track_oracle as O
+from tests._util import golden
+
+DEV = "cuda"
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dt, f32=2e-5, bf=3e-2):
+    return f32 if dt == torch.float32 else bf
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def q(t, dt):
+    """Quantise a CPU fp32 tensor through dtype `dt` (so the reference sees the same inputs)."""
+    return t.to(dt).float()
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (77, 288, 256), (1000, 64, 96), (129, 1024, 256), (513, 32, 384),
+                                   (64, 8, 16)])
+def test_gemm_linear_variants(dt, M, N, K):
+    x, w = q(rnd(M, K, seed=1), dt), q(rnd(N, K, seed=2, scale=1 / math.sqrt(K)), dt)
+    b = rnd(N, seed=3, scale=0.1)
+    r = q(rnd(M, N, seed=4), dt)
+    xd, wd = x.to(DEV, dt), ops.pad_weight(w.to(DEV), dt)
+    # bias + relu
+    y = ops.gemm(xd, wd, N, K, shift=b.to(DEV), act=L.ACT_RELU)
+    ref = F.relu(x @ w.T + b)
+    assert torch.allclose(y.float().cpu(), ref, atol=tol(dt), rtol=tol(dt, 1e-5, 1e-2))
+    # scale + shift + silu + residual, fp32 output
+    sc = rnd(N, seed=5) * 0.2 + 1.0
+    y = ops.gemm(xd, wd, N, K, scale=sc.to(DEV), shift=b.to(DEV), act=L.ACT_SILU, R=r.to(DEV, dt), out_f32=True)
+    ref = F.silu((x @ w.T) * sc + b) + r
+    assert y.dtype == torch.float32
+    assert torch.allclose(y.cpu(), ref, atol=tol(dt, 2e-5, 2e-2), rtol=1e-5)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_layernorm_residual_prologue_add_gather_mask(dt):
+    M, N, K = 333, 256, 256
+    x, p = q(rnd(M, K, seed=1), dt), q(rnd(M, K, seed=6), dt)
+    w = q(rnd(N, K, seed=2, scale=1 / 16), dt)
+    b, g, be = rnd(N, seed=3, scale=0.1), rnd(N, seed=7) * 0.2 + 1, rnd(N, seed=8, scale=0.1)
+    r = q(rnd(M, N, seed=4), dt)
+    wd = ops.pad_weight(w.to(DEV), dt)
+    y = ops.gemm(x.to(DEV, dt), wd, N, K, shift=b.to(DEV), A2=p.to(DEV, dt), R=r.to(DEV, dt), ln=(g.to(DEV), be.to(DEV)))
+    xin = q(x + p, dt) if dt == torch.bfloat16 else x + p
+    ref = F.layer_norm(xin @ w.T + b + r, (N,), g, be, 1e-5)
+    assert torch.allclose(y.float().cpu(), ref, atol=tol(dt, 3e-5, 4e-2))
+    # row gather + row mask (period) + LN
+    rows = torch.randperm(M, generator=torch.Generator().manual_seed(9))[:200].int()
+    mask = (torch.arange(50) % 3 != 0).to(torch.uint8)
+    y = ops.gemm(x.to(DEV, dt), wd, N, K, shift=b.to(DEV), a_rows=rows.to(DEV), ln=(g.to(DEV), be.to(DEV)))
+    ref = F.layer_norm(x[rows.long()] @ w.T + b, (N,), g, be, 1e-5)
+    assert torch.allclose(y.float().cpu(), ref, atol=tol(dt, 3e-5, 4e-2))
+    y = ops.gemm(x.to(DEV, dt), wd, N, K, shift=b.to(DEV), a_mask=mask.to(DEV), mask_period=50)
+    mrow = mask[torch.arange(M) % 50].float()[:, None]
+    ref = (x * mrow) @ w.T + b
+    assert torch.allclose(y.float().cpu(), ref, atol=tol(dt, 2e-5, 2e-2))
+    # output row remap (level-major token scatter)
+    y = ops.gemm(x[:300].to(DEV, dt), wd, N, K, c_rpb=100, c_bstride=150,
+                 out=torch.zeros(450, N, device=DEV, dtype=dt))
+    ref = x[:300] @ w.T
+    got = y.float().cpu().view(3, 150, N)
+    assert torch.allclose(got[:, :100].reshape(300, N), ref, atol=tol(dt, 2e-5, 2e-2))
+    assert float(got[:, 100:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,s", [(2, 13, 21, 16, 32, 1), (1, 38, 68, 64, 64, 2), (3, 8, 12, 32, 24, 1),
+                                                (1, 19, 34, 128, 128, 1), (2, 16, 16, 8, 16, 2)])
+def test_gemm_conv3x3(dt, B, H, W, Cin, Cout, s):
+    x = q(rnd(B, Cin, H, W, seed=1), dt)
+    w = q(rnd(Cout, Cin, 3, 3, seed=2, scale=1 / math.sqrt(9 * Cin)), dt)
+    sc, sh = rnd(Cout, seed=3) * 0.2 + 1, rnd(Cout, seed=4, scale=0.1)
+    ref = F.silu(F.conv2d(x, w, None, s, 1) * sc[None, :, None, None] + sh[None, :, None, None])
+    Ho, Wo = ref.shape[2:]
+    xr = x.permute(0, 2, 3, 1).reshape(B * H * W, Cin).contiguous().to(DEV, dt)
+    wp = ops.pad_weight(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).to(DEV), dt)
+    y = ops.gemm(xr, wp, Cout, 9 * Cin, ksize=3, stride=s, geom=(B, H, W, Ho, Wo, Cin), scale=sc.to(DEV), shift=sh.to(DEV),
+                 act=L.ACT_SILU)
+    got = y.float().cpu().view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    assert torch.allclose(got, ref, atol=tol(dt, 2e-5, 3e-2), rtol=1e-5)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_channel_slice_views(dt):
+    """A / R / C as channel slices of wider concat buffers (C2f / Concat without copies)."""
+    M, Cb = 500, 96
+    buf = q(rnd(M, Cb, seed=1), dt)
+    w = q(rnd(32, 32, seed=2, scale=0.2), dt)
+    bd = buf.to(DEV, dt)
+    out = torch.zeros(M, 128, device=DEV, dtype=dt)
+    ops.gemm(bd[:, 32:64], ops.pad_weight(w.to(DEV), dt), 32, 32, R=bd[:, 64:96], out=out[:, 64:96])
+    ref = buf[:, 32:64] @ w.T + buf[:, 64:96]
+    assert torch.allclose(out[:, 64:96].float().cpu(), ref, atol=tol(dt, 2e-5, 2e-2))
+    assert float(out[:, :64].abs().max()) == 0 and float(out[:, 96:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("fmt", ["u8", "f32"])
+def test_stem_conv_fused_preprocess(dt, fmt):
+    B, H, W, Cout = 2, 32, 48, 16
+    g = torch.Generator().manual_seed(0)
+    u8 = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    x = u8.flip(-1).permute(0, 3, 1, 2).float() / 255          # predictor.py:125-133
+    w = rnd(Cout, 3, 3, 3, seed=2, scale=0.3)
+    sc, sh = rnd(Cout, seed=3) * 0.2 + 1, rnd(Cout, seed=4, scale=0.1)
+    ref = F.silu(F.conv2d(x, w, None, 2, 1) * sc[None, :, None, None] + sh[None, :, None, None])
+    w27 = w.permute(2, 3, 1, 0).reshape(27, Cout).contiguous().to(DEV)
+    src = u8.to(DEV) if fmt == "u8" else x.contiguous().to(DEV)
+    y = ops.stem_conv(src, w27, sc.to(DEV), sh.to(DEV), dt)
+    got = y.float().cpu().view(B, H // 2, W // 2, Cout).permute(0, 3, 1, 2)
+    assert torch.allclose(got, ref, atol=tol(dt, 1e-5, 2e-2))
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_sppf_pool_and_upsample(dt):
+    B, H, W, Cc = 2, 19, 34, 16
+    x = q(rnd(B, Cc, H, W, seed=1), dt)
+    xr = x.permute(0, 2, 3, 1).reshape(-1, Cc).contiguous().to(DEV, dt)
+    y1 = F.max_pool2d(x, 5, 1, 2); y2 = F.max_pool2d(y1, 5, 1, 2); y3 = F.max_pool2d(y2, 5, 1, 2)
+    for got, ref in zip(ops.sppf_pool(xr, B, H, W), (y1, y2, y3)):
+        assert torch.equal(got.float().cpu().view(B, H, W, Cc).permute(0, 3, 1, 2), ref)
+    up = ops.upsample2x(xr, B, H, W).float().cpu().view(B, 2 * H, 2 * W, Cc).permute(0, 3, 1, 2)
+    assert torch.equal(up, F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_rowdot_modes(dt):
+    M, K = 257, 256
+    x = q(rnd(M, K, seed=1), dt)
+    w, b = rnd(4, K, seed=2, scale=0.1), rnd(4, seed=3)
+    xd = x.to(DEV, dt)
+    y = ops.rowdot(xd, w.to(DEV), b.to(DEV))
+    assert torch.allclose(y.cpu(), x @ w.T + b, atol=2e-5)
+    w1 = rnd(1, K, seed=5, scale=0.1)
+    assert torch.allclose(ops.rowdot(xd, w1.to(DEV), b[:1].to(DEV)).cpu(), x @ w1.T + b[:1], atol=2e-5)
+    ref_box = torch.rand(M, 4, generator=torch.Generator().manual_seed(4))
+    ref_box[0] = torch.tensor([0.0, 1.0, 1e-7, 1 - 1e-7])      # inverse_sigmoid clamps (eps 1e-5)
+    y = ops.rowdot(xd, w.to(DEV), b.to(DEV), mode=1, aux=ref_box.to(DEV))
+    assert torch.allclose(y.cpu(), torch.sigmoid(x @ w.T + b + O.inverse_sigmoid(ref_box)), atol=2e-6)
+    anchors = rnd(100, 4, seed=6)
+    anchors[7] = float("inf")
+    ar = (torch.arange(M) * 7 % 100).int()
+    y = ops.rowdot(xd, w.to(DEV), b.to(DEV), mode=2, aux=anchors.to(DEV), aux_rows=ar.to(DEV))
+    ref = x @ w.T + b + anchors[ar.long()]
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isfinite(y.cpu()), fin) and torch.allclose(y.cpu()[fin], ref[fin], atol=2e-5)
+    rows = torch.randperm(M, generator=torch.Generator().manual_seed(9))[:50].int()
+    y = ops.rowdot(xd, w.to(DEV), b.to(DEV), x_rows=rows.to(DEV))
+    assert torch.allclose(y.cpu(), x[rows.long()] @ w.T + b, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,S,nc,nq", [(1, 13566, 1, 300), (3, 315, 1, 50), (2, 126, 3, 20), (1, 42840, 1, 500), (2, 1000, 2, 1000)])
+def test_topk_matches_torch_and_flags_masked(B, S, nc, nq):
+    sc = rnd(B, S, nc, seed=B + S)
+    il, ig, nm = ops.topk(sc.to(DEV), nq)
+    ref = torch.topk(sc.max(-1).values, nq, dim=1).indices
+    assert torch.equal(il.cpu().long(), ref)
+    assert torch.equal(ig.cpu().long(), ref + torch.arange(B)[:, None] * S)
+    # ties (constant masked-token score): lowest index first, masked selections counted
+    sc2 = sc.clone()
+    valid = torch.ones(S, dtype=torch.uint8)
+    valid[S // 2:] = 0
+    sc2[:, S // 2:] = 10.0                                   # masked tokens outrank everything, all tied
+    il, _, nm = ops.topk(sc2.to(DEV), nq, valid.to(DEV))
+    k = min(nq, S - S // 2)
+    assert torch.equal(il.cpu()[:, :k].long(), (S // 2 + torch.arange(k)).expand(B, k))
+    assert nm.cpu().tolist() == [k] * B
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_pos2posemb(dt):
+    pos = rnd(123, 4, seed=1, scale=6.0)
+    y = ops.pos2posemb(pos.to(DEV), dt)
+    assert torch.allclose(y.float().cpu(), O.pos2posemb(pos), atol=tol(dt, 3e-5, 1e-2))
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,Lq", [(1, 300), (2, 50), (1, 500), (3, 7)])
+def test_mha_core(dt, B, Lq):
+    E, nh = 256, 8
+    qkv = q(rnd(B * Lq, 3 * E, seed=Lq), dt)
+    y = ops.mha_core(qkv.to(DEV, dt), B, Lq, nh)
+    t = qkv.view(B, Lq, 3, nh, 32)
+    qq, kk, vv = (t[:, :, i].transpose(1, 2) for i in range(3))
+    a = torch.softmax((qq / math.sqrt(32)) @ kk.transpose(-1, -2), -1)
+    ref = (a @ vv).transpose(1, 2).reshape(B * Lq, E)
+    assert torch.allclose(y.float().cpu(), ref, atol=tol(dt, 1e-5, 1e-2))
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_msda_fused_vs_oracle(dt):
+    B, Lq, shapes = 2, 37, [(12, 20), (6, 10), (3, 5)]
+    S = sum(h * w for h, w in shapes)
+    value = q(rnd(B, S, 256, seed=1), dt)
+    offaw = torch.cat([rnd(B * Lq, 192, seed=2, scale=6.0), rnd(B * Lq, 96, seed=3, scale=2.0)], 1)
+    ref_box = torch.rand(B * Lq, 4, generator=torch.Generator().manual_seed(4))
+    ref_box[:, 2:] = ref_box[:, 2:] * 0.5 + 0.05
+    ref_box[0, :2] = torch.tensor([0.01, 0.99])               # taps fall outside: zero padding
+    y = ops.msda_fused(value.view(B * S, 256).to(DEV, dt), B, S, shapes, offaw.to(DEV), ref_box.to(DEV), Lq)
+    off = offaw[:, :192].view(B, Lq, 8, 3, 4, 2)
+    aw = torch.softmax(offaw[:, 192:].view(B, Lq, 8, 12), -1).view(B, Lq, 8, 3, 4)
+    rb = ref_box.view(B, Lq, 1, 1, 1, 4)
+    loc = rb[..., :2] + off / 4 * rb[..., 2:] * 0.5
+    ref = O.msda_core(value.view(B, S, 8, 32), shapes, loc, aw).view(B * Lq, 256)
+    assert torch.allclose(y.float().cpu(), ref, atol=tol(dt, 2e-5, 1e-2))
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_ms_deform_attn_forward_kats(dt):
+    """The reference operator API on its own KAT construction (MOTR/models/ops/test.py:21-30),
+    expected values produced by the reference's torch op in the build container."""
+    g = golden("msda_kat")
+    for name in ("kat_tiny", "kat_heads8", "kat_odd"):
+        v, loc, aw = (torch.from_numpy(g[f"{name}.{k}"]) for k in ("value", "loc", "aw"))
+        shapes = torch.from_numpy(g[name + ".shapes"])
+        lsi = torch.cat((shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]))
+        y = ops.ms_deform_attn_forward(v.to(DEV, dt), shapes.to(DEV), lsi.to(DEV), loc.to(DEV, dt), aw.to(DEV, dt), 64)
+        want = torch.from_numpy(g[name + ".out"])
+        if dt == torch.float32:
+            assert torch.allclose(y.cpu(), want, atol=1e-3, rtol=1e-2)       # the reference's own fp32 bar (ops/test.py:50)
+            assert torch.allclose(y.cpu(), want, atol=1e-7, rtol=1e-5)       # ours
+        else:
+            assert torch.allclose(y.float().cpu(), want, atol=3e-4, rtol=3e-2)
+
+
+def test_assign_post_semantics():
+    B, nq, nc = 4, 300, 2
+    logits = rnd(B, nq, nc, seed=1, scale=4.0)
+    logits[1] = -9.0                                          # nothing active -> detection fallback
+    logits[2] = 9.0                                           # all 300 active
+    logits[3, :, :] = torch.logit(torch.tensor(0.3))          # between conf 0.25 and birth 0.4: fallback rows
+    boxes = torch.rand(B, nq, 4, generator=torch.Generator().manual_seed(2))
+    out = ops.assign_post(logits.to(DEV), boxes.to(DEV), 0.4, 0.25, (1088.0, 608.0))
+    out = {k: v.cpu() for k, v in out.items()}
+    for b in range(B):
+        y = torch.cat((boxes[b], logits[b].sigmoid()), -1)
+        assert torch.allclose(out["y"][b], y, atol=1e-6)
+        scores = logits[b].sigmoid().max(-1).values
+        ids = O.assign_ids(scores)
+        assert torch.equal(out["obj_idxes"][b], ids), b
+        rows, tid = O.postprocess(y, logits[b], ids, 0.25, orig_hw=(608, 1088))
+        n = int(out["n_rows"][b])
+        assert n == rows.shape[0]
+        assert torch.allclose(out["rows"][b, :n], rows, atol=1e-3, rtol=1e-6)
+        if tid is None:
+            assert int(out["n_ids"][b]) == -1
+        else:
+            k = int(out["n_ids"][b])
+            assert k == tid.numel() and torch.equal(out["track_id"][b, :k], tid)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_small_helpers(dt):
+    x = q(rnd(100, 64, seed=1), dt)
+    rows = torch.tensor([5, 5, 99, 0], dtype=torch.int32)
+    assert torch.equal(ops.gather_rows(x.to(DEV, dt), rows.to(DEV)).float().cpu(), x[rows.long()])
+    f = rnd(10, 8, seed=2)
+    assert torch.equal(ops.cast_f32_to(f.to(DEV), dt).cpu(), f.to(dt))
+    assert torch.allclose(ops.sigmoid_f32(f.to(DEV)).cpu(), f.sigmoid(), atol=1e-6)
