@@ -289,78 +289,151 @@ __global__ __launch_bounds__(256) void posemb_kernel(const float* __restrict__ p
 }
 
 // ------------------------------------------------------------------------------------------------
-// Self-attention core, head dim 32.  Block = (b, head, 64-query tile); K (padded rows) and V of the
-// (b, head) pair staged in LDS as fp32; per query: lane-parallel q.k over keys, wave-shuffle
-// softmax, probabilities through a wave-private LDS row, PV with lanes = 2 key halves x 32 dims.
-constexpr int MHA_QT = 64;
+// Self-attention core, head dim 32, L <= 512 keys, on the matrix cores.
+// Block = (b, head, slice of 16-query tiles); K ([key][32], 64-B panels, swizzled like the GEMM
+// tiles) and V transposed ([d][key]) of the (b, head) pair are staged in LDS once per block.
+// Per wave and 16-query tile:
+//   S^T = K . Q^T   (MFMA, keys on the accumulator rows, the query on the lane -> each lane owns
+//                    4 keys per 16-key tile of ONE query)
+//   softmax over keys: in-lane over the tiles + two xor-shuffles (lanes r, r+16, r+32, r+48)
+//   O^T = V^T . P^T (MFMA; P goes from the accumulator layout straight into the B operand: the
+//                    key order inside a k-step is permuted identically for V^T's fragment)
+// bf16: v_mfma_f32_16x16x32_bf16 (P rounded to bf16); f32: v_mfma_f32_16x16x4_f32 (exact fp32).
+__device__ __forceinline__ int swz16(int row, int q) { return q ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3); }
 
 template <typename T>
+__device__ __forceinline__ void mma16(f32x4& acc, u32x4 afrag, u32x4 bfrag);
+template <>
+__device__ __forceinline__ void mma16<bf16_t>(f32x4& acc, u32x4 afrag, u32x4 bfrag) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afrag), __builtin_bit_cast(bf16x8, bfrag), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma16<float>(f32x4& acc, u32x4 afrag, u32x4 bfrag) {
+  const f32x4 a = __builtin_bit_cast(f32x4, afrag), b = __builtin_bit_cast(f32x4, bfrag);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+}
+
+template <typename T, int NKT>   // NKT (even): max 16-key tiles, compile-time bound of the score registers
 __global__ __launch_bounds__(256) void mha_kernel(const T* __restrict__ qkv, int64_t ld, int L, int nh, int E,
-                                                  T* __restrict__ out, int64_t ldo) {
+                                                  T* __restrict__ out, int64_t ldo, int tiles_per_block) {
+  constexpr int KPB = DT<T>::KPB;
+  constexpr int NPD = 32 / (4 * KPB);             // 64-B panels per K row: bf16 1, f32 2
+  constexpr int ESZ = 16 / KPB;
+  constexpr bool BF = KPB == 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-  float* Ks = reinterpret_cast<float*>(dyn);          // [L][33]
-  float* Vs = Ks + (long)L * 33;                      // [L][32]
-  float* Ps = Vs + (long)L * 32;                      // [4][Lp]
-  const int Lp = (L + 63) & ~63;
+  const int Lp = (L + 31) & ~31;                  // keys padded to a whole PV k-step
+  const int vstride = Lp * ESZ + 16;              // bytes per V^T row (pad breaks the power-of-two stride)
+  unsigned char* Ks = dyn;                         // [NPD][Lp][64 B]
+  unsigned char* Vt = dyn + NPD * Lp * 64;         // [32][vstride]
   const int b = blockIdx.x / nh, h = blockIdx.x % nh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q4 = lane >> 4;
   const T* base = qkv + (long)b * L * ld;
-  // stage K, V: 8 threads per key row, 4 elements each
-  for (int i = tid; i < L * 8; i += 256) {
-    const int j = i >> 3, d4 = (i & 7) * 4;
-    const f32x4 kv = DT<T>::load4(base + (long)j * ld + E + h * 32 + d4);
-    const f32x4 vv = DT<T>::load4(base + (long)j * ld + 2 * E + h * 32 + d4);
-    float* kd = Ks + j * 33 + d4;
-    kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
-    *reinterpret_cast<f32x4*>(Vs + j * 32 + d4) = vv;
+  // ---- stage K (zero padded) and V^T
+  constexpr int CPK = 4 * NPD;                    // 16-B chunks per key row
+  for (int i = tid; i < Lp * CPK; i += 256) {
+    const int key = i / CPK, ch = i % CPK;
+    u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+    if (key < L) {
+      kv = *reinterpret_cast<const u32x4*>(base + (long)key * ld + E + h * 32 + ch * KPB);
+      vv = *reinterpret_cast<const u32x4*>(base + (long)key * ld + 2 * E + h * 32 + ch * KPB);
+    }
+    const int pd = ch >> 2, c4 = ch & 3;
+    *reinterpret_cast<u32x4*>(Ks + (pd * Lp + key) * 64 + swz16(key, c4) * 16) = kv;
+    if (BF) {
+      const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint16_t hv = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+        *reinterpret_cast<uint16_t*>(Vt + (ch * 8 + e) * vstride + key * 2) = hv;
+      }
+    } else {
+      const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) *reinterpret_cast<uint32_t*>(Vt + (ch * 4 + e) * vstride + key * 4) = w[e];
+    }
   }
   __syncthreads();
-  float* P = Ps + wave * Lp;
-  const float scaling = 0.17677669529663687f;   // 32^-0.5, applied to q before QK^T (torch MHA)
-  const int q_begin = blockIdx.y * MHA_QT;
-  const int nkeys = (L + 63) >> 6;
-  for (int qi = q_begin + wave; qi < min(L, q_begin + MHA_QT); qi += 4) {
-    float qv[32];
-    const T* qp = base + (long)qi * ld + h * 32;
+  const int nkt = (L + 15) >> 4;
+  const int nqt = (L + 15) >> 4;
+  const float scaling = 0.17677669529663687f;     // 32^-0.5 (torch MHA scales q before QK^T)
+  const int t_begin = blockIdx.y * tiles_per_block;
+  const int t_end = min(nqt, t_begin + tiles_per_block);
+  for (int qt = t_begin + wave; qt < t_end; qt += 4) {
+    const int query = qt * 16 + r;
+    const int qld = min(query, L - 1);
+    u32x4 qf[NPD];
 #pragma unroll
-    for (int d = 0; d < 32; d += 4) {
-      const f32x4 t4 = DT<T>::load4(qp + d);
-      qv[d] = t4.x * scaling; qv[d + 1] = t4.y * scaling; qv[d + 2] = t4.z * scaling; qv[d + 3] = t4.w * scaling;
-    }
-    float s[8];
+    for (int pd = 0; pd < NPD; ++pd)
+      qf[pd] = *reinterpret_cast<const u32x4*>(base + (long)qld * ld + h * 32 + (pd * 4 + q4) * KPB);
+    f32x4 s[NKT];
     float mx = -INFINITY;
-    for (int t = 0; t < nkeys; ++t) {
-      const int j = lane + t * 64;
-      float a = -INFINITY;
-      if (j < L) {
-        const float* kr = Ks + j * 33;
-        a = 0.f;
 #pragma unroll
-        for (int d = 0; d < 32; ++d) a = fmaf(qv[d], kr[d], a);
+    for (int kt = 0; kt < NKT; ++kt) {
+      s[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (kt < nkt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int krow = kt * 16 + r;
+#pragma unroll
+        for (int pd = 0; pd < NPD; ++pd) {
+          const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + (pd * Lp + krow) * 64 + swz16(krow, q4) * 16);
+          mma16<T>(acc, kf, qf[pd]);             // D[key = q4*4+reg][query = r]
+        }
+        const int k0 = kt * 16 + q4 * 4;
+        acc = acc * scaling;
+        acc.x = k0 + 0 < L ? acc.x : -INFINITY; acc.y = k0 + 1 < L ? acc.y : -INFINITY;
+        acc.z = k0 + 2 < L ? acc.z : -INFINITY; acc.w = k0 + 3 < L ? acc.w : -INFINITY;
+        s[kt] = acc;
+        mx = fmaxf(mx, fmaxf(fmaxf(acc.x, acc.y), fmaxf(acc.z, acc.w)));
       }
-      s[t] = a;
-      mx = fmaxf(mx, a);
     }
-    mx = wave_max(mx);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
-    for (int t = 0; t < nkeys; ++t) {
-      const int j = lane + t * 64;
-      const float e = j < L ? expf(s[t] - mx) : 0.f;
-      sum += e;
-      P[j] = e;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4 e;
+      e.x = expf(s[kt].x - mx); e.y = expf(s[kt].y - mx); e.z = expf(s[kt].z - mx); e.w = expf(s[kt].w - mx);
+      s[kt] = e;                                  // exp(-inf) = 0 for masked / unused tiles
+      sum += (e.x + e.y) + (e.z + e.w);
     }
-    sum = wave_sum(sum);
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    const int d = lane & 31, half = lane >> 5;
-    const int jh = (L + 1) >> 1;
-    const int j0 = half * jh, j1 = min(L, j0 + jh);
-    float o = 0.f;
-    for (int j = j0; j < j1; ++j) o = fmaf(P[j], Vs[j * 32 + d], o);
-    o += __shfl_xor(o, 32, 64);
-    if (half == 0) DT<T>::store1(out + ((long)b * L + qi) * ldo + h * 32 + d, o / sum);
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (BF) {
+#pragma unroll
+      for (int kb = 0; kb < (NKT + 1) / 2; ++kb)
+        if (kb * 2 < nkt) {
+          const f32x4 p0 = s[2 * kb], p1 = s[2 * kb + 1];
+          const u32x4 pf = {pack_bf2(p0.x, p0.y), pack_bf2(p0.z, p0.w), pack_bf2(p1.x, p1.y), pack_bf2(p1.z, p1.w)};
+#pragma unroll
+          for (int dh = 0; dh < 2; ++dh) {
+            const unsigned char* vr = Vt + (dh * 16 + r) * vstride + (kb * 32 + q4 * 4) * 2;
+            const u32x2 v0 = *reinterpret_cast<const u32x2*>(vr), v1 = *reinterpret_cast<const u32x2*>(vr + 32);
+            mma16<T>(o[dh], u32x4{v0.x, v0.y, v1.x, v1.y}, pf);   // D[d = q4*4+reg][query = r]
+          }
+        }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+        if (kt < nkt) {
+          const u32x4 pf = __builtin_bit_cast(u32x4, s[kt]);
+#pragma unroll
+          for (int dh = 0; dh < 2; ++dh) {
+            const u32x4 vf = *reinterpret_cast<const u32x4*>(Vt + (dh * 16 + r) * vstride + (kt * 16 + q4 * 4) * 4);
+            mma16<T>(o[dh], vf, pf);
+          }
+        }
+    }
+    if (query < L) {
+      const float inv = 1.0f / sum;
+      T* op = out + ((long)b * L + query) * ldo + h * 32 + q4 * 4;
+      DT<T>::store4(op, o[0] * inv);
+      DT<T>::store4(op + 16, o[1] * inv);
+    }
   }
 }
 
@@ -680,25 +753,38 @@ extern "C" int moy_pos2posemb(const float* pos, int M, void* out, int64_t ldo, i
   })
 }
 
+template <typename T, int NKT>
+static int mha_launch(const void* qkv, int64_t ld_qkv, int B, int L, int nh, int E, void* out, int64_t ldo, hipStream_t st) {
+  constexpr int NPD = 32 / (4 * DT<T>::KPB), ESZ = 16 / DT<T>::KPB;
+  const int Lp = (L + 31) & ~31;
+  const size_t lds = (size_t)NPD * Lp * 64 + 32 * ((size_t)Lp * ESZ + 16);
+  auto kern = mha_kernel<T, NKT>;
+  static bool attr_set = false;   // opt in to > 64 KiB of LDS once per kernel symbol
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return MOY_ELAUNCH;
+    attr_set = true;
+  }
+  // enough blocks to cover the chip: split the 16-query tiles of a (b, head) pair over grid.y
+  const int nqt = (L + 15) / 16;
+  int splits = (768 + B * nh - 1) / (B * nh);
+  splits = splits < 1 ? 1 : (splits > (nqt + 3) / 4 ? (nqt + 3) / 4 : splits);
+  const int tpb = (nqt + splits - 1) / splits;
+  hipLaunchKernelGGL(kern, dim3(B * nh, (nqt + tpb - 1) / tpb), dim3(256), lds, st, static_cast<const T*>(qkv), ld_qkv, L, nh, E,
+                     static_cast<T*>(out), ldo, tpb);
+  return launch_status();
+}
+
 extern "C" int moy_mha_core(const void* qkv, int64_t ld_qkv, int B, int L, int nh, int E, void* out, int64_t ldo, int dtype,
                             void* stream) {
-  if (!qkv || !out || B <= 0 || L <= 0 || nh <= 0 || E != nh * 32 || ld_qkv < 3 * E || (ld_qkv % 4) || (ldo % 4)) return MOY_EINVAL;
-  const int Lp = (L + 63) & ~63;
-  if (Lp > 512) return MOY_ENOSYS;   // per-lane score registers s[8]
-  const size_t lds = ((size_t)L * 33 + (size_t)L * 32 + 4 * (size_t)Lp) * 4;
-  if (lds > 160 * 1024) return MOY_ENOSYS;
+  if (!qkv || !out || B <= 0 || L <= 0 || nh <= 0 || E != nh * 32 || ld_qkv < 3 * E || (ld_qkv % 8) || (ldo % 4)) return MOY_EINVAL;
+  if (!aligned16(qkv) || reinterpret_cast<uintptr_t>(out) % 8) return MOY_EINVAL;
+  if (L > 512) return MOY_ENOSYS;    // score registers: 32 key tiles per lane
   hipStream_t st = static_cast<hipStream_t>(stream);
   MOY_DISPATCH_T(dtype, {
-    auto kern = mha_kernel<T>;
-    static bool attr_set = false;   // opt in to the full 160 KiB of LDS once per kernel symbol
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-        return MOY_ELAUNCH;
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(B * nh, (L + MHA_QT - 1) / MHA_QT), dim3(256), lds, st, static_cast<const T*>(qkv), ld_qkv, L,
-                       nh, E, static_cast<T*>(out), ldo);
-    return launch_status();
+    if (L <= 128) return mha_launch<T, 8>(qkv, ld_qkv, B, L, nh, E, out, ldo, st);
+    if (L <= 320) return mha_launch<T, 20>(qkv, ld_qkv, B, L, nh, E, out, ldo, st);
+    return mha_launch<T, 32>(qkv, ld_qkv, B, L, nh, E, out, ldo, st);
   })
 }
 

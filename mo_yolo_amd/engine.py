@@ -71,6 +71,7 @@ class TrackEngine:
         self.S = sum(h * w for h, w in self.shapes)
         self._keep: List[torch.Tensor] = []          # device tensors referenced by raw pointers
         self._steps: List = []                       # (fn, args tuple) launches
+        self.meta: List[dict] = []                   # per launch: name, algorithmic bytes, flops
         self.sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
         self._graph = None
         with torch.no_grad():
@@ -104,8 +105,12 @@ class TrackEngine:
         shift = sd[p + ".bias"] - sd[p + ".running_mean"] * scale
         return self._dev(scale), self._dev(shift)
 
-    def _add(self, fn, *args):
+    def _add(self, fn, *args, meta=None):
         self._steps.append((fn, args))
+        m = dict(name=fn.__name__, bytes=0, flops=0)
+        if meta:
+            m.update(meta)
+        self.meta.append(m)
 
     def _gemm(self, A: View, Wt, N, K, C_: View, M, *, ksize=1, stride=1, geom=None, scale=None, shift=None, act=0,
               A2: View | None = None, a_rows=None, a_mask=None, mask_period=0, R: View | None = None, ln=None,
@@ -132,7 +137,14 @@ class TrackEngine:
         a.C, a.ldc, a.out_f32, a.dtype = C_.ptr, C_.ld, int(out_f32), self.code
         a.c_rows_per_batch, a.c_batch_stride = c_rpb, c_bstride
         self._keep.append(a)
-        self._add(self.lib.moy_gemm, C.byref(a))
+        esz = 2 if self.dtype == torch.bfloat16 else 4
+        if geom is not None:
+            a_elems = geom[0] * geom[1] * geom[2] * geom[5]      # every input pixel read once
+        else:
+            a_elems = M * K * (2 if A2 is not None else 1)
+        alg = (a_elems + N * K) * esz + M * N * (4 if out_f32 else esz) + (M * N * esz if R is not None else 0)
+        tag = f"gemm{ksize}x{ksize}" + ("s2" if stride == 2 else "") + ("+ln" if ln is not None else "")
+        self._add(self.lib.moy_gemm, C.byref(a), meta=dict(name=f"{tag} M{M} N{N} K{K}", bytes=alg, flops=2 * M * N * K))
 
     # conv + BN + SiLU on channels-last views
     def _conv(self, p, x: View, hw_in, cin, cout, k, s, out: View, R: View | None = None, act=L.ACT_SILU):
