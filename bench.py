@@ -33,12 +33,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
     ap.add_argument("--config", default="c2", choices=["c2", "c4"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=12)
+    ap.add_argument("--dump-launches", default=None, help="write the per-launch timing table (json) here")
     return ap.parse_args()
 
 
@@ -151,6 +152,9 @@ def main():
         roof_step = {"bound": "hbm", "achieved": round(ach_s, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(ach_s / HBM_PEAK_GBS, 4), "alg_bytes_per_step": bytes_step,
                      "launches": nL, "sum_kernel_ms_eager": round(sum(per), 3)}
+        if a.dump_launches:
+            with open(a.dump_launches, "w") as f:
+                json.dump([dict(i=i, ms=per[i], **eng.meta[i]) for i in range(nL)], f)
         top = sorted(range(nL), key=lambda i: -per[i])[:8]
         roof_step["top_kernels"] = [{"name": eng.meta[i]["name"], "ms": round(per[i], 4)} for i in top]
 

@@ -62,14 +62,20 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// accurate forms (feed thresholds / final outputs)
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float siluf_(float x) { return x / (1.0f + expf(-x)); }
+// epilogue forms: v_exp_f32 + v_rcp_f32 (about 1 ulp each, 5 VALU ops instead of ~40): the GEMM
+// epilogues were VALU-bound on the libm expf + IEEE divide (profiles/r01_b_pmc_gemm.txt)
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float siluf_(float x) { return x * fast_sigmoid(x); }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case MOY_ACT_SILU: return siluf_(v);
     case MOY_ACT_RELU: return fmaxf(v, 0.0f);
-    case MOY_ACT_SIGMOID: return sigmoidf_(v);
+    case MOY_ACT_SIGMOID: return fast_sigmoid(v);
     default: return v;
   }
 }

@@ -14,6 +14,8 @@
 //     optional LayerNorm with wave shuffles) -> coalesced vector stores.
 //   * blockIdx is remapped so that the column tiles of one row tile run on the same XCD (they
 //     re-read the same activation rows from that XCD's L2).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace moy {
@@ -88,6 +90,65 @@ constexpr int gemm_lds_bytes() {
   constexpr int stage = 2 * (BM + BN) * PANELS * 64;
   constexpr int epi = BM * (BN + 4) * 4;
   return stage > epi ? stage : epi;
+}
+
+template <typename T, int BM, int BN, bool LN, int NTHR>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const float* Cs, int m0, int n0, int tid) {
+  constexpr int LDC = BN + 4;
+  const int lane = tid & 63, wave = tid >> 6;
+  const T* __restrict__ Rg = static_cast<const T*>(p.R);
+  if (!LN) {
+    constexpr int CPR = BN / 4;          // 4-column chunks per row
+    constexpr int RSTEP = NTHR / CPR;
+    const int cc = tid % CPR, rr0 = tid / CPR;
+    const int n = n0 + cc * 4;
+    if (n < p.N) {                        // N % 4 == 0 (host-checked)
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+      for (int rr = rr0; rr < BM; rr += RSTEP) {
+        const int m = m0 + rr;
+        if (m >= p.M) break;
+        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + cc * 4);
+        v = v * sc + sh;
+        v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
+        v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+        if (Rg) v += DT<T>::load4(Rg + (int64_t)m * p.ldr + n);
+        const int64_t mo = p.c_rpb ? (int64_t)(m / p.c_rpb) * p.c_bstride + (m % p.c_rpb) : (int64_t)m;
+        if (p.out_f32)
+          *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + mo * p.ldc + n) = v;
+        else
+          DT<T>::store4(static_cast<T*>(p.C) + mo * p.ldc + n, v);
+      }
+    }
+  } else {
+    // one wave per row; lane owns columns lane*4 .. +3 (N == BN == 256)
+    const int n = lane * 4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+    if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(p.ln_g + n);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(p.ln_b + n);
+    for (int rr = wave; rr < BM; rr += NTHR / 64) {
+      const int m = m0 + rr;
+      if (m >= p.M) break;
+      f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + n);
+      v = v * sc + sh;
+      v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
+      v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+      if (Rg) v += DT<T>::load4(Rg + (int64_t)m * p.ldr + n);
+      const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / 256.0f);
+      const f32x4 d = v - mean;
+      const float var = wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * (1.0f / 256.0f);
+      const float rstd = 1.0f / sqrtf(var + 1e-5f);
+      v = d * rstd * g + be;
+      const int64_t mo = p.c_rpb ? (int64_t)(m / p.c_rpb) * p.c_bstride + (m % p.c_rpb) : (int64_t)m;
+      if (p.out_f32)
+        *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + mo * p.ldc + n) = v;
+      else
+        DT<T>::store4(static_cast<T*>(p.C) + mo * p.ldc + n, v);
+    }
+  }
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, bool LN, int KS>
@@ -268,59 +329,224 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     }
   __syncthreads();
 
-  const T* __restrict__ Rg = static_cast<const T*>(p.R);
-  if (!LN) {
-    constexpr int CPR = BN / 4;          // 4-column chunks per row
-    constexpr int RSTEP = 256 / CPR;
-    const int cc = tid % CPR, rr0 = tid / CPR;
-    const int n = n0 + cc * 4;
-    if (n < p.N) {                        // N % 4 == 0 (host-checked)
-      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-      for (int rr = rr0; rr < BM; rr += RSTEP) {
-        const int m = m0 + rr;
-        if (m >= p.M) break;
-        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + cc * 4);
-        v = v * sc + sh;
-        v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
-        v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
-        if (Rg) v += DT<T>::load4(Rg + (int64_t)m * p.ldr + n);
-        const int64_t mo = p.c_rpb ? (int64_t)(m / p.c_rpb) * p.c_bstride + (m % p.c_rpb) : (int64_t)m;
-        if (p.out_f32)
-          *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + mo * p.ldc + n) = v;
-        else
-          DT<T>::store4(static_cast<T*>(p.C) + mo * p.ldc + n, v);
+  gemm_epilogue<T, BM, BN, LN, 256>(p, Cs, m0, n0, tid);
+}
+
+// =================================================================================================
+// LDS-DMA variant of the main loop (global_load_lds_dwordx4, no staging registers):
+//   * NST-deep ring of LDS stages; the DMA for stage kt+NST-1 is issued while stage kt is computed,
+//     so NST-1 stages (tens of KB per CU) are in flight continuously -- these GEMMs have K of only
+//     64..2304 and stream M rows once, so bytes in flight, not MFMA rate, set their speed;
+//   * a wave instruction writes 1 KiB of LDS linearly (16 rows x 64 B of one panel); the XOR
+//     swizzle is applied on the SOURCE address (lane i fetches the chunk that belongs at its linear
+//     slot), and the ds_read side applies the same involution;
+//   * out-of-image taps, M / N tails, masked rows and K padding are fetched from a 16-byte zero page;
+//   * one raw s_barrier per stage with a counted s_waitcnt vmcnt (never __syncthreads in the loop,
+//     which would drain the DMA queue).
+// The epilogue is shared with the register-staged kernel.
+__device__ __attribute__((aligned(16))) uint32_t g_zero_page[4] = {0u, 0u, 0u, 0u};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BN, int NST>
+constexpr int gemm_dma_lds_bytes() {
+  constexpr int stage = NST * (BM + BN) * PANELS * 64;
+  constexpr int epi = BM * (BN + 4) * 4;
+  return stage > epi ? stage : epi;
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, bool LN, int KS, int NST>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_dma_kernel(const GemmParams p) {
+  constexpr int NW = WGM * WGN, NTHR = 64 * NW;
+  constexpr int KPB = DT<T>::KPB, BKP = 4 * KPB, BK = BKP * PANELS;
+  constexpr int TM = BM / WGM, TN = BN / WGN, MT = TM / 16, NT = TN / 16;
+  constexpr int A_BYTES = BM * PANELS * 64, B_BYTES = BN * PANELS * 64, ST_BYTES = A_BYTES + B_BYTES;
+  constexpr int RGA = BM / 16, RGB = BN / 16;               // 16-row groups per panel
+  constexpr int PA = RGA * PANELS, PB = RGB * PANELS;       // 1-KiB pieces per stage
+  constexpr int PPA = (PA + NW - 1) / NW, PPB = (PB + NW - 1) / NW;   // pieces per wave
+  constexpr int NPW = PPA + PPB;                            // DMA instructions per wave and stage
+  static_assert(PA % NW == 0 && PB % NW == 0, "pieces must divide over the waves");
+  static_assert(!LN || BN == 256, "LayerNorm epilogue needs the whole row in one tile");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  int bid = blockIdx.x;
+  {
+    const int nb = p.nblocks, qd = nb >> 3, rm = nb & 7, x = bid & 7;
+    bid = (x < rm ? x * (qd + 1) : rm * (qd + 1) + (x - rm) * qd) + (bid >> 3);
+  }
+  const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const T* __restrict__ Ag = static_cast<const T*>(p.A);
+  const T* __restrict__ Wg = static_cast<const T*>(p.W);
+  const T* zero = reinterpret_cast<const T*>(g_zero_page);
+
+  // ---- per-lane, per-piece source coordinates (loop invariant)
+  const int lrow = lane >> 2, lcol = lane & 3;
+  int64_t a_off[PPA];
+  int iy0[PPA], ix0[PPA], a_q[PPA];
+  bool a_ok[PPA];
+#pragma unroll
+  for (int j = 0; j < PPA; ++j) {
+    const int pc = wave + NW * j, rg = pc % RGA;
+    const int row = rg * 16 + lrow, m = m0 + row;
+    a_q[j] = swz(row, lcol);                 // chunk that lives at this lane's linear LDS slot
+    a_ok[j] = m < p.M;
+    a_off[j] = 0; iy0[j] = ix0[j] = 0;
+    if (a_ok[j]) {
+      if (KS == 1) {
+        if (p.a_mask && p.a_mask[m % p.mask_period] == 0) a_ok[j] = false;
+        const int64_t rowi = p.a_rows ? (int64_t)p.a_rows[m] : (int64_t)m;
+        a_off[j] = rowi * p.lda;
+      } else {
+        const int hw = p.Hout * p.Wout;
+        const int b = m / hw, rem = m - b * hw;
+        const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+        iy0[j] = oy * p.stride - 1; ix0[j] = ox * p.stride - 1;
+        a_off[j] = (int64_t)b * p.Hin * p.Win * p.lda;
       }
     }
-  } else {
-    // one wave per row; lane owns columns lane*4 .. +3 (N == BN == 256)
-    const int n = lane * 4;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-    if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-    const f32x4 g = *reinterpret_cast<const f32x4*>(p.ln_g + n);
-    const f32x4 be = *reinterpret_cast<const f32x4*>(p.ln_b + n);
-    for (int rr = wave; rr < BM; rr += 4) {
-      const int m = m0 + rr;
-      if (m >= p.M) break;
-      f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + n);
-      v = v * sc + sh;
-      v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
-      v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
-      if (Rg) v += DT<T>::load4(Rg + (int64_t)m * p.ldr + n);
-      const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / 256.0f);
-      const f32x4 d = v - mean;
-      const float var = wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * (1.0f / 256.0f);
-      const float rstd = 1.0f / sqrtf(var + 1e-5f);
-      v = d * rstd * g + be;
-      const int64_t mo = p.c_rpb ? (int64_t)(m / p.c_rpb) * p.c_bstride + (m % p.c_rpb) : (int64_t)m;
-      if (p.out_f32)
-        *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + mo * p.ldc + n) = v;
-      else
-        DT<T>::store4(static_cast<T*>(p.C) + mo * p.ldc + n, v);
-    }
   }
+  int64_t b_off[PPB];
+  int b_q[PPB];
+  bool b_ok[PPB];
+#pragma unroll
+  for (int j = 0; j < PPB; ++j) {
+    const int pc = wave + NW * j, rg = pc % RGB;
+    const int row = rg * 16 + lrow, n = n0 + row;
+    b_q[j] = swz(row, lcol);
+    b_ok[j] = n < p.N;
+    b_off[j] = (int64_t)n * p.Kpad;
+  }
+
+  auto issue_stage = [&](int kt, int buf) {
+    unsigned char* As = smem + buf * ST_BYTES;
+    unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int j = 0; j < PPA; ++j) {
+      const int pc = wave + NW * j, pn = pc / RGA, rg = pc % RGA;
+      const int kc = kt * BK + pn * BKP + a_q[j] * KPB;
+      const T* src = zero;
+      if (KS == 1) {
+        if (a_ok[j] && kc < p.K) src = Ag + a_off[j] + kc;
+      } else {
+        const int tap = kc >> p.lgC, c = kc & (p.Cin - 1);
+        const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+        const int iy = iy0[j] + ky, ix = ix0[j] + kx;
+        if (a_ok[j] && tap < 9 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win)
+          src = Ag + a_off[j] + ((int64_t)iy * p.Win + ix) * p.lda + c;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(As + (pn * BM + rg * 16) * 64), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < PPB; ++j) {
+      const int pc = wave + NW * j, pn = pc / RGB, rg = pc % RGB;
+      const int kc = kt * BK + pn * BKP + b_q[j] * KPB;
+      const T* src = b_ok[j] ? Wg + b_off[j] + kc : zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(Bs + (pn * BN + rg * 16) * 64), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.Kpad / BK;
+  // prologue: NST-1 stages in flight
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) issue_stage(s, s);
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt must have landed; the (up to NST-2) younger stages stay in flight
+    const int younger = min(NST - 2, nk - 1 - kt);
+    if (NST >= 4 && younger == 2) wait_vmcnt<2 * NPW>();
+    else if (NST >= 3 && younger == 1) wait_vmcnt<NPW>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NST - 1 < nk) {
+      int nb = buf + NST - 1;
+      if (nb >= NST) nb -= NST;
+      issue_stage(kt + NST - 1, nb);
+    }
+    const unsigned char* As = smem + buf * ST_BYTES;
+    const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int pn = 0; pn < PANELS; ++pn) {
+      u32x4 af[MT], wf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = wm * TM + i * 16 + r;
+        af[i] = *reinterpret_cast<const u32x4*>(As + (pn * BM + row) * 64 + swz(row, q) * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int row = wn * TN + j * 16 + r;
+        wf[j] = *reinterpret_cast<const u32x4*>(Bs + (pn * BN + row) * 64 + swz(row, q) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) mma_panel<T>(acc[i][j], wf[j], af[i]);
+    }
+    if (++buf == NST) buf = 0;
+  }
+  __syncthreads();   // all waves done with the ring before it is reused as the fp32 output tile
+
+  constexpr int LDC = BN + 4;
+  float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int ml = wm * TM + i * 16 + r, nl = wn * TN + j * 16 + q * 4;
+      *reinterpret_cast<f32x4*>(Cs + ml * LDC + nl) = acc[i][j];
+    }
+  __syncthreads();
+  gemm_epilogue<T, BM, BN, LN, NTHR>(p, Cs, m0, n0, tid);
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, bool LN, int KS, int NST>
+static int launch_dma(GemmParams& p, hipStream_t st) {
+  const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  p.nblocks = tiles_m * p.tiles_n;
+  constexpr int lds = gemm_dma_lds_bytes<T, BM, BN, NST>();
+  static_assert(lds <= 160 * 1024, "LDS");
+  auto kern = gemm_dma_kernel<T, BM, BN, WGM, WGN, LN, KS, NST>;
+  static bool attr_set = false;
+  if (lds > 65536 && !attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return MOY_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(64 * WGM * WGN), lds, st, p);
+  return launch_status();
+}
+
+template <typename T, int KS>
+static int dispatch_dma(GemmParams& p, bool ln, hipStream_t st) {
+  if (ln) return launch_dma<T, 64, 256, 1, 4, true, KS, 3>(p, st);
+  const long big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  if (p.N > 64) {
+    if (big >= 384) return launch_dma<T, 128, 128, 2, 2, false, KS, 3>(p, st);
+    return launch_dma<T, 64, 128, 2, 2, false, KS, 3>(p, st);
+  }
+  const long mid = (long)((p.M + 127) / 128);
+  if (mid >= 384) return launch_dma<T, 128, 64, 2, 2, false, KS, 3>(p, st);
+  return launch_dma<T, 64, 64, 2, 2, false, KS, 3>(p, st);
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, bool LN, int KS>
@@ -403,6 +629,16 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
     p.lgC = lg;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // Main-loop variant: register-staged (default) or LDS-DMA ring (MOY_GEMM_IMPL=dma).  Measured on
+  // MI355X (tools/bench_gemm.py, round 1): the DMA ring needs 72-120 KB of LDS per block, i.e. 1-2
+  // blocks per CU, and loses 20-50 % to the register-staged kernel at 2-3 blocks per CU on every
+  // shape of this path -- these short-K GEMMs hide latency with occupancy, not with ring depth.
+  static const bool use_dma = [] { const char* e = getenv("MOY_GEMM_IMPL"); return e && e[0] == 'd'; }();
+  if (!a->A2 && use_dma) {   // the A + A2 prologue add needs the register-staged kernel
+    if (a->dtype == MOY_BF16)
+      return a->ksize == 1 ? dispatch_dma<bf16_t, 1>(p, ln, st) : dispatch_dma<bf16_t, 3>(p, ln, st);
+    return a->ksize == 1 ? dispatch_dma<float, 1>(p, ln, st) : dispatch_dma<float, 3>(p, ln, st);
+  }
   if (a->dtype == MOY_BF16)
     return a->ksize == 1 ? dispatch_tile<bf16_t, 1>(p, ln, st) : dispatch_tile<bf16_t, 3>(p, ln, st);
   return a->ksize == 1 ? dispatch_tile<float, 1>(p, ln, st) : dispatch_tile<float, 3>(p, ln, st);

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of moy_gemm on the shapes of the C2 plan (B=32 frames): us, GB/s (algorithmic
+bytes), TF/s per shape.  Interleaved rounds in one process (cdna guide rule 24)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from mo_yolo_amd import _lib as L
+from mo_yolo_amd import ops
+
+B = int(os.environ.get("BG_B", 32))
+dt = torch.bfloat16
+dev = "cuda"
+# (name, ksize, stride, Hin, Win, Cin, Cout, ln)
+SHAPES = [
+    ("L1 3x3s2 32->64", 3, 2, 304, 544, 32, 64, False),
+    ("L2m 3x3 32->32", 3, 1, 152, 272, 32, 32, False),
+    ("L2cv2 1x1 96->64", 1, 1, 152, 272, 96, 64, False),
+    ("L4m 3x3 64->64", 3, 1, 76, 136, 64, 64, False),
+    ("L4cv2 1x1 256->128", 1, 1, 76, 136, 256, 128, False),
+    ("L6m 3x3 128->128", 3, 1, 38, 68, 128, 128, False),
+    ("L5 3x3s2 128->256", 3, 2, 76, 136, 128, 256, False),
+    ("L8m 3x3 128->128 P5", 3, 1, 19, 34, 128, 128, False),
+    ("value 1x1 256->1536", 1, 1, 1, 13566, 256, 1536, False),
+    ("encout+ln 256->256", 1, 1, 1, 13566, 256, 256, True),
+    ("dec ffn1 256->1024", 1, 1, 1, 300, 256, 1024, False),
+    ("dec ffn2+ln 1024->256", 1, 1, 1, 300, 1024, 256, True),
+    ("dec qk 256->512", 1, 1, 1, 300, 256, 512, False),
+]
+
+
+def make(s):
+    name, ks, st, H, W, Cin, Cout, ln = s
+    x = (torch.rand(B * H * W, Cin, device=dev) - 0.5).to(dt)
+    K = ks * ks * Cin
+    w = ops.pad_weight((torch.rand(Cout, K, device=dev) - 0.5) / K ** 0.5, dt)
+    sc = torch.rand(Cout, device=dev) + 0.5
+    sh = torch.rand(Cout, device=dev) - 0.5
+    if ks == 3:
+        Ho, Wo = (H + 2 - 3) // st + 1, (W + 2 - 3) // st + 1
+        geom = (B, H, W, Ho, Wo, Cin)
+        M = B * Ho * Wo
+    else:
+        geom, M = None, B * H * W
+    out = torch.empty(M, Cout, device=dev, dtype=dt)
+    conv = H > 1          # backbone convs carry BN + SiLU; the head / decoder linears only a bias
+    kw = dict(out=out, ksize=ks, stride=st, geom=geom, scale=sc if conv else None, shift=sh,
+              act=L.ACT_SILU if conv else L.ACT_NONE)
+    if ln:
+        kw.update(ln=(sc, sh), act=L.ACT_NONE)
+    alg = (x.numel() + w.numel() + out.numel()) * 2
+    flops = 2 * M * Cout * K
+    return (lambda: ops.gemm(x, w, Cout, K, **kw)), alg, flops, M
+
+
+def main():
+    only = os.environ.get("BG_ONLY")
+    shapes = [s for s in SHAPES if not only or any(o in s[0] for o in only.split(","))]
+    cases = [(s[0],) + make(s) for s in shapes]
+    for _, f, *_ in cases:
+        f()
+    torch.cuda.synchronize()
+    rounds, reps = int(os.environ.get('BG_ROUNDS', 5)), int(os.environ.get('BG_REPS', 10))
+    best = {c[0]: 1e9 for c in cases}
+    for _ in range(rounds):
+        for name, f, alg, flops, M in cases:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            best[name] = min(best[name], e0.elapsed_time(e1) / reps)
+    tot = 0
+    for name, f, alg, flops, M in cases:
+        ms = best[name]
+        tot += ms
+        print(f"{name:26s} M={M:8d} {ms*1e3:8.1f} us {alg/ms/1e6:7.0f} GB/s {flops/ms/1e9:7.1f} TF/s")
+    print(f"sum {tot*1e3:.1f} us")
+
+
+if __name__ == "__main__":
+    main()
