@@ -58,7 +58,8 @@ def _code(dtype):
 class TrackEngine:
     def __init__(self, arch: TrackArch, state_dict: Dict[str, torch.Tensor], H: int, W: int, batch: int = 1,
                  dtype: torch.dtype = torch.float32, device="cuda", input_format: str = "u8", conf: float = 0.25,
-                 score_thresh: float = 0.4, scale_boxes: bool = True):
+                 score_thresh: float = 0.4, scale_boxes: bool = True, head_only: bool = False,
+                 level_shapes_override=None):
         if not torch.cuda.is_available():
             raise L.MoyoloError("TrackEngine needs a HIP device (no CPU path)")
         self.lib = L.lib()
@@ -67,7 +68,8 @@ class TrackEngine:
         self.input_format = input_format
         self.conf, self.score_thresh = conf, score_thresh
         self.img_wh = (float(W), float(H)) if scale_boxes else (1.0, 1.0)
-        self.shapes = level_shapes(H, W)
+        self.head_only = head_only
+        self.shapes = [tuple(s) for s in level_shapes_override] if level_shapes_override else level_shapes(H, W)
         self.S = sum(h * w for h, w in self.shapes)
         self._keep: List[torch.Tensor] = []          # device tensors referenced by raw pointers
         self._steps: List = []                       # (fn, args tuple) launches
@@ -172,110 +174,120 @@ class TrackEngine:
     def _build(self):
         arch, B, H, W, sd, lib, code = self.arch, self.B, self.H, self.W, self.sd, self.lib, self.code
         nlayers = len(arch.layers)
-        if self.input_format == "u8":
-            self.input = torch.zeros(B, H, W, 3, device=self.dev, dtype=torch.uint8)
-        elif self.input_format == "f32":
-            self.input = torch.zeros(B, 3, H, W, device=self.dev, dtype=torch.float32)
-        else:
-            raise ValueError(self.input_format)
-
-        # spatial size per layer output
-        hw = {}
-        cur = (H, W)
-        for Ls in arch.layers:
-            src_hw = hw[Ls.src[0]] if Ls.src[0] >= 0 else (H, W)
-            if Ls.kind == "Conv":
-                cur = ((src_hw[0] + 2 * (Ls.k // 2) - Ls.k) // Ls.s + 1, (src_hw[1] + 2 * (Ls.k // 2) - Ls.k) // Ls.s + 1)
-            elif Ls.kind == "Upsample":
-                cur = (src_hw[0] * 2, src_hw[1] * 2)
-            else:
-                cur = src_hw
-            hw[Ls.i] = cur
-
-        # homes: outputs that feed a Concat live inside the concat buffer
-        home: Dict[int, View] = {}
-        for Ls in arch.layers:
-            if Ls.kind == "Concat":
-                h_, w_ = hw[Ls.i]
-                buf = self._buf(B * h_ * w_, Ls.c2)
-                off = 0
-                for j in Ls.src:
-                    cj = arch.layers[j].c2
-                    assert j not in home, "a tensor may live in one concat buffer only"
-                    home[j] = View(buf, off, cj)
-                    off += cj
-                home[Ls.i] = View(buf)
         outv: Dict[int, View] = {}
-
-        def out_view(i, c):
-            if i in home:
-                return home[i]
-            h_, w_ = hw[i]
-            return View(self._buf(B * h_ * w_, c))
-
-        for Ls in arch.layers:
-            p = f"model.{Ls.i}"
-            x = outv[Ls.src[0]] if Ls.src[0] >= 0 else None
-            hin = hw[Ls.src[0]] if Ls.src[0] >= 0 else (H, W)
-            if Ls.kind == "Conv" and Ls.i == 0:
-                assert Ls.k == 3 and Ls.s == 2 and Ls.c1 == 3
-                o = out_view(0, Ls.c2)
-                wst = self._dev(sd[p + ".conv.weight"].permute(2, 3, 1, 0).reshape(27, Ls.c2))
-                scale, shift = self._bn(p + ".bn")
-                self._add(lib.moy_stem_conv, self.input.data_ptr(), 0 if self.input_format == "u8" else 1, B, H, W,
-                          wst.data_ptr(), scale.data_ptr(), shift.data_ptr(), Ls.c2, o.ptr, o.ld, code)
-                outv[0] = o
-            elif Ls.kind == "Conv":
-                o = out_view(Ls.i, Ls.c2)
-                self._conv(p, x, hin, Ls.c1, Ls.c2, Ls.k, Ls.s, o)
-                outv[Ls.i] = o
-            elif Ls.kind == "C2f":
-                c = Ls.c2 // 2
-                h_, w_ = hin
-                cat = View(self._buf(B * h_ * w_, (2 + Ls.n) * c))
-                tmp = View(self._buf(B * h_ * w_, c))
-                self._conv(p + ".cv1", x, hin, Ls.c1, 2 * c, 1, 1, cat.slice(0, 2 * c))
-                for j in range(Ls.n):
-                    src = cat.slice((1 + j) * c, c)
-                    self._conv(f"{p}.m.{j}.cv1", src, hin, c, c, 3, 1, tmp)
-                    self._conv(f"{p}.m.{j}.cv2", tmp, hin, c, c, 3, 1, cat.slice((2 + j) * c, c),
-                               R=src if Ls.shortcut else None)
-                o = out_view(Ls.i, Ls.c2)
-                self._conv(p + ".cv2", cat, hin, (2 + Ls.n) * c, Ls.c2, 1, 1, o)
-                outv[Ls.i] = o
-            elif Ls.kind == "SPPF":
-                c_ = Ls.c1 // 2
-                h_, w_ = hin
-                cat = View(self._buf(B * h_ * w_, 4 * c_))
-                self._conv(p + ".cv1", x, hin, Ls.c1, c_, 1, 1, cat.slice(0, c_))
-                s0, s1, s2, s3 = (cat.slice(i * c_, c_) for i in range(4))
-                self._add(lib.moy_sppf_pool, s0.ptr, s0.ld, B, h_, w_, c_, s1.ptr, s2.ptr, s3.ptr, cat.ld, code)
-                o = out_view(Ls.i, Ls.c2)
-                self._conv(p + ".cv2", cat, hin, 4 * c_, Ls.c2, 1, 1, o)
-                outv[Ls.i] = o
-            elif Ls.kind == "Upsample":
-                o = out_view(Ls.i, Ls.c2)
-                self._add(lib.moy_upsample2x, x.ptr, x.ld, B, hin[0], hin[1], Ls.c1, o.ptr, o.ld, code)
-                outv[Ls.i] = o
-            elif Ls.kind == "Concat":
-                outv[Ls.i] = home[Ls.i]
+        hw: Dict[int, tuple] = {}
+        if self.head_only:
+            # MOTRTrack.forward surface: the three pyramid levels are the inputs (head.py:191)
+            self.input = None
+            self.head_inputs = []
+            for li, (h_, w_) in enumerate(self.shapes):
+                v = View(self._buf(B * h_ * w_, arch.head_ch[li]))
+                self.head_inputs.append(v)
+            head_src = [(v, hw_) for v, hw_ in zip(self.head_inputs, self.shapes)]
+        else:
+            if self.input_format == "u8":
+                self.input = torch.zeros(B, H, W, 3, device=self.dev, dtype=torch.uint8)
+            elif self.input_format == "f32":
+                self.input = torch.zeros(B, 3, H, W, device=self.dev, dtype=torch.float32)
             else:
-                raise ValueError(Ls.kind)
-        self.layer_views, self.layer_hw = outv, hw
+                raise ValueError(self.input_format)
 
+            # spatial size per layer output
+            cur = (H, W)
+            for Ls in arch.layers:
+                src_hw = hw[Ls.src[0]] if Ls.src[0] >= 0 else (H, W)
+                if Ls.kind == "Conv":
+                    cur = ((src_hw[0] + 2 * (Ls.k // 2) - Ls.k) // Ls.s + 1, (src_hw[1] + 2 * (Ls.k // 2) - Ls.k) // Ls.s + 1)
+                elif Ls.kind == "Upsample":
+                    cur = (src_hw[0] * 2, src_hw[1] * 2)
+                else:
+                    cur = src_hw
+                hw[Ls.i] = cur
+
+            # homes: outputs that feed a Concat live inside the concat buffer
+            home: Dict[int, View] = {}
+            for Ls in arch.layers:
+                if Ls.kind == "Concat":
+                    h_, w_ = hw[Ls.i]
+                    buf = self._buf(B * h_ * w_, Ls.c2)
+                    off = 0
+                    for j in Ls.src:
+                        cj = arch.layers[j].c2
+                        assert j not in home, "a tensor may live in one concat buffer only"
+                        home[j] = View(buf, off, cj)
+                        off += cj
+                    home[Ls.i] = View(buf)
+            def out_view(i, c):
+                if i in home:
+                    return home[i]
+                h_, w_ = hw[i]
+                return View(self._buf(B * h_ * w_, c))
+
+            for Ls in arch.layers:
+                p = f"model.{Ls.i}"
+                x = outv[Ls.src[0]] if Ls.src[0] >= 0 else None
+                hin = hw[Ls.src[0]] if Ls.src[0] >= 0 else (H, W)
+                if Ls.kind == "Conv" and Ls.i == 0:
+                    assert Ls.k == 3 and Ls.s == 2 and Ls.c1 == 3
+                    o = out_view(0, Ls.c2)
+                    wst = self._dev(sd[p + ".conv.weight"].permute(2, 3, 1, 0).reshape(27, Ls.c2))
+                    scale, shift = self._bn(p + ".bn")
+                    self._add(lib.moy_stem_conv, self.input.data_ptr(), 0 if self.input_format == "u8" else 1, B, H, W,
+                              wst.data_ptr(), scale.data_ptr(), shift.data_ptr(), Ls.c2, o.ptr, o.ld, code)
+                    outv[0] = o
+                elif Ls.kind == "Conv":
+                    o = out_view(Ls.i, Ls.c2)
+                    self._conv(p, x, hin, Ls.c1, Ls.c2, Ls.k, Ls.s, o)
+                    outv[Ls.i] = o
+                elif Ls.kind == "C2f":
+                    c = Ls.c2 // 2
+                    h_, w_ = hin
+                    cat = View(self._buf(B * h_ * w_, (2 + Ls.n) * c))
+                    tmp = View(self._buf(B * h_ * w_, c))
+                    self._conv(p + ".cv1", x, hin, Ls.c1, 2 * c, 1, 1, cat.slice(0, 2 * c))
+                    for j in range(Ls.n):
+                        src = cat.slice((1 + j) * c, c)
+                        self._conv(f"{p}.m.{j}.cv1", src, hin, c, c, 3, 1, tmp)
+                        self._conv(f"{p}.m.{j}.cv2", tmp, hin, c, c, 3, 1, cat.slice((2 + j) * c, c),
+                                   R=src if Ls.shortcut else None)
+                    o = out_view(Ls.i, Ls.c2)
+                    self._conv(p + ".cv2", cat, hin, (2 + Ls.n) * c, Ls.c2, 1, 1, o)
+                    outv[Ls.i] = o
+                elif Ls.kind == "SPPF":
+                    c_ = Ls.c1 // 2
+                    h_, w_ = hin
+                    cat = View(self._buf(B * h_ * w_, 4 * c_))
+                    self._conv(p + ".cv1", x, hin, Ls.c1, c_, 1, 1, cat.slice(0, c_))
+                    s0, s1, s2, s3 = (cat.slice(i * c_, c_) for i in range(4))
+                    self._add(lib.moy_sppf_pool, s0.ptr, s0.ld, B, h_, w_, c_, s1.ptr, s2.ptr, s3.ptr, cat.ld, code)
+                    o = out_view(Ls.i, Ls.c2)
+                    self._conv(p + ".cv2", cat, hin, 4 * c_, Ls.c2, 1, 1, o)
+                    outv[Ls.i] = o
+                elif Ls.kind == "Upsample":
+                    o = out_view(Ls.i, Ls.c2)
+                    self._add(lib.moy_upsample2x, x.ptr, x.ld, B, hin[0], hin[1], Ls.c1, o.ptr, o.ld, code)
+                    outv[Ls.i] = o
+                elif Ls.kind == "Concat":
+                    outv[Ls.i] = home[Ls.i]
+                else:
+                    raise ValueError(Ls.kind)
+            self.layer_views, self.layer_hw = outv, hw
+
+            head_src = [(outv[j], hw[j]) for j in (15, 18, 21)]
+        self._head_start = len(self._steps)
         # ---------------- head (MYDecoder)
         d = f"model.{nlayers}.decoder"
         hd, nq, nc, S, nl = arch.hd, arch.nq, arch.nc, self.S, arch.nl
         assert hd == 256 and arch.nh == 8 and arch.ndp == 4, "kernels are specialised to hd 256 / 8 heads / 4 points"
         feats = View(self._buf(B * S, hd))
         off = 0
-        for li, (j, (h_, w_)) in enumerate(zip((15, 18, 21), self.shapes)):
-            assert hw[j] == (h_, w_)
+        for li, ((src_view, src_hw), (h_, w_)) in enumerate(zip(head_src, self.shapes)):
+            assert tuple(src_hw) == (h_, w_)
             cin = arch.head_ch[li]
             Wt = self._weight(sd[f"{d}.input_proj.{li}.0.weight"].reshape(hd, cin))
             scale, shift = self._bn(f"{d}.input_proj.{li}.1")
             dst = View(feats.buf[off:], 0, hd) if off else feats
-            self._gemm(outv[j], Wt, hd, cin, dst, B * h_ * w_, scale=scale, shift=shift, c_rpb=h_ * w_, c_bstride=S)
+            self._gemm(src_view, Wt, hd, cin, dst, B * h_ * w_, scale=scale, shift=shift, c_rpb=h_ * w_, c_bstride=S)
             off += h_ * w_
         self.feats = feats
 
@@ -415,6 +427,13 @@ class TrackEngine:
             self._graph.replay()
         else:
             self.run_steps()
+        return self.outputs()
+
+    def forward_head(self, feats):
+        """MOTRTrack.forward surface: feats = [P3, P4, P5] NCHW-shaped device tensors."""
+        for v, (h_, w_), f in zip(self.head_inputs, self.shapes, feats):
+            v.buf.view(self.B, h_, w_, -1).copy_(f.permute(0, 2, 3, 1))
+        self.run_steps(self._head_start)
         return self.outputs()
 
     def forward_with_topk(self, frames, topk_local: torch.Tensor):

@@ -1,0 +1,104 @@
+"""Predictor counterpart: the reference's stream loop I/O contract for the `track` task.
+
+Mirrors `BasePredictor.__call__/stream_inference/preprocess` (ultralytics/engine/predictor.py:117-134,
+229-344), `TrackPredictor.postprocess` (ultralytics/models/MOTRtrack/predict.py:13-94) and
+`TrackResults.save_txt` (ultralytics/engine/results.py:366-371, 475-512).  Preprocess, the network
+and the row building all run on the device inside one TrackEngine step; this file only moves frames
+in, rows out, and formats text.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from .engine import TrackEngine
+
+
+class TrackResults:
+    """boxes: float32 [K, 6] = (x1, y1, x2, y2, score, cls) in `orig_shape` pixels (or normalised for
+    tensor sources, predict.py:66); track_id: int64 [K'] or None for the detection-style fallback."""
+
+    def __init__(self, boxes: np.ndarray, track_id, orig_shape, path="", speed=None):
+        self.boxes, self.track_id, self.orig_shape, self.path = boxes, track_id, tuple(orig_shape), path
+        self.speed = speed or {}
+
+    def __len__(self):
+        return len(self.boxes)
+
+    def txt_lines(self, save_conf=False) -> List[str]:
+        """`track_id cls cx cy w h [conf]`, xywh normalised by orig_shape, %g (results.py:495-507)."""
+        if self.track_id is None:
+            raise ValueError("detection-style fallback results carry no track ids")
+        h, w = self.orig_shape
+        out = []
+        for j in range(len(self.boxes)):
+            x1, y1, x2, y2, cf, c = (np.float32(v) for v in self.boxes[j])
+            xywhn = ((x1 + x2) / 2 / w, (y1 + y2) / 2 / h, (x2 - x1) / w, (y2 - y1) / h)
+            line = (int(self.track_id[j]), int(c), *xywhn) + ((float(cf),) if save_conf else ())
+            out.append(("%g " * len(line)).rstrip() % line)
+        return out
+
+    def save_txt(self, txt_file, save_conf=False):
+        lines = self.txt_lines(save_conf)
+        if lines:
+            with open(txt_file, "a") as f:
+                f.writelines(t + "\n" for t in lines)
+
+
+class TrackPredictor:
+    def __init__(self, arch, state_dict, imgsz=(608, 1088), conf=0.25, dtype=torch.float32, device="cuda", batch=1,
+                 graph=False):
+        self.arch, self.sd, self.imgsz, self.conf, self.dtype, self.device = arch, state_dict, tuple(imgsz), conf, dtype, device
+        self.batch, self.graph = batch, graph
+        self._engines = {}
+
+    def _engine(self, fmt):
+        if fmt not in self._engines:
+            H, W = self.imgsz
+            eng = TrackEngine(self.arch, self.sd, H, W, batch=self.batch, dtype=self.dtype, device=self.device,
+                              input_format=fmt, conf=self.conf, scale_boxes=(fmt == "u8"))
+            if self.graph:
+                eng.forward(torch.zeros_like(eng.input))
+                eng.capture()
+            self._engines[fmt] = eng
+        return self._engines[fmt]
+
+    def preprocess(self, im):
+        """List of uint8 BGR HWC frames (at network resolution) or float [B,3,H,W] in [0,1].
+        The BGR->RGB / CHW / float / 255 arithmetic of predictor.py:125-133 is fused into the stem
+        kernel, so 'preprocess' only validates and uploads."""
+        if isinstance(im, torch.Tensor):
+            if im.dim() != 4 or im.shape[1] != 3 or tuple(im.shape[2:]) != self.imgsz:
+                raise ValueError(f"tensor source must be [B,3,{self.imgsz[0]},{self.imgsz[1]}]")
+            if im.shape[2] % 32 or im.shape[3] % 32:
+                raise ValueError("tensor source sides must be multiples of 32 (data/loaders.py:316-332)")
+            return im.to(self.device, torch.float32), "f32"
+        arr = np.stack(im) if not isinstance(im, np.ndarray) else im
+        if arr.dtype != np.uint8 or arr.ndim != 4 or arr.shape[3] != 3:
+            raise ValueError("frame source must be uint8 [B,H,W,3] BGR")
+        if tuple(arr.shape[1:3]) != self.imgsz:
+            raise NotImplementedError("stretch-resize (LetterBox scaleFill, predict.py:96-105) is not part of this round: "
+                                      "feed frames at network resolution (SURVEY H7)")
+        return torch.from_numpy(arr).to(self.device), "u8"
+
+    @torch.no_grad()
+    def __call__(self, source, paths: Sequence[str] | None = None) -> List[TrackResults]:
+        x, fmt = self.preprocess(source)
+        eng = self._engine(fmt)
+        results: List[TrackResults] = []
+        n = x.shape[0]
+        for s in range(0, n, self.batch):
+            chunk = x[s:s + self.batch]
+            k = chunk.shape[0]
+            if k < self.batch:                                     # ragged tail: pad with the last frame
+                chunk = torch.cat([chunk, chunk[-1:].expand(self.batch - k, *chunk.shape[1:])], 0)
+            out = eng.forward(chunk.contiguous())
+            rows, tid = out["rows"].cpu().numpy(), out["track_id"].cpu().numpy()
+            n_rows, n_ids = out["n_rows"].cpu().numpy(), out["n_ids"].cpu().numpy()
+            for b in range(k):
+                t = None if n_ids[b] < 0 else tid[b, :n_ids[b]].copy()
+                results.append(TrackResults(rows[b, :n_rows[b]].copy(), t, self.imgsz,
+                                            path=(paths[s + b] if paths else "")))
+        return results

@@ -1,0 +1,94 @@
+"""CPU tests of host-side logic: architecture/state_dict surface, sharding over gloo (world 2),
+result formatting, synthetic streams."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from mo_yolo_amd.config import build_arch, level_shapes, param_shapes
+from mo_yolo_amd.synth import SyntheticSequence, to_network_input
+from tests._util import golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_arch_matches_survey_tables():
+    a = build_arch(0.33, 0.50, 1, 300)
+    assert a.head_ch == (128, 256, 256)                        # SURVEY §8 "Head input channels at s-scale"
+    assert [L.n for L in a.layers if L.kind == "C2f"] == [1, 2, 2, 1, 1, 1, 1, 1]
+    n_params = sum(int(np.prod(s)) for k, s in param_shapes(a).items() if not k.endswith("num_batches_tracked")
+                   and "running_" not in k)
+    assert n_params == 12849283                                 # 12.85 M params
+    assert sum(h * w for h, w in level_shapes(608, 1088)) == 13566
+    assert sum(h * w for h, w in level_shapes(1088, 1920)) == 42840
+
+
+def test_module_state_dict_keys_match_reference_names():
+    from mo_yolo_amd.modules import TrackingModel
+    m = TrackingModel(0.33, 0.25, nc=3, nq=20)
+    want = param_shapes(build_arch(0.33, 0.25, 3, 20))
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert set(got) == set(want)
+    assert all(got[k] == tuple(want[k]) for k in want)
+
+
+def test_synthetic_stream_is_deterministic_and_matches_golden_digest():
+    import hashlib
+    g = golden("c2")
+    fr = SyntheticSequence(0, 608, 1088, "mot17").frames(0, 1)
+    assert hashlib.sha256(fr.tobytes()).hexdigest() == str(g["frame0_sha256"])
+    x = to_network_input(fr)
+    assert x.shape == (1, 3, 608, 1088) and float(x.max()) <= 1.0
+    assert np.array_equal(fr[0, :, :, ::-1].transpose(2, 0, 1), (x[0] * 255).round().numpy().astype(np.uint8))
+
+
+def test_track_results_txt_matches_reference_lines():
+    from mo_yolo_amd.predictor import TrackResults
+    g = golden("tiny")
+    for t in range(3):
+        r = TrackResults(g[f"post.{t}.boxes"], g[f"post.{t}.track_id"].reshape(-1), (96, 160))
+        want = str(g[f"post.{t}.txt"]).strip().split("\n")
+        got = r.txt_lines()
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            fa, fb = a.split(), b.split()
+            assert fa[:2] == fb[:2] and np.allclose([float(v) for v in fa[2:]], [float(v) for v in fb[2:]], atol=2e-6)
+        wc = str(g[f"post.{t}.txt_conf"]).strip().split("\n")
+        assert [l.split()[-1] for l in r.txt_lines(save_conf=True)] == [l.split()[-1] for l in wc]
+
+
+_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from mo_yolo_amd import shard
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+seqs = shard.sequences_for_rank(8, rank, world)
+dt = shard.max_over_ranks(1.0 + rank)                 # rank 1 is the slow one
+res = shard.gather_objects({{"rank": rank, "seqs": seqs}})
+dist.barrier()
+if rank == 0:
+    print(json.dumps({{"dt": dt, "fps": shard.whole_job_fps(100, dt, world), "res": res}}))
+dist.destroy_process_group()
+"""
+
+
+def test_sharding_two_process_gloo(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    import json
+    d = json.loads(outs[0][0].decode().strip().splitlines()[-1])
+    assert d["dt"] == 2.0 and d["fps"] == 100.0                 # MAX over ranks; whole-job aggregate
+    assert d["res"][0]["seqs"] == [0, 2, 4, 6] and d["res"][1]["seqs"] == [1, 3, 5, 7]
