@@ -53,6 +53,7 @@ const char* moy_strerror(int code);
  *
  * A operand (channels-last activations, dtype T):
  *   ksize == 1: row m of A is A[arow(m) * lda + k];  arow(m) = a_rows ? a_rows[m] : m
+ *               (a gathered A must span < 2 GiB: it is addressed through one buffer descriptor)
  *   ksize == 3: m = (b, oy, ox) over [B, Hout, Wout]; k = (ky*3+kx)*Cin + c; the element is
  *               A[((b*Hin + oy*stride+ky-1)*Win + ox*stride+kx-1) * lda + c], 0 outside the image
  *               (pad = 1).  Cin must be a power of two >= 8 (bf16) / 4 (f32).
@@ -71,6 +72,7 @@ typedef struct moy_gemm_args {
   const void* A;
   const void* A2;
   const int32_t* a_rows;
+  int32_t a_rows_bound;   /* with a_rows: every a_rows[m] < a_rows_bound (rows of the A buffer) */
   const uint8_t* a_mask;
   int32_t mask_period;
   int64_t lda;

@@ -20,7 +20,7 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 class GemmArgs(C.Structure):
     """Mirror of `moy_gemm_args` (include/moyolo.h)."""
     _fields_ = [
-        ("A", vp), ("A2", vp), ("a_rows", vp), ("a_mask", vp), ("mask_period", i32), ("lda", i64),
+        ("A", vp), ("A2", vp), ("a_rows", vp), ("a_rows_bound", i32), ("a_mask", vp), ("mask_period", i32), ("lda", i64),
         ("W", vp), ("M", i32), ("N", i32), ("K", i32), ("ksize", i32), ("stride", i32),
         ("B", i32), ("Hin", i32), ("Win", i32), ("Hout", i32), ("Wout", i32), ("Cin", i32),
         ("scale", vp), ("shift", vp), ("act", i32), ("R", vp), ("ldr", i64), ("ln_g", vp), ("ln_b", vp),

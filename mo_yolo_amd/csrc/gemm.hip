@@ -29,6 +29,7 @@ struct GemmParams {
   const uint8_t* a_mask;
   int mask_period;
   int64_t lda;
+  int64_t a_bytes;   // bytes addressable from A (bounds of the buffer descriptor)
   const void* W;
   int M, N, K, Kpad;
   int ksize, stride;
@@ -92,56 +93,89 @@ constexpr int gemm_lds_bytes() {
   return stage > epi ? stage : epi;
 }
 
+// ---- epilogue, part 1 (registers): v = act(acc * scale + shift), then the fp32 tile goes to LDS.
+// Each lane owns 4 consecutive output channels per 16x16 sub-tile, so scale/shift are NT float4
+// loads per lane, waited for once in straight-line code.
+template <int ACT>
+__device__ __forceinline__ f32x4 act4(f32x4 v) {
+  if (ACT == MOY_ACT_SILU) { v.x = siluf_(v.x); v.y = siluf_(v.y); v.z = siluf_(v.z); v.w = siluf_(v.w); }
+  else if (ACT == MOY_ACT_RELU) { v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f}); }
+  else if (ACT == MOY_ACT_SIGMOID) { v.x = fast_sigmoid(v.x); v.y = fast_sigmoid(v.y); v.z = fast_sigmoid(v.z); v.w = fast_sigmoid(v.w); }
+  return v;
+}
+
+template <int ACT, int BN, int TM, int TN, int MT, int NT>
+__device__ __forceinline__ void stage_acc_act(const GemmParams& p, f32x4 (&acc)[MT][NT], float* Cs, int n0, int wm, int wn, int r,
+                                              int q) {
+  constexpr int LDC = BN + 4;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int nl = wn * TN + j * 16 + q * 4, n = n0 + nl;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (n < p.N) {
+      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int ml = wm * TM + i * 16 + r;     // D[n_local = q*4 + reg][m_local = r]
+      *reinterpret_cast<f32x4*>(Cs + ml * LDC + nl) = act4<ACT>(acc[i][j] * sc + sh);
+    }
+  }
+}
+
+template <int BN, int TM, int TN, int MT, int NT>
+__device__ __forceinline__ void stage_acc(const GemmParams& p, f32x4 (&acc)[MT][NT], float* Cs, int n0, int wm, int wn, int r, int q) {
+  switch (p.act) {   // wave-uniform: one branch, not one per element
+    case MOY_ACT_SILU: stage_acc_act<MOY_ACT_SILU, BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q); break;
+    case MOY_ACT_RELU: stage_acc_act<MOY_ACT_RELU, BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q); break;
+    case MOY_ACT_SIGMOID: stage_acc_act<MOY_ACT_SIGMOID, BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q); break;
+    default: stage_acc_act<MOY_ACT_NONE, BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q); break;
+  }
+}
+
+// ---- epilogue, part 2 (after the barrier): row-wise pass over the LDS tile: residual add,
+// optional LayerNorm (wave shuffles), coalesced vector stores.  The pass is FULLY UNROLLED with all
+// residual loads issued up front: CDNA4's vmcnt counts stores too, so a wait placed inside a rolled
+// store loop (as hipcc did for the first version: s_waitcnt vmcnt(0) per iteration) serialises every
+// store behind the HBM write latency -- that alone was ~60 % of the 1x1-GEMM time.
 template <typename T, int BM, int BN, bool LN, int NTHR>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const float* Cs, int m0, int n0, int tid) {
   constexpr int LDC = BN + 4;
   const int lane = tid & 63, wave = tid >> 6;
   const T* __restrict__ Rg = static_cast<const T*>(p.R);
-  if (!LN) {
-    constexpr int CPR = BN / 4;          // 4-column chunks per row
-    constexpr int RSTEP = NTHR / CPR;
-    const int cc = tid % CPR, rr0 = tid / CPR;
-    const int n = n0 + cc * 4;
-    if (n < p.N) {                        // N % 4 == 0 (host-checked)
-      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-      for (int rr = rr0; rr < BM; rr += RSTEP) {
-        const int m = m0 + rr;
-        if (m >= p.M) break;
-        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + cc * 4);
-        v = v * sc + sh;
-        v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
-        v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
-        if (Rg) v += DT<T>::load4(Rg + (int64_t)m * p.ldr + n);
-        const int64_t mo = p.c_rpb ? (int64_t)(m / p.c_rpb) * p.c_bstride + (m % p.c_rpb) : (int64_t)m;
-        if (p.out_f32)
-          *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + mo * p.ldc + n) = v;
-        else
-          DT<T>::store4(static_cast<T*>(p.C) + mo * p.ldc + n, v);
-      }
+  constexpr int CPR = LN ? 64 : BN / 4;             // 4-column chunks per row handled per pass
+  constexpr int RSTEP = LN ? NTHR / 64 : NTHR / CPR; // rows advanced per pass
+  constexpr int NPASS = BM / RSTEP;
+  const int cc = LN ? lane : tid % CPR;
+  const int rr0 = LN ? wave : tid / CPR;
+  const int n = n0 + cc * 4;
+  const bool col_ok = n < p.N;                      // N % 4 == 0 (host-checked)
+  f32x4 res[NPASS];
+  if (Rg) {
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {
+      const int m = m0 + rr0 + k * RSTEP;
+      res[k] = (col_ok && m < p.M) ? DT<T>::load4(Rg + (int64_t)m * p.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  } else {
-    // one wave per row; lane owns columns lane*4 .. +3 (N == BN == 256)
-    const int n = lane * 4;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-    if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-    const f32x4 g = *reinterpret_cast<const f32x4*>(p.ln_g + n);
-    const f32x4 be = *reinterpret_cast<const f32x4*>(p.ln_b + n);
-    for (int rr = wave; rr < BM; rr += NTHR / 64) {
-      const int m = m0 + rr;
-      if (m >= p.M) break;
-      f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + n);
-      v = v * sc + sh;
-      v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
-      v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
-      if (Rg) v += DT<T>::load4(Rg + (int64_t)m * p.ldr + n);
+  }
+  f32x4 g = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+  if (LN) {
+    g = *reinterpret_cast<const f32x4*>(p.ln_g + n);
+    be = *reinterpret_cast<const f32x4*>(p.ln_b + n);
+  }
+#pragma unroll
+  for (int k = 0; k < NPASS; ++k) {
+    const int rr = rr0 + k * RSTEP, m = m0 + rr;
+    f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + cc * 4);
+    if (Rg) v += res[k];
+    if (LN) {   // one wave per row; lane owns columns lane*4 .. +3 (N == BN == 256)
       const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / 256.0f);
       const f32x4 d = v - mean;
       const float var = wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * (1.0f / 256.0f);
-      const float rstd = 1.0f / sqrtf(var + 1e-5f);
-      v = d * rstd * g + be;
+      v = d * (1.0f / sqrtf(var + 1e-5f)) * g + be;
+    }
+    if (col_ok && m < p.M) {
       const int64_t mo = p.c_rpb ? (int64_t)(m / p.c_rpb) * p.c_bstride + (m % p.c_rpb) : (int64_t)m;
       if (p.out_f32)
         *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + mo * p.ldc + n) = v;
@@ -156,8 +190,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   constexpr int KPB = DT<T>::KPB;      // elements per 16-B chunk
   constexpr int BKP = 4 * KPB;         // elements per 64-B panel
   constexpr int BK = BKP * PANELS;     // elements per stage
-  constexpr int RA = BM / 64;          // A rows staged per thread (per panel)
-  constexpr int RB = BN / 64;
   constexpr int TM = BM / WGM, TN = BN / WGN;
   constexpr int MT = TM / 16, NT = TN / 16;
   constexpr int A_BYTES = BM * PANELS * 64, B_BYTES = BN * PANELS * 64;
@@ -186,96 +218,115 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   const T* __restrict__ A2g = static_cast<const T*>(p.A2);
   const T* __restrict__ Wg = static_cast<const T*>(p.W);
 
-  // ---- per-thread staging coordinates (loop invariant)
-  const int srow = tid >> 2, sq = tid & 3;
-  int64_t a_off[RA];   // element offset of the row start (ksize 1) / of pixel (b, 0, 0) (ksize 3)
-  bool a_ok[RA];
-  int iy0[RA], ix0[RA];
+  // ---- per-thread staging coordinates (loop invariant).  A wave-instruction covers 8 rows x 128 B
+  // (both 64-B panels of a row).  All global reads are buffer loads: a wave-uniform descriptor plus a
+  // 32-bit per-lane byte offset computed ONCE; rows beyond M / N, masked rows, taps outside the image
+  // and the K tail use an out-of-range offset that the hardware range check turns into zeros.  The
+  // k advance of a 1x1 conv / linear is the scalar `soffset`, so its main loop issues no address VALU
+  // at all (the first version spent ~35 VALU ops per 16-B chunk on 64-bit addressing + predicates
+  // and was VALU-bound: profiles/r01_b_pmc_gemm.txt).
+  static_assert(PANELS == 2, "staging map assumes two 64-B panels per stage");
+  constexpr int RA2 = BM / 32, RB2 = BN / 32;
+  constexpr int ESZ = 16 / KPB;
+  constexpr uint32_t OOB = 0x80000000u;        // >= num_records of every descriptor below
+  const int srow = tid >> 3, spn = (tid >> 2) & 1, sq = tid & 3;
+  const int kc0 = spn * BKP + sq * KPB;        // this thread's k element inside a stage
+
+  // descriptors (built from kernel arguments / blockIdx only => provably wave-uniform)
+  int b0 = 0;
+  int64_t a_base = 0;                          // element offset of the descriptor base inside A
+  if (KS == 1) {
+    if (!p.a_rows) a_base = (int64_t)m0 * p.lda;
+  } else {
+    b0 = m0 / (p.Hout * p.Wout);
+    a_base = (int64_t)b0 * p.Hin * p.Win * p.lda;
+  }
+  const int64_t a_left = p.a_bytes - a_base * ESZ;
+  const uint32_t a_rec = (uint32_t)(a_left < 0x7fffffffLL ? a_left : 0x7fffffffLL);
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Ag + a_base), 0, a_rec, 0x00020000);
+  const auto rsA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>((A2g ? A2g : Ag) + a_base), 0, a_rec, 0x00020000);
+  const int64_t w_base = (int64_t)n0 * p.Kpad;
+  const int64_t w_left = ((int64_t)p.N * p.Kpad - w_base) * ESZ;
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Wg + w_base), 0,
+                                                     (uint32_t)(w_left < 0x7fffffffLL ? w_left : 0x7fffffffLL), 0x00020000);
+
+  uint32_t a_voff[RA2];    // byte offset of (row, kc0) for ksize 1; of pixel (iy0, ix0) channel 0 for ksize 3
+  uint32_t a_taps[RA2];    // ksize 3: bit t set <=> tap t of this output pixel lies inside the image
 #pragma unroll
-  for (int j = 0; j < RA; ++j) {
-    const int m = m0 + srow + j * 64;
-    a_ok[j] = m < p.M;
-    a_off[j] = 0;
-    iy0[j] = ix0[j] = 0;
-    if (a_ok[j]) {
+  for (int j = 0; j < RA2; ++j) {
+    const int m = m0 + srow + j * 32;
+    a_voff[j] = OOB;
+    a_taps[j] = 0;
+    if (m < p.M) {
       if (KS == 1) {
-        if (p.a_mask && p.a_mask[m % p.mask_period] == 0) a_ok[j] = false;
-        const int64_t row = p.a_rows ? (int64_t)p.a_rows[m] : (int64_t)m;
-        a_off[j] = row * p.lda;
+        const bool masked = p.a_mask && p.a_mask[m % p.mask_period] == 0;
+        const int64_t row = p.a_rows ? (int64_t)p.a_rows[m] : (int64_t)(m - m0);
+        if (!masked) a_voff[j] = (uint32_t)((row * p.lda + kc0) * ESZ);
       } else {
         const int hw = p.Hout * p.Wout;
         const int b = m / hw, rem = m - b * hw;
         const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-        iy0[j] = oy * p.stride - 1;
-        ix0[j] = ox * p.stride - 1;
-        a_off[j] = (int64_t)b * p.Hin * p.Win * p.lda;
+        const int iy0 = oy * p.stride - 1, ix0 = ox * p.stride - 1;
+        a_voff[j] = (uint32_t)((((int64_t)(b - b0) * p.Hin + iy0) * p.Win + ix0) * p.lda * ESZ);   // may wrap below 0: fixed by the tap delta
+        uint32_t msk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+          if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) msk |= 1u << t;
+        }
+        a_taps[j] = msk;
       }
     }
   }
-  int64_t b_off[RB];
-  bool b_ok[RB];
+  uint32_t b_voff[RB2];
 #pragma unroll
-  for (int j = 0; j < RB; ++j) {
-    const int n = n0 + srow + j * 64;
-    b_ok[j] = n < p.N;
-    b_off[j] = (int64_t)n * p.Kpad;
+  for (int j = 0; j < RB2; ++j) {
+    const int n = n0 + srow + j * 32;
+    b_voff[j] = n < p.N ? (uint32_t)(((int64_t)(srow + j * 32) * p.Kpad + kc0) * ESZ) : OOB;
   }
 
-  u32x4 areg[PANELS][RA], breg[PANELS][RB];
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  u32x4 areg[RA2], breg[RB2];
 
   auto load_stage = [&](int kt) {
+    const int soff = kt * BK * ESZ;            // wave-uniform k advance in bytes
+    if (KS == 1) {
+      const bool ktail = kt * BK + kc0 >= p.K; // only the zero-padded tail of K (Kpad > K)
 #pragma unroll
-    for (int pn = 0; pn < PANELS; ++pn) {
-      const int kc = kt * BK + pn * BKP + sq * KPB;
-      if (KS == 1) {
-        const bool kin = kc < p.K;
+      for (int j = 0; j < RA2; ++j) areg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ktail ? OOB : a_voff[j], soff, 0);
+      if (A2g) {                                // prologue add (q = k = x + pos): second stream, same offsets
+        u32x4 t2[RA2];
 #pragma unroll
-        for (int j = 0; j < RA; ++j) {
-          u32x4 v = zero4;
-          if (a_ok[j] && kin) {
-            v = *reinterpret_cast<const u32x4*>(Ag + a_off[j] + kc);
-            if (A2g) v = add_chunks<T>(v, *reinterpret_cast<const u32x4*>(A2g + a_off[j] + kc));
-          }
-          areg[pn][j] = v;
-        }
-      } else {
-        const int tap = kc >> p.lgC, c = kc & (p.Cin - 1);
-        const int ky = (tap * 11) >> 5, kx = tap - ky * 3;   // tap / 3 for tap < 16
-        const bool kin = tap < 9;
+        for (int j = 0; j < RA2; ++j) t2[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA2, ktail ? OOB : a_voff[j], soff, 0);
 #pragma unroll
-        for (int j = 0; j < RA; ++j) {
-          const int iy = iy0[j] + ky, ix = ix0[j] + kx;
-          u32x4 v = zero4;
-          if (a_ok[j] && kin && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win)
-            v = *reinterpret_cast<const u32x4*>(Ag + a_off[j] + ((int64_t)iy * p.Win + ix) * p.lda + c);
-          areg[pn][j] = v;
-        }
+        for (int j = 0; j < RA2; ++j) areg[j] = add_chunks<T>(areg[j], t2[j]);
       }
+    } else {
+      const int kc = kt * BK + kc0;
+      const int tap = kc >> p.lgC, c = kc & (p.Cin - 1);
+      const int ky = (tap * 11) >> 5, kx = tap - ky * 3;   // tap / 3 for tap < 16
+      const uint32_t delta = (uint32_t)(((ky * p.Win + kx) * (int)p.lda + c) * ESZ);
 #pragma unroll
-      for (int j = 0; j < RB; ++j) {
-        u32x4 v = zero4;
-        if (b_ok[j]) v = *reinterpret_cast<const u32x4*>(Wg + b_off[j] + kc);   // kc < Kpad by construction
-        breg[pn][j] = v;
+      for (int j = 0; j < RA2; ++j) {
+        const uint32_t vo = ((a_taps[j] >> tap) & 1u) ? a_voff[j] + delta : OOB;   // tap >= 9 never set
+        areg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0);
       }
     }
+#pragma unroll
+    for (int j = 0; j < RB2; ++j) breg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, b_voff[j], soff, 0);
   };
 
   auto store_stage = [&](int buf) {
     unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
     unsigned char* Bs = As + A_BYTES;
 #pragma unroll
-    for (int pn = 0; pn < PANELS; ++pn) {
+    for (int j = 0; j < RA2; ++j) {
+      const int row = srow + j * 32;
+      *reinterpret_cast<u32x4*>(As + (spn * BM + row) * 64 + swz(row, sq) * 16) = areg[j];
+    }
 #pragma unroll
-      for (int j = 0; j < RA; ++j) {
-        const int row = srow + j * 64;
-        *reinterpret_cast<u32x4*>(As + (pn * BM + row) * 64 + swz(row, sq) * 16) = areg[pn][j];
-      }
-#pragma unroll
-      for (int j = 0; j < RB; ++j) {
-        const int row = srow + j * 64;
-        *reinterpret_cast<u32x4*>(Bs + (pn * BN + row) * 64 + swz(row, sq) * 16) = breg[pn][j];
-      }
+    for (int j = 0; j < RB2; ++j) {
+      const int row = srow + j * 32;
+      *reinterpret_cast<u32x4*>(Bs + (spn * BN + row) * 64 + swz(row, sq) * 16) = breg[j];
     }
   };
 
@@ -317,16 +368,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 
   // ---- epilogue: accumulators -> LDS fp32 tile [BM][BN+4]
-  constexpr int LDC = BN + 4;
   float* Cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      // D[n_local = q*4 + reg][m_local = r]
-      const int ml = wm * TM + i * 16 + r, nl = wn * TN + j * 16 + q * 4;
-      *reinterpret_cast<f32x4*>(Cs + ml * LDC + nl) = acc[i][j];
-    }
+  stage_acc<BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q);
   __syncthreads();
 
   gemm_epilogue<T, BM, BN, LN, 256>(p, Cs, m0, n0, tid);
@@ -505,15 +548,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_dma_kernel(const GemmPara
   }
   __syncthreads();   // all waves done with the ring before it is reused as the fp32 output tile
 
-  constexpr int LDC = BN + 4;
   float* Cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int ml = wm * TM + i * 16 + r, nl = wn * TN + j * 16 + q * 4;
-      *reinterpret_cast<f32x4*>(Cs + ml * LDC + nl) = acc[i][j];
-    }
+  stage_acc<BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q);
   __syncthreads();
   gemm_epilogue<T, BM, BN, LN, NTHR>(p, Cs, m0, n0, tid);
 }
@@ -547,6 +583,171 @@ static int dispatch_dma(GemmParams& p, bool ln, hipStream_t st) {
   const long mid = (long)((p.M + 127) / 128);
   if (mid >= 384) return launch_dma<T, 128, 64, 2, 2, false, KS, 3>(p, st);
   return launch_dma<T, 64, 64, 2, 2, false, KS, 3>(p, st);
+}
+
+
+// =================================================================================================
+// Streaming GEMM for 1x1 convs / linears (ksize 1, no LayerNorm) whose weight tile fits in LDS:
+//   * a block owns BN output columns; its [BN, Kpad] weight tile is loaded into LDS ONCE and stays
+//     there while the block walks over row tiles (persistent along M) -> no weight re-staging;
+//   * activations never touch LDS: each lane loads its MFMA operand chunks (16 B) straight from
+//     global memory, a whole row tile (all of K) per wave is in flight at once, and the NEXT row
+//     tile is prefetched into a second register set while the current one is multiplied;
+//   * waves are independent after the one barrier that publishes the weight tile: no barrier in
+//     the main loop;
+//   * epilogue straight from the accumulators (each lane owns 4 consecutive output channels of a
+//     row): scale/shift, activation, residual, 8/16-byte stores.
+// These GEMMs stream M rows once against a small weight matrix; the design keeps tens of KB per
+// CU continuously in flight instead of alternating load / LDS-write / barrier / compute phases.
+template <typename T, int BN, int MT, int NPMAX>
+__global__ __launch_bounds__(256) void gemm_stream_kernel(const GemmParams p, int row_groups) {
+  constexpr int KPB = DT<T>::KPB, BKP = 4 * KPB;
+  constexpr int NT = BN / 16;
+  constexpr int ROWS_W = MT * 16, ROWS_B = 4 * ROWS_W;      // rows per wave / per block iteration
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int np = p.Kpad / BKP;
+
+  int bid = blockIdx.x;
+  {
+    const int nb = p.nblocks, qd = nb >> 3, rm = nb & 7, x = bid & 7;
+    bid = (x < rm ? x * (qd + 1) : rm * (qd + 1) + (x - rm) * qd) + (bid >> 3);
+  }
+  const int tile_n = bid % p.tiles_n, rg = bid / p.tiles_n;
+  const int n0 = tile_n * BN;
+
+  const T* __restrict__ Ag = static_cast<const T*>(p.A);
+  const T* __restrict__ A2g = static_cast<const T*>(p.A2);
+  const T* __restrict__ Wg = static_cast<const T*>(p.W);
+  const T* __restrict__ Rg = static_cast<const T*>(p.R);
+
+  // ---- weight tile -> LDS, [panel][BN][64 B], 16-B columns swizzled
+  for (int c = tid; c < np * BN * 4; c += 256) {
+    const int pn = c / (BN * 4), rem = c - pn * BN * 4, row = rem >> 2, cq = rem & 3;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (n0 + row < p.N) v = *reinterpret_cast<const u32x4*>(Wg + (int64_t)(n0 + row) * p.Kpad + pn * BKP + cq * KPB);
+    *reinterpret_cast<u32x4*>(smem + (pn * BN + row) * 64 + swz(row, cq) * 16) = v;
+  }
+  __syncthreads();
+
+  const int n_row_tiles = (p.M + ROWS_B - 1) / ROWS_B;
+  u32x4 areg[2][NPMAX][MT];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  auto load_tile = [&](int rt, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = rt * ROWS_B + wave * ROWS_W + i * 16 + r;
+      bool ok = m < p.M;
+      if (ok && p.a_mask && p.a_mask[m % p.mask_period] == 0) ok = false;
+      const int64_t off = ok ? (p.a_rows ? (int64_t)p.a_rows[m] : (int64_t)m) * p.lda + q * KPB : 0;
+#pragma unroll
+      for (int pn = 0; pn < NPMAX; ++pn) {
+        u32x4 v = zero4;
+        if (pn < np && ok && pn * BKP + q * KPB < p.K) {
+          v = *reinterpret_cast<const u32x4*>(Ag + off + pn * BKP);
+          if (A2g) v = add_chunks<T>(v, *reinterpret_cast<const u32x4*>(A2g + off + pn * BKP));
+        }
+        areg[SET][pn][i] = v;
+      }
+    }
+  };
+
+  auto compute_tile = [&](int rt, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pn = 0; pn < NPMAX; ++pn)
+      if (pn < np) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int row = j * 16 + r;
+          const u32x4 wf = *reinterpret_cast<const u32x4*>(smem + (pn * BN + row) * 64 + swz(row, q) * 16);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) mma_panel<T>(acc[i][j], wf, areg[SET][pn][i]);
+        }
+      }
+    // epilogue from registers: lane owns channels n .. n+3 of row m
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + j * 16 + q * 4;
+      if (n < p.N) {
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int m = rt * ROWS_B + wave * ROWS_W + i * 16 + r;
+          if (m < p.M) {
+            f32x4 v = acc[i][j] * sc + sh;
+            v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
+            v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+            if (Rg) v += DT<T>::load4(Rg + (int64_t)m * p.ldr + n);
+            const int64_t mo = p.c_rpb ? (int64_t)(m / p.c_rpb) * p.c_bstride + (m % p.c_rpb) : (int64_t)m;
+            if (p.out_f32)
+              *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + mo * p.ldc + n) = v;
+            else
+              DT<T>::store4(static_cast<T*>(p.C) + mo * p.ldc + n, v);
+          }
+        }
+      }
+    }
+  };
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  int rt = rg;
+  if (rt < n_row_tiles) load_tile(rt, S0{});
+  while (rt < n_row_tiles) {
+    const int rt1 = rt + row_groups;
+    if (rt1 < n_row_tiles) load_tile(rt1, S1{});
+    compute_tile(rt, S0{});
+    if (rt1 >= n_row_tiles) break;
+    const int rt2 = rt1 + row_groups;
+    if (rt2 < n_row_tiles) load_tile(rt2, S0{});
+    compute_tile(rt1, S1{});
+    rt = rt2;
+  }
+}
+
+template <typename T, int BN, int MT, int NPMAX>
+static int launch_stream(GemmParams& p, hipStream_t st) {
+  constexpr int BKP = 4 * DT<T>::KPB;
+  const int np = p.Kpad / BKP;
+  const int lds = np * BN * 64;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const int n_row_tiles = (p.M + 64 * MT - 1) / (64 * MT);
+  // about two resident blocks per CU (512) so that the weight tile is loaded few times and row
+  // tiles are spread evenly
+  int row_groups = (512 + p.tiles_n - 1) / p.tiles_n;
+  if (row_groups > n_row_tiles) row_groups = n_row_tiles;
+  p.nblocks = row_groups * p.tiles_n;
+  auto kern = gemm_stream_kernel<T, BN, MT, NPMAX>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+      return MOY_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds, st, p, row_groups);
+  return launch_status();
+}
+
+// Returns MOY_ENOSYS when the shape does not fit the streaming kernel (caller falls back).
+template <typename T>
+static int dispatch_stream(GemmParams& p, hipStream_t st) {
+  constexpr int BKP = 4 * DT<T>::KPB;
+  const int np = p.Kpad / BKP;
+  if (np <= 4) return launch_stream<T, 128, 2, 4>(p, st);
+  if (np <= 8) return launch_stream<T, 128, 2, 8>(p, st);
+  if (np <= 16) return launch_stream<T, 64, 2, 16>(p, st);
+  return MOY_ENOSYS;
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, bool LN, int KS>
@@ -606,6 +807,20 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
   if (a->a_rows && a->ksize != 1) return MOY_EINVAL;
 
   GemmParams p{};
+  {
+    // bytes reachable from A: the descriptor bound.  ksize 1: the last row read (gathered rows may be
+    // anywhere below a_rows_bound) ; ksize 3: the whole [B, Hin, Win] image stack.
+    const int64_t rows = a->ksize == 3 ? (int64_t)a->B * a->Hin * a->Win : (a->a_rows ? a->a_rows_bound : (int64_t)a->M);
+    if (a->a_rows && a->a_rows_bound <= 0) return MOY_EINVAL;
+    p.a_bytes = ((rows - 1) * a->lda + (a->ksize == 3 ? a->Cin : a->K)) * esz;
+    if (a->a_rows && p.a_bytes > 0x7fffffffLL) return MOY_ENOSYS;    // gathered rows need one 2 GiB window
+    if (a->ksize == 3) {   // a 128-row tile may span several images: all of them must fit one 2 GiB window
+      const int64_t span = 128 / ((int64_t)a->Hout * a->Wout > 0 ? (int64_t)a->Hout * a->Wout : 1) + 2;
+      const int64_t img = (int64_t)a->Hin * a->Win * a->lda * esz;
+      if (span * img > 0x7fffffffLL && (int64_t)a->B * img > 0x7fffffffLL) return MOY_ENOSYS;
+    }
+    if (a->ksize == 1 && !a->a_rows && (int64_t)256 * a->lda * esz > 0x7fffffffLL) return MOY_ENOSYS;
+  }
   p.A = a->A; p.A2 = a->A2; p.a_rows = a->a_rows; p.a_mask = a->a_mask; p.mask_period = a->mask_period;
   p.lda = a->lda; p.W = a->W; p.M = a->M; p.N = a->N; p.K = a->K;
   p.Kpad = (a->K + bk - 1) / bk * bk;
@@ -634,6 +849,14 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
   // blocks per CU, and loses 20-50 % to the register-staged kernel at 2-3 blocks per CU on every
   // shape of this path -- these short-K GEMMs hide latency with occupancy, not with ring depth.
   static const bool use_dma = [] { const char* e = getenv("MOY_GEMM_IMPL"); return e && e[0] == 'd'; }();
+  // Streaming variant (weights resident in LDS, activations straight to registers): measured 1.5-2.3x
+  // SLOWER than the LDS-staged kernel (value GEMM 2533 vs 1120 us): its fragment-shaped accesses
+  // (16 rows x 64 B per load, 16 rows x 32 B per store) multiply the request count per byte.  Opt-in only.
+  static const bool use_stream = [] { const char* e = getenv("MOY_GEMM_STREAM"); return e && e[0] == '1'; }();
+  if (use_stream && a->ksize == 1 && !ln) {
+    const int rc = a->dtype == MOY_BF16 ? dispatch_stream<bf16_t>(p, st) : dispatch_stream<float>(p, st);
+    if (rc != MOY_ENOSYS) return rc;
+  }
   if (!a->A2 && use_dma) {   // the A + A2 prologue add needs the register-staged kernel
     if (a->dtype == MOY_BF16)
       return a->ksize == 1 ? dispatch_dma<bf16_t, 1>(p, ln, st) : dispatch_dma<bf16_t, 3>(p, ln, st);

@@ -123,6 +123,7 @@ class TrackEngine:
         if A2 is not None:
             assert A2.ld == A.ld
         a.a_rows = a_rows.data_ptr() if a_rows is not None else None
+        a.a_rows_bound = A.rows if a_rows is not None else 0
         a.a_mask = a_mask.data_ptr() if a_mask is not None else None
         a.mask_period = mask_period
         a.W, a.M, a.N, a.K = Wt.data_ptr(), M, N, K

@@ -54,7 +54,7 @@ def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shi
         a.A2 = A2.data_ptr()
     if a_rows is not None:
         assert a_rows.dtype == torch.int32
-        a.a_rows = a_rows.data_ptr()
+        a.a_rows, a.a_rows_bound = a_rows.data_ptr(), A.shape[0]
     if a_mask is not None:
         assert a_mask.dtype == torch.uint8
         a.a_mask, a.mask_period = a_mask.data_ptr(), mask_period

@@ -48,7 +48,7 @@ def make(s):
     out = torch.empty(M, Cout, device=dev, dtype=dt)
     conv = H > 1          # backbone convs carry BN + SiLU; the head / decoder linears only a bias
     kw = dict(out=out, ksize=ks, stride=st, geom=geom, scale=sc if conv else None, shift=sh,
-              act=L.ACT_SILU if conv else L.ACT_NONE)
+              act=(L.ACT_SILU if conv else L.ACT_NONE))
     if ln:
         kw.update(ln=(sc, sh), act=L.ACT_NONE)
     alg = (x.numel() + w.numel() + out.numel()) * 2
