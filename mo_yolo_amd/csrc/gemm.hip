@@ -151,19 +151,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const float* 
   const int rr0 = LN ? wave : tid / CPR;
   const int n = n0 + cc * 4;
   const bool col_ok = n < p.N;                      // N % 4 == 0 (host-checked)
+  const int nc = col_ok ? n : 0;                    // clamped column: loads below are always in range
   f32x4 res[NPASS];
-  if (Rg) {
+  if (Rg) {   // straight-line, branch-free loads (clamped row), so all NPASS are in flight together
+    const T* rp = Rg + nc;
 #pragma unroll
     for (int k = 0; k < NPASS; ++k) {
-      const int m = m0 + rr0 + k * RSTEP;
-      res[k] = (col_ok && m < p.M) ? DT<T>::load4(Rg + (int64_t)m * p.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const int m = min(m0 + rr0 + k * RSTEP, p.M - 1);
+      res[k] = DT<T>::load4(rp + (int64_t)m * p.ldr);
     }
   }
   f32x4 g = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
   if (LN) {
-    g = *reinterpret_cast<const f32x4*>(p.ln_g + n);
-    be = *reinterpret_cast<const f32x4*>(p.ln_b + n);
+    g = *reinterpret_cast<const f32x4*>(p.ln_g + nc);
+    be = *reinterpret_cast<const f32x4*>(p.ln_b + nc);
   }
+  const int out_esz = p.out_f32 ? 4 : (int)sizeof(T);
+  unsigned char* cbase = static_cast<unsigned char*>(p.C) + (int64_t)n * out_esz;
 #pragma unroll
   for (int k = 0; k < NPASS; ++k) {
     const int rr = rr0 + k * RSTEP, m = m0 + rr;
@@ -176,11 +180,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const float* 
       v = d * (1.0f / sqrtf(var + 1e-5f)) * g + be;
     }
     if (col_ok && m < p.M) {
-      const int64_t mo = p.c_rpb ? (int64_t)(m / p.c_rpb) * p.c_bstride + (m % p.c_rpb) : (int64_t)m;
+      int64_t mo = m;
+      if (p.c_rpb) mo = (int64_t)(m / p.c_rpb) * p.c_bstride + (m % p.c_rpb);   // wave-uniform rare path
+      unsigned char* cp = cbase + mo * p.ldc * out_esz;
       if (p.out_f32)
-        *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + mo * p.ldc + n) = v;
+        *reinterpret_cast<f32x4*>(cp) = v;
       else
-        DT<T>::store4(static_cast<T*>(p.C) + mo * p.ldc + n, v);
+        DT<T>::store4(reinterpret_cast<T*>(cp), v);
     }
   }
 }
