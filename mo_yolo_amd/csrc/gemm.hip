@@ -192,14 +192,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const float* 
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, bool LN, int KS>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p) {
   constexpr int KPB = DT<T>::KPB;      // elements per 16-B chunk
   constexpr int BKP = 4 * KPB;         // elements per 64-B panel
   constexpr int BK = BKP * PANELS;     // elements per stage
   constexpr int TM = BM / WGM, TN = BN / WGN;
   constexpr int MT = TM / 16, NT = TN / 16;
   constexpr int A_BYTES = BM * PANELS * 64, B_BYTES = BN * PANELS * 64;
-  static_assert(WGM * WGN == 4, "4 waves");
+  constexpr int NW = WGM * WGN, NTHR = 64 * NW;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   static_assert(BM % 64 == 0 && BN % 64 == 0, "tile");
   static_assert(!LN || BN == 256, "LayerNorm epilogue needs the whole row in one tile");
 
@@ -232,7 +233,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   // at all (the first version spent ~35 VALU ops per 16-B chunk on 64-bit addressing + predicates
   // and was VALU-bound: profiles/r01_b_pmc_gemm.txt).
   static_assert(PANELS == 2, "staging map assumes two 64-B panels per stage");
-  constexpr int RA2 = BM / 32, RB2 = BN / 32;
+  constexpr int RPP = NTHR / 8;                 // rows staged per pass (8 threads per 128-B row)
+  constexpr int RA2 = BM / RPP, RB2 = BN / RPP;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile vs thread count");
   constexpr int ESZ = 16 / KPB;
   constexpr uint32_t OOB = 0x80000000u;        // >= num_records of every descriptor below
   const int srow = tid >> 3, spn = (tid >> 2) & 1, sq = tid & 3;
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   uint32_t a_taps[RA2];    // ksize 3: bit t set <=> tap t of this output pixel lies inside the image
 #pragma unroll
   for (int j = 0; j < RA2; ++j) {
-    const int m = m0 + srow + j * 32;
+    const int m = m0 + srow + j * RPP;
     a_voff[j] = OOB;
     a_taps[j] = 0;
     if (m < p.M) {
@@ -287,8 +290,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   uint32_t b_voff[RB2];
 #pragma unroll
   for (int j = 0; j < RB2; ++j) {
-    const int n = n0 + srow + j * 32;
-    b_voff[j] = n < p.N ? (uint32_t)(((int64_t)(srow + j * 32) * p.Kpad + kc0) * ESZ) : OOB;
+    const int n = n0 + srow + j * RPP;
+    b_voff[j] = n < p.N ? (uint32_t)(((int64_t)(srow + j * RPP) * p.Kpad + kc0) * ESZ) : OOB;
   }
 
   u32x4 areg[RA2], breg[RB2];
@@ -326,12 +329,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     unsigned char* Bs = As + A_BYTES;
 #pragma unroll
     for (int j = 0; j < RA2; ++j) {
-      const int row = srow + j * 32;
+      const int row = srow + j * RPP;
       *reinterpret_cast<u32x4*>(As + (spn * BM + row) * 64 + swz(row, sq) * 16) = areg[j];
     }
 #pragma unroll
     for (int j = 0; j < RB2; ++j) {
-      const int row = srow + j * 32;
+      const int row = srow + j * RPP;
       *reinterpret_cast<u32x4*>(Bs + (spn * BN + row) * 64 + swz(row, sq) * 16) = breg[j];
     }
   };
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   stage_acc<BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q);
   __syncthreads();
 
-  gemm_epilogue<T, BM, BN, LN, 256>(p, Cs, m0, n0, tid);
+  gemm_epilogue<T, BM, BN, LN, NTHR>(p, Cs, m0, n0, tid);
 }
 
 // =================================================================================================
@@ -770,21 +773,22 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
       return MOY_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(64 * WGM * WGN), lds, st, p);
   return launch_status();
 }
 
 template <typename T, int KS>
 static int dispatch_tile(GemmParams& p, bool ln, hipStream_t st) {
-  if (ln) return launch_cfg<T, 64, 256, 1, 4, true, KS>(p, st);
+  static const bool w8 = [] { const char* e = getenv("MOY_GEMM_W8"); return !(e && e[0] == '0'); }();
+  if (ln) return w8 ? launch_cfg<T, 64, 256, 2, 4, true, KS>(p, st) : launch_cfg<T, 64, 256, 1, 4, true, KS>(p, st);
   // Tile choice: fill >= ~2 blocks per CU when the problem allows it, keep tiles large otherwise.
   const long big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
   if (p.N > 64) {
-    if (big >= 384) return launch_cfg<T, 128, 128, 2, 2, false, KS>(p, st);
+    if (big >= 384) return w8 ? launch_cfg<T, 128, 128, 2, 4, false, KS>(p, st) : launch_cfg<T, 128, 128, 2, 2, false, KS>(p, st);
     return launch_cfg<T, 64, 128, 2, 2, false, KS>(p, st);
   }
   const long mid = (long)((p.M + 127) / 128);
-  if (mid >= 384) return launch_cfg<T, 128, 64, 2, 2, false, KS>(p, st);
+  if (mid >= 384) return w8 ? launch_cfg<T, 128, 64, 4, 2, false, KS>(p, st) : launch_cfg<T, 128, 64, 2, 2, false, KS>(p, st);
   return launch_cfg<T, 64, 64, 2, 2, false, KS>(p, st);
 }
 
