@@ -65,7 +65,7 @@ const char* moy_strerror(int code);
  *   v = acc * scale[n] + shift[n]   (BN folded to scale/shift, or bias with scale == NULL)
  *   v = act(v)
  *   v += R[m * ldr + n]             (residual, dtype T)
- *   v = LayerNorm_n(v) * ln_g[n] + ln_b[n]   (eps 1e-5; requires N == 256)
+ *   v = LayerNorm_n(v) * ln_g[n] + ln_b[n]   (eps 1e-5; requires N == 256)  [+ optional fused narrow head, see dot_*]
  *   C[m * ldc + n] = v              (dtype T, or fp32 when out_f32 != 0)
  * -------------------------------------------------------------------------------------------- */
 typedef struct moy_gemm_args {
@@ -96,6 +96,13 @@ typedef struct moy_gemm_args {
    * [B, h*w] rows of a pyramid level into the level-major [B, S] token buffer (head.py:1023-1028). */
   int32_t c_rows_per_batch;
   int32_t c_batch_stride;
+  /* optional narrow head fused behind the LayerNorm epilogue (requires ln_g): for j < dot_n (<= 8)
+   *   dot_out[m * dot_n + j] = sum_n LN(v)[m, n] * dot_w[j * 256 + n] + dot_b[j]     (all fp32)
+   * -- enc_score_head(enc_output(x)) without re-reading the features (head.py:1041-1042). */
+  const float* dot_w;
+  const float* dot_b;
+  float* dot_out;
+  int32_t dot_n;
 } moy_gemm_args;
 
 int moy_gemm(const moy_gemm_args* args, void* stream);

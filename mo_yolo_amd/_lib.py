@@ -26,6 +26,7 @@ class GemmArgs(C.Structure):
         ("scale", vp), ("shift", vp), ("act", i32), ("R", vp), ("ldr", i64), ("ln_g", vp), ("ln_b", vp),
         ("C", vp), ("ldc", i64), ("out_f32", i32), ("dtype", i32),
         ("c_rows_per_batch", i32), ("c_batch_stride", i32),
+        ("dot_w", vp), ("dot_b", vp), ("dot_out", vp), ("dot_n", i32),
     ]
 
 

@@ -45,6 +45,10 @@ struct GemmParams {
   int64_t ldc;
   int out_f32;
   int c_rpb, c_bstride;
+  const float* dot_w;
+  const float* dot_b;
+  float* dot_out;
+  int dot_n;
   int tiles_n, nblocks;
 };
 
@@ -162,9 +166,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const float* 
     }
   }
   f32x4 g = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dw[8];
   if (LN) {
     g = *reinterpret_cast<const f32x4*>(p.ln_g + nc);
     be = *reinterpret_cast<const f32x4*>(p.ln_b + nc);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dw[c] = c < p.dot_n ? *reinterpret_cast<const f32x4*>(p.dot_w + c * 256 + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int out_esz = p.out_f32 ? 4 : (int)sizeof(T);
   unsigned char* cbase = static_cast<unsigned char*>(p.C) + (int64_t)n * out_esz;
@@ -178,6 +185,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const float* 
       const f32x4 d = v - mean;
       const float var = wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * (1.0f / 256.0f);
       v = d * (1.0f / sqrtf(var + 1e-5f)) * g + be;
+      if (p.dot_n) {   // fused narrow head on the normalised row (wave-uniform branch)
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c < p.dot_n) {
+            const float sdot = wave_sum(v.x * dw[c].x + v.y * dw[c].y + v.z * dw[c].z + v.w * dw[c].w);
+            if (lane == 0 && m < p.M) p.dot_out[(int64_t)m * p.dot_n + c] = sdot + p.dot_b[c];
+          }
+      }
     }
     if (col_ok && m < p.M) {
       int64_t mo = m;
@@ -201,7 +216,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
   constexpr int A_BYTES = BM * PANELS * 64, B_BYTES = BN * PANELS * 64;
   constexpr int NW = WGM * WGN, NTHR = 64 * NW;
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
-  static_assert(BM % 64 == 0 && BN % 64 == 0, "tile");
+  static_assert(BM % 64 == 0 && BN % 32 == 0, "tile");
   static_assert(!LN || BN == 256, "LayerNorm epilogue needs the whole row in one tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -788,6 +803,7 @@ static int dispatch_tile(GemmParams& p, bool ln, hipStream_t st) {
     return launch_cfg<T, 64, 128, 2, 2, false, KS>(p, st);
   }
   const long mid = (long)((p.M + 127) / 128);
+  if (p.N <= 32 && mid >= 384) return launch_cfg<T, 128, 32, 4, 1, false, KS>(p, st);   // no half-empty 64-wide tile
   if (mid >= 384) return w8 ? launch_cfg<T, 128, 64, 4, 2, false, KS>(p, st) : launch_cfg<T, 128, 64, 2, 2, false, KS>(p, st);
   return launch_cfg<T, 64, 64, 2, 2, false, KS>(p, st);
 }
@@ -839,6 +855,9 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
   p.ln_g = a->ln_g; p.ln_b = a->ln_b; p.C = a->C; p.ldc = a->ldc; p.out_f32 = a->out_f32;
   if (a->c_rows_per_batch < 0 || (a->c_rows_per_batch > 0 && a->c_batch_stride < a->c_rows_per_batch)) return MOY_EINVAL;
   p.c_rpb = a->c_rows_per_batch; p.c_bstride = a->c_batch_stride;
+  if (a->dot_n < 0 || a->dot_n > 8) return MOY_EINVAL;
+  if (a->dot_n && (!ln || !a->dot_w || !a->dot_b || !a->dot_out || !aligned16(a->dot_w))) return MOY_EINVAL;
+  p.dot_w = a->dot_w; p.dot_b = a->dot_b; p.dot_out = a->dot_out; p.dot_n = a->dot_n;
   if (a->ksize == 1) {
     if (a->K % kpb) return MOY_EINVAL;
   } else {

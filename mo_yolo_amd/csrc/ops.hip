@@ -67,40 +67,63 @@ __global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ in, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// SPPF: windows 5 / 9 / 13 (== three cascaded 5x5 stride-1 max pools with -inf padding).
+// SPPF: y1 = pool5(x), y2 = pool5(y1), y3 = pool5(y2) (stride 1, pad 2, -inf padding), exactly the
+// cascade of block.py:129-134.  One block = one (frame, 16-byte channel chunk): the H x W plane of
+// that chunk lives in LDS and each 5x5 pool is a separable row pass + column pass (5 + 5 reads per
+// pixel instead of the 169 taps of a direct 13x13 window).
 template <typename T>
-__global__ __launch_bounds__(256) void sppf_pool_kernel(const T* __restrict__ x, int64_t ldx, int B, int H, int W, int C,
+__device__ __forceinline__ u32x4 max_chunk(u32x4 a, u32x4 b);
+template <>
+__device__ __forceinline__ u32x4 max_chunk<float>(u32x4 a, u32x4 b) {
+  return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(f32x4, a), __builtin_bit_cast(f32x4, b)));
+}
+template <>
+__device__ __forceinline__ u32x4 max_chunk<bf16_t>(u32x4 a, u32x4 b) {
+  u32x4 r;
+  r.x = pack_bf2(fmaxf(bflo(a.x), bflo(b.x)), fmaxf(bfhi(a.x), bfhi(b.x)));
+  r.y = pack_bf2(fmaxf(bflo(a.y), bflo(b.y)), fmaxf(bfhi(a.y), bfhi(b.y)));
+  r.z = pack_bf2(fmaxf(bflo(a.z), bflo(b.z)), fmaxf(bfhi(a.z), bfhi(b.z)));
+  r.w = pack_bf2(fmaxf(bflo(a.w), bflo(b.w)), fmaxf(bfhi(a.w), bfhi(b.w)));
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_pool_kernel(const T* __restrict__ x, int64_t ldx, int H, int W, int C,
                                                         T* __restrict__ y1, T* __restrict__ y2, T* __restrict__ y3,
                                                         int64_t ldy) {
-  const int cpr = C >> 2;
-  const long total = (long)B * H * W * cpr;
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= total) return;
-  const int cc = (int)(t % cpr);
-  const long pix = t / cpr;
-  const int b = (int)(pix / ((long)H * W));
-  const int rem = (int)(pix - (long)b * H * W);
-  const int y = rem / W, xx = rem - y * W;
-  const float ninf = -INFINITY;
-  f32x4 m5 = {ninf, ninf, ninf, ninf}, m9 = m5, m13 = m5;
-  for (int dy = -6; dy <= 6; ++dy) {
-    const int iy = y + dy;
-    if ((unsigned)iy >= (unsigned)H) continue;
-    const int ady = dy < 0 ? -dy : dy;
-    for (int dx = -6; dx <= 6; ++dx) {
-      const int ix = xx + dx;
-      if ((unsigned)ix >= (unsigned)W) continue;
-      const int adx = dx < 0 ? -dx : dx;
-      const int rad = ady > adx ? ady : adx;
-      const f32x4 v = DT<T>::load4(x + (((long)b * H + iy) * W + ix) * ldx + cc * 4);
-      m13 = __builtin_elementwise_max(m13, v);
-      if (rad <= 4) m9 = __builtin_elementwise_max(m9, v);
-      if (rad <= 2) m5 = __builtin_elementwise_max(m5, v);
+  constexpr int KPB = DT<T>::KPB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  u32x4* P = reinterpret_cast<u32x4*>(dyn);            // [H*W] current plane
+  u32x4* Q = P + H * W;                                // [H*W] row-pass result
+  const int cpr = C / KPB;
+  const int b = blockIdx.x / cpr, cc = blockIdx.x % cpr;
+  const int npx = H * W, tid = threadIdx.x;
+  const long pix0 = (long)b * npx;
+  for (int i = tid; i < npx; i += 256) P[i] = *reinterpret_cast<const u32x4*>(x + (pix0 + i) * ldx + cc * KPB);
+  __syncthreads();
+  T* outs[3] = {y1, y2, y3};
+#pragma unroll 1
+  for (int s = 0; s < 3; ++s) {
+    for (int i = tid; i < npx; i += 256) {             // row pass
+      const int yy = i / W, xx = i - yy * W;
+      u32x4 m = P[i];
+#pragma unroll
+      for (int d = -2; d <= 2; ++d)
+        if (d != 0 && (unsigned)(xx + d) < (unsigned)W) m = max_chunk<T>(m, P[i + d]);
+      Q[i] = m;
     }
+    __syncthreads();
+    for (int i = tid; i < npx; i += 256) {             // column pass + store
+      const int yy = i / W;
+      u32x4 m = Q[i];
+#pragma unroll
+      for (int d = -2; d <= 2; ++d)
+        if (d != 0 && (unsigned)(yy + d) < (unsigned)H) m = max_chunk<T>(m, Q[i + d * W]);
+      P[i] = m;
+      *reinterpret_cast<u32x4*>(outs[s] + (pix0 + i) * ldy + cc * KPB) = m;
+    }
+    __syncthreads();
   }
-  DT<T>::store4(y1 + pix * ldy + cc * 4, m5);
-  DT<T>::store4(y2 + pix * ldy + cc * 4, m9);
-  DT<T>::store4(y3 + pix * ldy + cc * 4, m13);
 }
 
 template <typename T>
@@ -697,11 +720,20 @@ extern "C" int moy_stem_conv(const void* in, int in_fmt, int B, int H, int W, co
 
 extern "C" int moy_sppf_pool(const void* x, int64_t ldx, int B, int H, int W, int C, void* y1, void* y2, void* y3,
                              int64_t ldy, int dtype, void* stream) {
-  if (!x || !y1 || !y2 || !y3 || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldx % 4) || (ldy % 4)) return MOY_EINVAL;
+  if (!x || !y1 || !y2 || !y3 || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (ldy % 8)) return MOY_EINVAL;
+  if (!aligned16(x) || !aligned16(y1) || !aligned16(y2) || !aligned16(y3)) return MOY_EINVAL;
+  const size_t lds = (size_t)H * W * 32;
+  if (lds > 160 * 1024) return MOY_ENOSYS;     // the plane of one channel chunk must fit in LDS (P5 level: 19x34 .. 34x60)
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const long total = (long)B * H * W * (C / 4);
   MOY_DISPATCH_T(dtype, {
-    hipLaunchKernelGGL((sppf_pool_kernel<T>), dim3(nblk(total)), dim3(256), 0, st, static_cast<const T*>(x), ldx, B, H, W, C,
+    auto kern = sppf_pool_kernel<T>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return MOY_ELAUNCH;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(B * (C / DT<T>::KPB)), dim3(256), lds, st, static_cast<const T*>(x), ldx, H, W, C,
                        static_cast<T*>(y1), static_cast<T*>(y2), static_cast<T*>(y3), ldy);
     return launch_status();
   })

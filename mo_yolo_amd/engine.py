@@ -116,7 +116,7 @@ class TrackEngine:
 
     def _gemm(self, A: View, Wt, N, K, C_: View, M, *, ksize=1, stride=1, geom=None, scale=None, shift=None, act=0,
               A2: View | None = None, a_rows=None, a_mask=None, mask_period=0, R: View | None = None, ln=None,
-              out_f32=False, c_rpb=0, c_bstride=0):
+              out_f32=False, c_rpb=0, c_bstride=0, dot=None):
         a = L.GemmArgs()
         a.A, a.lda = A.ptr, A.ld
         a.A2 = A2.ptr if A2 is not None else None
@@ -139,6 +139,8 @@ class TrackEngine:
             a.ln_g, a.ln_b = ln[0].data_ptr(), ln[1].data_ptr()
         a.C, a.ldc, a.out_f32, a.dtype = C_.ptr, C_.ld, int(out_f32), self.code
         a.c_rows_per_batch, a.c_batch_stride = c_rpb, c_bstride
+        if dot is not None:
+            a.dot_w, a.dot_b, a.dot_out, a.dot_n = dot[0].data_ptr(), dot[1].data_ptr(), dot[2].data_ptr(), dot[0].shape[0]
         self._keep.append(a)
         esz = 2 if self.dtype == torch.bfloat16 else 4
         if geom is not None:
@@ -300,13 +302,15 @@ class TrackEngine:
         features = View(self._buf(B * S, hd))
         Wt, bias = self._linear_w(d + ".enc_output.0")
         ln = (self._dev(sd[d + ".enc_output.1.weight"]), self._dev(sd[d + ".enc_output.1.bias"]))
-        self._gemm(feats, Wt, hd, hd, features, B * S, shift=bias, a_mask=self.valid, mask_period=S, ln=ln)
-        self.features = features
-
         self.scores_all = self._buf(B * S, nc, torch.float32)
         wsc, bsc = self._dev(sd[d + ".enc_score_head.weight"]), self._dev(sd[d + ".enc_score_head.bias"])
-        self._add(lib.moy_rowdot, features.ptr, features.ld, None, B * S, hd, wsc.data_ptr(), bsc.data_ptr(), nc, 0,
-                  None, None, self.scores_all.data_ptr(), code)
+        fuse_score = nc <= 8     # enc_score_head rides on the LayerNorm epilogue (no second pass over the features)
+        self._gemm(feats, Wt, hd, hd, features, B * S, shift=bias, a_mask=self.valid, mask_period=S, ln=ln,
+                   dot=(wsc, bsc, self.scores_all) if fuse_score else None)
+        self.features = features
+        if not fuse_score:
+            self._add(lib.moy_rowdot, features.ptr, features.ld, None, B * S, hd, wsc.data_ptr(), bsc.data_ptr(), nc, 0,
+                      None, None, self.scores_all.data_ptr(), code)
 
         self.topk_local = torch.zeros(B, nq, device=self.dev, dtype=torch.int32)
         self.topk_global = torch.zeros(B, nq, device=self.dev, dtype=torch.int32)

@@ -44,7 +44,8 @@ def pad_weight(w2d: torch.Tensor, dtype) -> torch.Tensor:
 
 
 def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shift=None, act=L.ACT_NONE, A2=None,
-         a_rows=None, a_mask=None, mask_period=0, R=None, ln=None, out_f32=False, M=None, c_rpb=0, c_bstride=0):
+         a_rows=None, a_mask=None, mask_period=0, R=None, ln=None, out_f32=False, M=None, c_rpb=0, c_bstride=0,
+         dot=None):
     """See moy_gemm.  A: 2-D row-major view [rows, >=Cin] (channels-last pixels or tokens)."""
     _need_gpu(A, Wp)
     a = L.GemmArgs()
@@ -79,8 +80,13 @@ def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shi
         out = torch.empty(rows, N, device=A.device, dtype=torch.float32 if out_f32 else A.dtype)
     a.C, a.ldc, a.out_f32, a.dtype = out.data_ptr(), _ld(out), int(out_f32), _code(A)
     a.c_rows_per_batch, a.c_batch_stride = c_rpb, c_bstride
+    dot_out = None
+    if dot is not None:     # (w fp32 [n, 256], b fp32 [n]) fused behind the LayerNorm
+        dw, db = dot
+        dot_out = torch.empty(M, dw.shape[0], device=A.device, dtype=torch.float32)
+        a.dot_w, a.dot_b, a.dot_out, a.dot_n = dw.data_ptr(), db.data_ptr(), dot_out.data_ptr(), dw.shape[0]
     L.check(L.lib().moy_gemm(C.byref(a), _st()), "moy_gemm")
-    return out
+    return out if dot is None else (out, dot_out)
 
 
 def stem_conv(x, w27, scale, shift, dtype):

@@ -66,6 +66,12 @@ def test_gemm_layernorm_residual_prologue_add_gather_mask(dt):
     xin = q(x + p, dt) if dt == torch.bfloat16 else x + p
     ref = F.layer_norm(xin @ w.T + b + r, (N,), g, be, 1e-5)
     assert torch.allclose(y.float().cpu(), ref, atol=tol(dt, 3e-5, 4e-2))
+    # narrow head fused behind the LayerNorm (enc_score_head on enc_output)
+    dw, db = rnd(3, N, seed=11, scale=0.1), rnd(3, seed=12)
+    y2, sc = ops.gemm(x.to(DEV, dt), wd, N, K, shift=b.to(DEV), A2=p.to(DEV, dt), R=r.to(DEV, dt), ln=(g.to(DEV), be.to(DEV)),
+                      dot=(dw.to(DEV), db.to(DEV)))
+    assert torch.equal(y2, y)
+    assert torch.allclose(sc.cpu(), ref @ dw.T + db, atol=tol(dt, 5e-5, 5e-2))
     # row gather + row mask (period) + LN
     rows = torch.randperm(M, generator=torch.Generator().manual_seed(9))[:200].int()
     mask = (torch.arange(50) % 3 != 0).to(torch.uint8)
