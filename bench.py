@@ -49,7 +49,8 @@ def cpu_baseline(cfg, arch, sd, n_frames):
     from oracle import track_oracle as O
     from mo_yolo_amd.synth import SyntheticSequence, to_network_input
     seq = SyntheticSequence(0, cfg["H"], cfg["W"], cfg["style"])
-    cores = torch.get_num_threads()
+    cores = min(torch.get_num_threads(), 16)      # eager batch-1 ops stop scaling (and regress) beyond ~16 threads
+    torch.set_num_threads(cores)
     with torch.no_grad():
         for t in range(2):
             O.forward(to_network_input(seq.frames(t, 1)), sd, arch)
@@ -140,8 +141,12 @@ def main():
         dom = max(range(nL), key=lambda i: per[i])
         m = eng.meta[dom]
         ach = m["bytes"] / (per[dom] * 1e-3) / 1e9 if m["bytes"] else 0.0
+        traffic = None      # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.sh), if this launch was profiled
+        tp = os.path.join(ROOT, "profiles", "traffic_by_launch.json")
+        if os.path.exists(tp):
+            traffic = json.load(open(tp)).get(m["name"], {}).get("hbm_bytes")
         roof = {"bound": "hbm", "kernel": m["name"], "launch_index": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_ms": round(per[dom], 4), "share_of_step": round(per[dom] / sum(per), 4),
                 "alg_bytes_per_launch": m["bytes"], "tflops": round(m["flops"] / (per[dom] * 1e-3) / 1e12, 2)}
         bytes_step = (ALG_BYTES_FRAME[a.config] - ALG_WEIGHT_BYTES) * B + ALG_WEIGHT_BYTES
