@@ -60,3 +60,27 @@ def check_close(got, g, key, atol, rtol=0.0, what=""):
     bad = err > tol
     assert not bool(bad.any()), f"{what}{key}: max err {err.max().item():.3e} (tol {atol}+{rtol}*|x|), {int(bad.sum())} bad"
     return float(err.max())
+
+
+def hota_of_tracks(cfg, per_frame_rows, per_frame_ids, seq_id=0):
+    """HOTA (the reference evaluator's algorithm, oracle/hota_oracle.py) of per-frame track rows
+    (xyxy pixels) + ids against the synthetic sequence's ground truth.  Data layout as the validator
+    builds it (val.py:418-432): ids are [n,1] int arrays re-indexed to 0..N-1, similarity = box IoU."""
+    from oracle import hota_oracle as H
+    seq = SyntheticSequence(seq_id, cfg["H"], cfg["W"], cfg["style"])
+    T = len(per_frame_rows)
+    gts = [seq.boxes(t) for t in range(T)]
+    ug = np.unique(np.concatenate([g[1] for g in gts]))
+    ut = np.unique(np.concatenate([np.asarray(i).reshape(-1) for i in per_frame_ids] + [np.zeros(0, np.int64)]))
+    gi, ti, sims = [], [], []
+    for t in range(T):
+        gb, gid = gts[t]
+        tb = np.asarray(per_frame_rows[t], dtype=np.float64).reshape(-1, 4)
+        gi.append(np.searchsorted(ug, gid).reshape(-1, 1))
+        ti.append(np.searchsorted(ut, np.asarray(per_frame_ids[t]).reshape(-1)).reshape(-1, 1))
+        ix1 = np.maximum(gb[:, None, 0], tb[None, :, 0]); iy1 = np.maximum(gb[:, None, 1], tb[None, :, 1])
+        ix2 = np.minimum(gb[:, None, 2], tb[None, :, 2]); iy2 = np.minimum(gb[:, None, 3], tb[None, :, 3])
+        inter = np.clip(ix2 - ix1, 0, None) * np.clip(iy2 - iy1, 0, None)
+        ua = (gb[:, 2] - gb[:, 0]) * (gb[:, 3] - gb[:, 1]); ub = (tb[:, 2] - tb[:, 0]) * (tb[:, 3] - tb[:, 1])
+        sims.append(inter / np.maximum(ua[:, None] + ub[None, :] - inter, 1e-9))
+    return H.eval_sequence(gi, ti, sims, len(ug), max(1, len(ut)))

@@ -391,10 +391,10 @@ def dump_hota():
             inter = np.clip(ix2 - ix1, 0, None) * np.clip(iy2 - iy1, 0, None)
             ua = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]); ub = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
             data["similarity_scores"].append(inter / (ua[:, None] + ub[None, :] - inter))
+        for t in range(T):   # inputs are saved BEFORE the call: the evaluator shifts tracker ids in place (hota.py:81-88)
+            out[f"{case}.gt_ids.{t}"] = data["gt_ids"][t].copy(); out[f"{case}.tracker_ids.{t}"] = data["tracker_ids"][t].copy()
+            out[f"{case}.sim.{t}"] = data["similarity_scores"][t].copy()
         res = HOTA().eval_sequence(data)
-        for t in range(T):
-            out[f"{case}.gt_ids.{t}"] = data["gt_ids"][t]; out[f"{case}.tracker_ids.{t}"] = data["tracker_ids"][t]
-            out[f"{case}.sim.{t}"] = data["similarity_scores"][t]
         out[f"{case}.T"] = np.array(T)
         out[f"{case}.num_gt_ids"] = np.array(len(ug)); out[f"{case}.num_tracker_ids"] = np.array(len(ut))
         for k, v in res.items():

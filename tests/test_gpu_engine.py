@@ -170,3 +170,42 @@ def test_engine_graph_replay_matches_eager():
     torch.cuda.synchronize()
     for k in ("y", "obj_idxes", "rows", "n_rows", "topk_ind"):
         assert torch.equal(a[k], b[k]), k
+
+
+def test_hota_parity_on_synthetic_stream():
+    """BASELINE metric, HOTA half: HOTA of the build's tracks vs HOTA of the oracle's tracks on the
+    same synthetic ground truth, with the reference evaluator's algorithm.  fp32: identical;
+    bf16: reported, bounded (stated bar: 2 HOTA points on the 0-100 scale)."""
+    from tests._util import hota_of_tracks
+    cfg, arch, sd = fixture("c2")
+    T = 6
+    fr = torch.from_numpy(frames_u8(cfg, 0, T)).to(DEV)
+
+    def tracks(out):
+        rows, ids = [], []
+        for t in range(T):
+            k = int(out["n_ids"][t])
+            k = max(k, 0)
+            # active rows in query order: boxes of rows with id >= 0 (not conf filtered, like track_id)
+            act = (out["obj_idxes"][t] >= 0).cpu()
+            b = out["boxes"][t].cpu()[act]
+            xyxy = torch.stack([(b[:, 0] - b[:, 2] / 2) * cfg["W"], (b[:, 1] - b[:, 3] / 2) * cfg["H"],
+                                (b[:, 0] + b[:, 2] / 2) * cfg["W"], (b[:, 1] + b[:, 3] / 2) * cfg["H"]], -1)
+            rows.append(xyxy.numpy()); ids.append(out["obj_idxes"][t].cpu()[act].numpy())
+        return rows, ids
+
+    with torch.no_grad():
+        r = O.forward(net_input(cfg, 0, T), sd, arch)
+    ref_out = dict(obj_idxes=O.assign_ids(r["dec_scores"].sigmoid().max(-1).values), boxes=r["dec_bboxes"],
+                   n_ids=torch.zeros(T))
+    h_ref = hota_of_tracks(cfg, *tracks(ref_out))
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=T, dtype=dt)
+        out = eng.forward_with_topk(fr, r["topk_ind"]) if dt == torch.float32 else eng.forward(fr)
+        torch.cuda.synchronize()
+        res[dt] = hota_of_tracks(cfg, *tracks({k: v.clone() for k, v in out.items()}))
+    d32 = abs(float(np.mean(res[torch.float32]["HOTA"])) - float(np.mean(h_ref["HOTA"]))) * 100
+    d16 = abs(float(np.mean(res[torch.bfloat16]["HOTA"])) - float(np.mean(h_ref["HOTA"]))) * 100
+    print(f"HOTA ref {100 * np.mean(h_ref['HOTA']):.3f}  fp32 delta {d32:.4f}  bf16 delta {d16:.4f}")
+    assert d32 <= 0.1 and d16 <= 2.0

@@ -125,3 +125,16 @@ def test_filter_and_copy_semantics():
     assert O.filter_tracks(b) == [True, False, True, False]
     rows, ids = O.tracker_update_copy([.9, .9, .9, .9], b, [0, 1, 2, 3])
     assert rows == [0, 2] and ids == [0, 1]
+
+
+def test_hota_restatement_vs_reference_evaluator():
+    """oracle/hota_oracle.py vs HOTA.eval_sequence of the reference (utils/hota.py:24-164) on the
+    validator's input layout, incl. the evaluator's in-place id shifting."""
+    from oracle import hota_oracle as H
+    g = golden("hota")
+    for case in ("easy", "hard"):
+        T = int(g[f"{case}.T"])
+        r = H.eval_sequence([g[f"{case}.gt_ids.{t}"] for t in range(T)], [g[f"{case}.tracker_ids.{t}"] for t in range(T)],
+                            [g[f"{case}.sim.{t}"] for t in range(T)], int(g[f"{case}.num_gt_ids"]), int(g[f"{case}.num_tracker_ids"]))
+        for k in ("HOTA", "DetA", "AssA", "DetRe", "DetPr", "AssRe", "AssPr", "LocA", "OWTA", "HOTA_TP", "HOTA_FN", "HOTA_FP"):
+            assert np.allclose(r[k], g[f"{case}.res.{k}"], atol=1e-7), (case, k)
