@@ -200,6 +200,30 @@ int moy_assign_post(const float* logits, const float* boxes, int B, int nq, int 
                     float img_w, float img_h, float* y, float* scores, int64_t* obj_idxes, float* rows,
                     int64_t* track_id, int32_t* n_rows, int32_t* n_ids, void* stream);
 
+/* Output-invisible per-sequence side state of the shipped path, kept ON DEVICE:
+ *  (1) the *copy* half of RuntimeTrackerBase.update (nn/modules/head.py:1245-1283): active rows ->
+ *      greedy O(K^2) suppression of rows whose (cx,cy,w,h)-as-(x,y,w,h) IoU with an earlier kept row
+ *      exceeds 0.8 (_filter_tracks :1155-1171, _calculate_iou :1173-1196 incl. its early-outs) ->
+ *      renumbering of ids above max_obj_id_pre (= 0 after the per-frame reset);
+ *  (2) QueryInteractionModule.forward -> FSQM.online_update (MOTR/models/qim.py:303-340,
+ *      MOTR/models/fsqm.py:117-180): update_confidence (indexed BY ID), inject_new_queries
+ *      (score > 0.7, first free slot, FIFO id pool), remove_inactive_queries (conf < 0.3 for 3
+ *      consecutive updates; frees never-used slots too and recycles their id -1, as shipped).
+ * Frames b = 0..B-1 are consecutive frames of ONE sequence and are applied in order.
+ *   scores fp32 [B,nq], boxes fp32 [B,nq,4], obj_idxes int64 [B,nq] (from moy_assign_post),
+ *   hs T [B*nq, ld_hs] (last decoder layer output, 256 wide)
+ *   copy_rows int32 [B,nq], copy_ids int64 [B,nq], n_copy int32 [B]: the filtered/renumbered copy
+ * FSQM state (caller-owned, zero/-1 initialised by moy_fsqm_reset), n_slots = 300:
+ *   mem fp32 [300,256], conf fp32 [300], ids int64 [300], fboxes fp32 [300,4], low int32 [300],
+ *   pool int32 [pool_cap] ring + pool_hc int32 [3] = {head, count, overflow flag}. */
+int moy_track_state_update(const float* scores, const float* boxes, const int64_t* obj_idxes, const void* hs, int64_t ld_hs,
+                           int B, int nq, int32_t* copy_rows, int64_t* copy_ids, int32_t* n_copy, float* mem, float* conf,
+                           int64_t* ids, float* fboxes, int32_t* low, int32_t* pool, int32_t pool_cap, int32_t* pool_hc,
+                           int dtype, void* stream);
+/* FSQM.reset (fsqm.py:182-190): zero memory, ids = -1, pool = 0..299. */
+int moy_fsqm_reset(float* mem, float* conf, int64_t* ids, float* fboxes, int32_t* low, int32_t* pool, int32_t pool_cap,
+                   int32_t* pool_hc, void* stream);
+
 /* Elementwise helpers. */
 /* dst T [M, N] (ldd) = src T [rows[m], :] (lds): row gather (features[batch_ind, topk_ind], head.py:1096). N % 8 == 0. */
 int moy_gather_rows(const void* src, int64_t lds, const int32_t* rows, int M, int N, void* dst, int64_t ldd, int dtype,

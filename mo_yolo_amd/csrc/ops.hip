@@ -644,6 +644,141 @@ __global__ __launch_bounds__(1024) void assign_post_kernel(const float* __restri
   if (i == 0) { n_rows[b] = nkeep; n_ids[b] = K > 0 ? K : -1; }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Side state of the shipped path on device: copy-filter of RuntimeTrackerBase.update + FSQM.
+constexpr int FSQM_SLOTS = 300, FSQM_DIM = 256;
+
+// head.py:1173-1196 in fp32 without fused multiply-adds (the reference evaluates each op separately)
+__device__ __forceinline__ bool iou_gt_08(const float* a, const float* b) {
+  if (fabsf(__fsub_rn(a[0], b[0])) > __fmul_rn(0.5f, fminf(a[0], b[0]))) return false;
+  if (fabsf(__fsub_rn(a[1], b[1])) > __fmul_rn(0.5f, fminf(a[1], b[1]))) return false;
+  const float ix1 = fmaxf(a[0], b[0]), iy1 = fmaxf(a[1], b[1]);
+  const float ix2 = fminf(__fadd_rn(a[0], a[2]), __fadd_rn(b[0], b[2]));
+  const float iy2 = fminf(__fadd_rn(a[1], a[3]), __fadd_rn(b[1], b[3]));
+  const float inter = __fmul_rn(fmaxf(0.f, __fsub_rn(ix2, ix1)), fmaxf(0.f, __fsub_rn(iy2, iy1)));
+  const float uni = __fsub_rn(__fadd_rn(__fmul_rn(a[2], a[3]), __fmul_rn(b[2], b[3])), inter);
+  return __fdiv_rn(inter, uni) > 0.8f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void track_state_kernel(const float* __restrict__ scores, const float* __restrict__ boxes,
+                                                           const int64_t* __restrict__ obj, const T* __restrict__ hs, int64_t ld_hs,
+                                                           int B, int nq, int32_t* __restrict__ copy_rows,
+                                                           int64_t* __restrict__ copy_ids, int32_t* __restrict__ n_copy,
+                                                           float* __restrict__ mem, float* __restrict__ conf, int64_t* __restrict__ ids,
+                                                           float* __restrict__ fboxes, int32_t* __restrict__ low,
+                                                           int32_t* __restrict__ pool, int pool_cap, int32_t* __restrict__ pool_hc) {
+  __shared__ int wsum[16];
+  __shared__ int act[1024];        // active rows (query order)
+  __shared__ int keep[1024];
+  __shared__ int kept_row[1024];   // rows of the copy
+  __shared__ int kept_id[1024];
+  __shared__ int inj_slot[1024];   // slot chosen for the v-th injected query (-1: none)
+  __shared__ float bx[1024][4];
+  __shared__ int sh_nvalid;
+  const int i = threadIdx.x;
+  for (int b = 0; b < B; ++b) {
+    const float* sc = scores + (long)b * nq;
+    const float* bb = boxes + (long)b * nq * 4;
+    const int64_t* ob = obj + (long)b * nq;
+    // ---- (1) copy half of RuntimeTrackerBase.update
+    const int is_act = i < nq && ob[i] >= 0;
+    int K;
+    const int apos = block_excl_scan(is_act, wsum, i, 1024, &K);
+    if (is_act) { act[apos] = i; bx[apos][0] = bb[i * 4]; bx[apos][1] = bb[i * 4 + 1]; bx[apos][2] = bb[i * 4 + 2]; bx[apos][3] = bb[i * 4 + 3]; }
+    if (i < 1024) keep[i] = 1;
+    __syncthreads();
+    for (int a = 0; a < K; ++a) {          // greedy suppression, head.py:1159-1169
+      if (keep[a] && i > a && i < K && keep[i] && iou_gt_08(bx[a], bx[i])) keep[i] = 0;
+      __syncthreads();
+    }
+    const int is_kept = i < K && keep[i];
+    int Kc;
+    const int kpos = block_excl_scan(is_kept, wsum, i, 1024, &Kc);
+    // renumber ids above max_obj_id_pre = 0 (head.py:1268-1275): k-th such row (in order) -> k + 1
+    const int idv = is_kept ? (int)ob[act[i]] : 0;
+    int dummy;
+    const int rpos = block_excl_scan(is_kept && idv > 0, wsum, i, 1024, &dummy);
+    if (is_kept) {
+      const int nid = idv > 0 ? rpos + 1 : idv;
+      kept_row[kpos] = act[i];
+      kept_id[kpos] = nid;
+      copy_rows[(long)b * nq + kpos] = act[i];
+      copy_ids[(long)b * nq + kpos] = nid;
+    }
+    if (i == 0) n_copy[b] = K > 0 ? Kc : 0;
+    __syncthreads();
+    // ---- (2a) FSQM.update_confidence over the nq-row track_queries, indexed BY ID (fsqm.py:127-132)
+    if (i < nq) {
+      const int64_t id = ob[i];
+      if (id >= 0 && id < FSQM_SLOTS) {
+        conf[id] = sc[i];
+        fboxes[id * 4] = bb[i * 4]; fboxes[id * 4 + 1] = bb[i * 4 + 1]; fboxes[id * 4 + 2] = bb[i * 4 + 2]; fboxes[id * 4 + 3] = bb[i * 4 + 3];
+        low[id] = 0;
+      }
+    }
+    __syncthreads();
+    // ---- (2b) inject_new_queries over the copy (detect_queries): control flow by one lane, as shipped
+    const int nd = K > 0 ? Kc : 0;   // no active row: update() returns the full Instances; its scores can exceed 0.7 only if active
+    if (i == 0) {
+      int nv = 0, cursor = 0, head = pool_hc[0], count = pool_hc[1];
+      for (int v = 0; v < nd; ++v) {
+        const int row = kept_row[v];
+        if (!(sc[row] > 0.7f)) continue;
+        while (cursor < FSQM_SLOTS && ids[cursor] != -1) ++cursor;
+        if (cursor >= FSQM_SLOTS) break;                    // memory full (fsqm.py:77-79)
+        int pid = -1;
+        if (count > 0) { pid = pool[head]; head = (head + 1) % pool_cap; --count; } else pool_hc[2] = 1;   // pop(0) of an empty list would raise
+        ids[cursor] = pid;
+        conf[cursor] = sc[row];
+        fboxes[cursor * 4] = bb[row * 4]; fboxes[cursor * 4 + 1] = bb[row * 4 + 1];
+        fboxes[cursor * 4 + 2] = bb[row * 4 + 2]; fboxes[cursor * 4 + 3] = bb[row * 4 + 3];
+        low[cursor] = 0;
+        inj_slot[nv] = cursor;
+        act[nv] = row;                                      // reuse: source row of the nv-th injection
+        ++nv;
+      }
+      pool_hc[0] = head; pool_hc[1] = count;
+      sh_nvalid = nv;
+    }
+    __syncthreads();
+    for (int v = 0; v < sh_nvalid; ++v)                     // embeddings, in injection order (later wins)
+      if (i < FSQM_DIM) mem[(long)inj_slot[v] * FSQM_DIM + i] = DT<T>::load1(hs + ((long)b * nq + act[v]) * ld_hs + i);
+    __syncthreads();
+    // ---- (2c) remove_inactive_queries (fsqm.py:102-115), pool appends in slot order
+    int freed = 0;
+    if (i < FSQM_SLOTS && conf[i] < 0.3f) {
+      const int l = low[i] + 1;
+      low[i] = l;
+      freed = l >= 3;
+    }
+    int nfree;
+    const int fpos = block_excl_scan(freed, wsum, i, 1024, &nfree);
+    if (freed) {
+      const int head = pool_hc[0], count = pool_hc[1];
+      if (count + fpos < pool_cap) pool[(head + count + fpos) % pool_cap] = (int)ids[i]; else pool_hc[2] = 1;
+      conf[i] = 0.f; ids[i] = -1; low[i] = 0;
+      fboxes[i * 4] = fboxes[i * 4 + 1] = fboxes[i * 4 + 2] = fboxes[i * 4 + 3] = 0.f;
+    }
+    __syncthreads();
+    if (i < 1024) keep[i] = freed;                          // reuse: freed-slot flags
+    __syncthreads();
+    for (int s = 0; s < FSQM_SLOTS; ++s)
+      if (keep[s] && i < FSQM_DIM) mem[(long)s * FSQM_DIM + i] = 0.f;
+    if (i == 0) pool_hc[1] = min(pool_cap, pool_hc[1] + nfree);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void fsqm_reset_kernel(float* mem, float* conf, int64_t* ids, float* fboxes, int32_t* low,
+                                                         int32_t* pool, int pool_cap, int32_t* pool_hc) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < FSQM_SLOTS * FSQM_DIM) mem[t] = 0.f;
+  if (t < FSQM_SLOTS) { conf[t] = 0.f; ids[t] = -1; low[t] = 0; pool[t] = t; fboxes[t * 4] = fboxes[t * 4 + 1] = fboxes[t * 4 + 2] = fboxes[t * 4 + 3] = 0.f; }
+  if (t == 0) { pool_hc[0] = 0; pool_hc[1] = FSQM_SLOTS; pool_hc[2] = 0; }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, int64_t lds_, int M, int N4, T* __restrict__ dst,
                                                    int64_t ldd) {
@@ -875,6 +1010,30 @@ extern "C" int moy_assign_post(const float* logits, const float* boxes, int B, i
   if (B <= 0 || nq <= 0 || nq > 1024 || nc <= 0) return MOY_EINVAL;
   hipLaunchKernelGGL(assign_post_kernel, dim3(B), dim3(1024), 0, static_cast<hipStream_t>(stream), logits, boxes, nq, nc,
                      score_thresh, conf, img_w, img_h, y, scores, obj_idxes, rows, track_id, n_rows, n_ids);
+  return launch_status();
+}
+
+extern "C" int moy_track_state_update(const float* scores, const float* boxes, const int64_t* obj_idxes, const void* hs, int64_t ld_hs,
+                                      int B, int nq, int32_t* copy_rows, int64_t* copy_ids, int32_t* n_copy, float* mem, float* conf,
+                                      int64_t* ids, float* fboxes, int32_t* low, int32_t* pool, int32_t pool_cap, int32_t* pool_hc,
+                                      int dtype, void* stream) {
+  if (!scores || !boxes || !obj_idxes || !hs || !copy_rows || !copy_ids || !n_copy || !mem || !conf || !ids || !fboxes || !low ||
+      !pool || !pool_hc)
+    return MOY_EINVAL;
+  if (B <= 0 || nq <= 0 || nq > 1024 || ld_hs < FSQM_DIM || pool_cap < FSQM_SLOTS) return MOY_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MOY_DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((track_state_kernel<T>), dim3(1), dim3(1024), 0, st, scores, boxes, obj_idxes, static_cast<const T*>(hs), ld_hs, B,
+                       nq, copy_rows, copy_ids, n_copy, mem, conf, ids, fboxes, low, pool, pool_cap, pool_hc);
+    return launch_status();
+  })
+}
+
+extern "C" int moy_fsqm_reset(float* mem, float* conf, int64_t* ids, float* fboxes, int32_t* low, int32_t* pool, int32_t pool_cap,
+                              int32_t* pool_hc, void* stream) {
+  if (!mem || !conf || !ids || !fboxes || !low || !pool || !pool_hc || pool_cap < FSQM_SLOTS) return MOY_EINVAL;
+  hipLaunchKernelGGL(fsqm_reset_kernel, dim3(nblk(FSQM_SLOTS * FSQM_DIM)), dim3(256), 0, static_cast<hipStream_t>(stream), mem, conf,
+                     ids, fboxes, low, pool, pool_cap, pool_hc);
   return launch_status();
 }
 

@@ -59,7 +59,7 @@ class TrackEngine:
     def __init__(self, arch: TrackArch, state_dict: Dict[str, torch.Tensor], H: int, W: int, batch: int = 1,
                  dtype: torch.dtype = torch.float32, device="cuda", input_format: str = "u8", conf: float = 0.25,
                  score_thresh: float = 0.4, scale_boxes: bool = True, head_only: bool = False,
-                 level_shapes_override=None):
+                 level_shapes_override=None, side_state: bool = False):
         if not torch.cuda.is_available():
             raise L.MoyoloError("TrackEngine needs a HIP device (no CPU path)")
         self.lib = L.lib()
@@ -69,6 +69,7 @@ class TrackEngine:
         self.conf, self.score_thresh = conf, score_thresh
         self.img_wh = (float(W), float(H)) if scale_boxes else (1.0, 1.0)
         self.head_only = head_only
+        self.side_state = side_state     # keep the output-invisible tracker copy + FSQM memory on device
         self.shapes = [tuple(s) for s in level_shapes_override] if level_shapes_override else level_shapes(H, W)
         self.S = sum(h * w for h, w in self.shapes)
         self._keep: List[torch.Tensor] = []          # device tensors referenced by raw pointers
@@ -407,6 +408,27 @@ class TrackEngine:
                   C.c_float(self.score_thresh), C.c_float(self.conf), C.c_float(self.img_wh[0]), C.c_float(self.img_wh[1]),
                   self.y.data_ptr(), self.scores.data_ptr(), self.obj_idxes.data_ptr(), self.rows.data_ptr(),
                   self.track_id.data_ptr(), self.n_rows.data_ptr(), self.n_ids.data_ptr())
+
+        if self.side_state:
+            i32, i64, f32 = torch.int32, torch.int64, torch.float32
+            z = lambda *shape, dt=f32: torch.zeros(*shape, device=self.dev, dtype=dt)
+            self.copy_rows, self.copy_ids, self.n_copy = z(B, nq, dt=i32), z(B, nq, dt=i64), z(B, dt=i32)
+            self.fsqm = dict(mem=z(300, 256), conf=z(300), ids=z(300, dt=i64), boxes=z(300, 4), low=z(300, dt=i32),
+                             pool=z(1 << 16, dt=i32), pool_hc=z(3, dt=i32))
+            self.reset_sequence()
+            f = self.fsqm
+            self._add(lib.moy_track_state_update, self.scores.data_ptr(), self.boxes.data_ptr(), self.obj_idxes.data_ptr(),
+                      self.hs.ptr, self.hs.ld, B, nq, self.copy_rows.data_ptr(), self.copy_ids.data_ptr(), self.n_copy.data_ptr(),
+                      f["mem"].data_ptr(), f["conf"].data_ptr(), f["ids"].data_ptr(), f["boxes"].data_ptr(), f["low"].data_ptr(),
+                      f["pool"].data_ptr(), f["pool"].numel(), f["pool_hc"].data_ptr(), code)
+
+    def reset_sequence(self):
+        """FSQM.reset (fsqm.py:182-190): call at the start of a new video sequence."""
+        if self.side_state:
+            f = self.fsqm
+            L.check(self.lib.moy_fsqm_reset(f["mem"].data_ptr(), f["conf"].data_ptr(), f["ids"].data_ptr(), f["boxes"].data_ptr(),
+                                            f["low"].data_ptr(), f["pool"].data_ptr(), f["pool"].numel(), f["pool_hc"].data_ptr(),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "moy_fsqm_reset")
 
     def _linear_w_raw(self, w, b):
         return self._weight(w), self._dev(b)

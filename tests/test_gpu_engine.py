@@ -209,3 +209,42 @@ def test_hota_parity_on_synthetic_stream():
     d16 = abs(float(np.mean(res[torch.bfloat16]["HOTA"])) - float(np.mean(h_ref["HOTA"]))) * 100
     print(f"HOTA ref {100 * np.mean(h_ref['HOTA']):.3f}  fp32 delta {d32:.4f}  bf16 delta {d16:.4f}")
     assert d32 <= 0.1 and d16 <= 2.0
+
+
+def test_side_state_copy_filter_and_fsqm_vs_oracle():
+    """a16 (copy half) + a17: the filtered/renumbered copy and the FSQM memory, kept on device, equal the
+    oracle's restatement of head.py:1245-1283 / fsqm.py over a multi-frame stream (state carries)."""
+    cfg, arch, sd = fixture("tiny")
+    sd = dict(sd)
+    d = f"model.{len(arch.layers)}.decoder"
+    sd[d + f".dec_score_head.{arch.ndl - 1}.bias"] = sd[d + f".dec_score_head.{arch.ndl - 1}.bias"] + 6.0   # many births, some > 0.7
+    B, steps = 3, 3
+    eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=torch.float32, side_state=True)
+    fs = O.FSQMOracle(300, 256)
+    for s in range(steps):
+        out = eng.forward(torch.from_numpy(frames_u8(cfg, s * B, B)).to(DEV))
+        torch.cuda.synchronize()
+        sc, bx, ids, hs = (out[k].cpu() for k in ("scores", "boxes", "obj_idxes", "hs"))
+        for b in range(B):
+            rows, nid = O.tracker_update_copy(sc[b].tolist(), bx[b].numpy(), ids[b].tolist())
+            n = int(eng.n_copy[b])
+            assert n == len(rows), (s, b, n, len(rows))
+            assert eng.copy_rows[b, :n].cpu().tolist() == rows
+            assert eng.copy_ids[b, :n].cpu().tolist() == nid
+            if rows:
+                det = (sc[b][rows].numpy(), bx[b][rows].numpy(), hs[b][rows].float().numpy())
+            else:       # no active row: update() hands FSQM the full Instances (head.py:1249-1251)
+                det = (sc[b].numpy(), bx[b].numpy(), hs[b].float().numpy())
+            fs.online_update(det[0], det[1], det[2], sc[b].numpy(), bx[b].numpy(), ids[b].numpy())
+        f = {k: v.cpu().numpy() for k, v in eng.fsqm.items()}
+        assert np.array_equal(f["ids"], fs.ids), s
+        assert np.array_equal(f["low"], fs.low)
+        assert np.allclose(f["conf"], fs.conf) and np.allclose(f["boxes"], fs.boxes)
+        assert np.allclose(f["mem"], fs.mem, atol=1e-6)
+        head, cnt, ovf = f["pool_hc"]
+        assert ovf == 0 and cnt == len(fs.pool)
+        assert [int(f["pool"][(head + k) % len(f["pool"])]) for k in range(cnt)] == fs.pool
+    assert (fs.ids >= 0).sum() > 0, "fixture should inject at least one query"
+    eng.reset_sequence()
+    torch.cuda.synchronize()
+    assert int((eng.fsqm["ids"] >= 0).sum()) == 0 and eng.fsqm["pool_hc"].cpu().tolist() == [0, 300, 0]
