@@ -119,6 +119,12 @@ int moy_gemm(const moy_gemm_args* args, void* stream);
 int moy_stem_conv(const void* in, int in_fmt, int B, int H, int W, const float* w, const float* scale,
                   const float* shift, int Cout, void* out, int64_t ldc, int dtype, void* stream);
 
+/* Same stem on the matrix cores (bf16 output, uint8 BGR input only): K = 27 padded to 32,
+ * wpad: bf16 [Cout, 32] with k = (ky*3+kx)*3 + c_rgb (zeros for k >= 27).  Cout in {16, 32, 64}.
+ * Input is converted as bf16(u8 * (1/255)) (the fp32 stem keeps the reference's exact u8/255). */
+int moy_stem_conv_mfma(const void* in_u8, int B, int H, int W, const void* wpad, const float* scale, const float* shift,
+                       int Cout, void* out, int64_t ldc, void* stream);
+
 /* SPPF pooling: y1 = maxpool5(x), y2 = maxpool5(y1), y3 = maxpool5(y2) (stride 1, pad 2, -inf
  * padding) == windows 5/9/13 of x.  Replaces the three nn.MaxPool2d calls of SPPF.forward
  * (nn/modules/block.py:129-134).  x: T [B,H,W,C] stride ldx; y1..y3: stride ldy. C % 8 == 0. */

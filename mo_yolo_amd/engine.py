@@ -234,10 +234,16 @@ class TrackEngine:
                 if Ls.kind == "Conv" and Ls.i == 0:
                     assert Ls.k == 3 and Ls.s == 2 and Ls.c1 == 3
                     o = out_view(0, Ls.c2)
-                    wst = self._dev(sd[p + ".conv.weight"].permute(2, 3, 1, 0).reshape(27, Ls.c2))
                     scale, shift = self._bn(p + ".bn")
-                    self._add(lib.moy_stem_conv, self.input.data_ptr(), 0 if self.input_format == "u8" else 1, B, H, W,
-                              wst.data_ptr(), scale.data_ptr(), shift.data_ptr(), Ls.c2, o.ptr, o.ld, code)
+                    if self.dtype == torch.bfloat16 and self.input_format == "u8" and Ls.c2 in (16, 32, 64):
+                        from .ops import stem_weights_mfma          # matrix-core stem (K 27 -> 32)
+                        wpad = self._dev(stem_weights_mfma(sd[p + ".conv.weight"]))
+                        self._add(lib.moy_stem_conv_mfma, self.input.data_ptr(), B, H, W, wpad.data_ptr(), scale.data_ptr(),
+                                  shift.data_ptr(), Ls.c2, o.ptr, o.ld)
+                    else:
+                        wst = self._dev(sd[p + ".conv.weight"].permute(2, 3, 1, 0).reshape(27, Ls.c2))
+                        self._add(lib.moy_stem_conv, self.input.data_ptr(), 0 if self.input_format == "u8" else 1, B, H, W,
+                                  wst.data_ptr(), scale.data_ptr(), shift.data_ptr(), Ls.c2, o.ptr, o.ld, code)
                     outv[0] = o
                 elif Ls.kind == "Conv":
                     o = out_view(Ls.i, Ls.c2)

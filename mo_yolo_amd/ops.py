@@ -104,6 +104,24 @@ def stem_conv(x, w27, scale, shift, dtype):
     return out
 
 
+def stem_weights_mfma(w):
+    """[Cout, 3, 3, 3] fp32 conv weight -> bf16 [Cout, 32], k = (ky*3+kx)*3 + c (zero padded from 27)."""
+    cout = w.shape[0]
+    out = torch.zeros(cout, 32, device=w.device, dtype=torch.float32)
+    out[:, :27] = w.permute(0, 2, 3, 1).reshape(cout, 27)
+    return out.to(torch.bfloat16).contiguous()
+
+
+def stem_conv_mfma(x_u8, wpad, scale, shift):
+    _need_gpu(x_u8)
+    B, H, W, _ = x_u8.shape
+    cout = wpad.shape[0]
+    out = torch.empty(B * (H // 2) * (W // 2), cout, device=x_u8.device, dtype=torch.bfloat16)
+    L.check(L.lib().moy_stem_conv_mfma(x_u8.data_ptr(), B, H, W, wpad.data_ptr(), scale.data_ptr(), shift.data_ptr(), cout,
+                                       out.data_ptr(), cout, _st()), "moy_stem_conv_mfma")
+    return out
+
+
 def sppf_pool(x, B, H, W):
     _need_gpu(x)
     Cc = x.shape[1]

@@ -139,6 +139,20 @@ def test_stem_conv_fused_preprocess(dt, fmt):
     assert torch.allclose(got, ref, atol=tol(dt, 1e-5, 2e-2))
 
 
+@pytest.mark.parametrize("B,H,W,Cout", [(2, 32, 48, 16), (1, 608, 1088, 32), (3, 34, 70, 32), (1, 18, 66, 64)])
+def test_stem_conv_mfma(B, H, W, Cout):
+    """Matrix-core stem (bf16): odd tile tails, image borders, every dword misalignment of the u8 rows."""
+    g = torch.Generator().manual_seed(B + W)
+    u8 = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    x = u8.flip(-1).permute(0, 3, 1, 2).float() / 255
+    w = q(rnd(Cout, 3, 3, 3, seed=2, scale=0.3), torch.bfloat16)
+    sc, sh = rnd(Cout, seed=3) * 0.2 + 1, rnd(Cout, seed=4, scale=0.1)
+    ref = F.silu(F.conv2d(q(x, torch.bfloat16), w, None, 2, 1) * sc[None, :, None, None] + sh[None, :, None, None])
+    y = ops.stem_conv_mfma(u8.to(DEV), ops.stem_weights_mfma(w.to(DEV)), sc.to(DEV), sh.to(DEV))
+    got = y.float().cpu().view(B, H // 2, W // 2, Cout).permute(0, 3, 1, 2)
+    assert torch.allclose(got, ref, atol=2e-2), float((got - ref).abs().max())
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_sppf_pool_and_upsample(dt):
     B, H, W, Cc = 2, 19, 34, 16
