@@ -845,6 +845,10 @@ static int dispatch_tile(GemmParams& p, bool ln, hipStream_t st) {
   if (ln) return w8 ? launch_cfg<T, 64, 256, 2, 4, true, KS>(p, st) : launch_cfg<T, 64, 256, 1, 4, true, KS>(p, st);
   // Tile choice: fill >= ~2 blocks per CU when the problem allows it, keep tiles large otherwise.
   const long big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  static const int force = [] { const char* e = getenv("MOY_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  if (force == 1 && !ln) return launch_cfg<T, 128, 64, 4, 2, false, KS>(p, st);
+  if (force == 2 && !ln) return launch_cfg<T, 64, 128, 2, 2, false, KS>(p, st);
+  if (force == 3 && !ln) return launch_cfg<T, 64, 64, 2, 2, false, KS>(p, st);
   if (p.N > 64) {
     if (big >= 384) return w8 ? launch_cfg<T, 128, 128, 2, 4, false, KS>(p, st) : launch_cfg<T, 128, 128, 2, 2, false, KS>(p, st);
     return launch_cfg<T, 64, 128, 2, 2, false, KS>(p, st);
