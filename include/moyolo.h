@@ -9,7 +9,7 @@
  *   - the caller owns every buffer; outputs need not be zero-initialised;
  *   - return value 0 on success, a negative MOY_E* code otherwise (shape/argument errors are
  *     detected on the host BEFORE anything is launched);
- *   - dtype codes: MOY_F32 = 0, MOY_BF16 = 1.  "T" below means the dtype selected by `dtype`.
+ *   - dtype codes: MOY_F32 = 0, MOY_BF16 = 1, MOY_F16 = 2 (the reference's `half` switch, predictor.py:131).  "T" below means the dtype selected by `dtype`.
  *   - activations are channels-last: an image tensor is [B, H, W, C] with a row (pixel) stride
  *     `ld` in elements, so channel slices of wider (concat) buffers are addressed in place.
  *
@@ -26,6 +26,7 @@ extern "C" {
 
 #define MOY_F32 0
 #define MOY_BF16 1
+#define MOY_F16 2
 
 #define MOY_OK 0
 #define MOY_EINVAL (-22)   /* bad shape / argument */

@@ -15,6 +15,10 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 struct bf16_t {
   uint16_t v;
 };
+struct f16_t {
+  uint16_t v;
+};
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float bf2f(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
 // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN preserving) on gfx950
@@ -24,6 +28,8 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 }
 __device__ __forceinline__ float bflo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+__device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
 
 template <typename T>
 struct DT;  // elements per 16-byte chunk, load/store of 4 consecutive elements as fp32
@@ -37,9 +43,29 @@ struct DT<float> {
   static __device__ __forceinline__ void store1(float* p, float v) { *p = v; }
 };
 template <>
+struct DT<f16_t> {
+  static constexpr int KPB = 8;
+  static constexpr int code = MOY_F16;
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)f2h(lo) | ((uint32_t)f2h(hi) << 16); }
+  static __device__ __forceinline__ float lo(uint32_t w) { return h2f((uint16_t)(w & 0xffffu)); }
+  static __device__ __forceinline__ float hi(uint32_t w) { return h2f((uint16_t)(w >> 16)); }
+  static __device__ __forceinline__ f32x4 load4(const f16_t* p) {
+    u32x2 w = *reinterpret_cast<const u32x2*>(p);
+    return f32x4{lo(w.x), hi(w.x), lo(w.y), hi(w.y)};
+  }
+  static __device__ __forceinline__ void store4(f16_t* p, f32x4 v) {
+    *reinterpret_cast<u32x2*>(p) = u32x2{pack2(v.x, v.y), pack2(v.z, v.w)};
+  }
+  static __device__ __forceinline__ float load1(const f16_t* p) { return h2f(p->v); }
+  static __device__ __forceinline__ void store1(f16_t* p, float v) { p->v = f2h(v); }
+};
+template <>
 struct DT<bf16_t> {
   static constexpr int KPB = 8;
   static constexpr int code = MOY_BF16;
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf2(lo, hi); }
+  static __device__ __forceinline__ float lo(uint32_t w) { return bflo(w); }
+  static __device__ __forceinline__ float hi(uint32_t w) { return bfhi(w); }
   static __device__ __forceinline__ f32x4 load4(const bf16_t* p) {
     u32x2 w = *reinterpret_cast<const u32x2*>(p);
     return f32x4{bflo(w.x), bfhi(w.x), bflo(w.y), bfhi(w.y)};

@@ -63,15 +63,20 @@ __device__ __forceinline__ u32x4 add_chunks<float>(u32x4 a, u32x4 b) {
   f32x4 x = __builtin_bit_cast(f32x4, a), y = __builtin_bit_cast(f32x4, b);
   return __builtin_bit_cast(u32x4, x + y);
 }
-template <>
-__device__ __forceinline__ u32x4 add_chunks<bf16_t>(u32x4 a, u32x4 b) {
+template <typename T>
+__device__ __forceinline__ u32x4 add_chunks16(u32x4 a, u32x4 b) {
+  using D = DT<T>;
   u32x4 r;
-  r.x = pack_bf2(bflo(a.x) + bflo(b.x), bfhi(a.x) + bfhi(b.x));
-  r.y = pack_bf2(bflo(a.y) + bflo(b.y), bfhi(a.y) + bfhi(b.y));
-  r.z = pack_bf2(bflo(a.z) + bflo(b.z), bfhi(a.z) + bfhi(b.z));
-  r.w = pack_bf2(bflo(a.w) + bflo(b.w), bfhi(a.w) + bfhi(b.w));
+  r.x = D::pack2(D::lo(a.x) + D::lo(b.x), D::hi(a.x) + D::hi(b.x));
+  r.y = D::pack2(D::lo(a.y) + D::lo(b.y), D::hi(a.y) + D::hi(b.y));
+  r.z = D::pack2(D::lo(a.z) + D::lo(b.z), D::hi(a.z) + D::hi(b.z));
+  r.w = D::pack2(D::lo(a.w) + D::lo(b.w), D::hi(a.w) + D::hi(b.w));
   return r;
 }
+template <>
+__device__ __forceinline__ u32x4 add_chunks<bf16_t>(u32x4 a, u32x4 b) { return add_chunks16<bf16_t>(a, b); }
+template <>
+__device__ __forceinline__ u32x4 add_chunks<f16_t>(u32x4 a, u32x4 b) { return add_chunks16<f16_t>(a, b); }
 
 template <typename T>
 __device__ __forceinline__ void mma_panel(f32x4& acc, u32x4 wfrag, u32x4 afrag);
@@ -79,6 +84,10 @@ template <>
 __device__ __forceinline__ void mma_panel<bf16_t>(f32x4& acc, u32x4 wfrag, u32x4 afrag) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, afrag),
                                                 acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_panel<f16_t>(f32x4& acc, u32x4 wfrag, u32x4 afrag) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wfrag), __builtin_bit_cast(f16x8, afrag), acc, 0, 0, 0);
 }
 template <>
 __device__ __forceinline__ void mma_panel<float>(f32x4& acc, u32x4 wfrag, u32x4 afrag) {
@@ -209,40 +218,40 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const float* 
 
 // bf16 output without LayerNorm: 8 columns per thread -> one 16-byte store (half the store
 // instructions of the 4-column form; 8-byte-per-lane stores run at ~0.6x the 16-byte rate).
-template <int BM, int BN, int NTHR>
+template <typename T, int BM, int BN, int NTHR>
 __device__ __forceinline__ void gemm_epilogue_bf16x8(const GemmParams& p, const float* Cs, int m0, int n0, int tid) {
   constexpr int LDC = BN + 4;
   constexpr int CPR = BN / 8, RSTEP = NTHR / CPR, NPASS = BM / RSTEP;
   static_assert(BM % RSTEP == 0, "tile vs threads");
-  const bf16_t* __restrict__ Rg = static_cast<const bf16_t*>(p.R);
+  const T* __restrict__ Rg = static_cast<const T*>(p.R);
   const int cc = tid % CPR, rr0 = tid / CPR;
   const int n = n0 + cc * 8;
   const bool col_ok = n < p.N;                       // N % 8 == 0 on this path (host-checked)
   const int nc = col_ok ? n : 0;
   u32x4 res[NPASS];
   if (Rg) {
-    const bf16_t* rp = Rg + nc;
+    const T* rp = Rg + nc;
 #pragma unroll
     for (int k = 0; k < NPASS; ++k) {
       const int m = min(m0 + rr0 + k * RSTEP, p.M - 1);
       res[k] = *reinterpret_cast<const u32x4*>(rp + (int64_t)m * p.ldr);
     }
   }
-  bf16_t* cbase = static_cast<bf16_t*>(p.C) + n;
+  T* cbase = static_cast<T*>(p.C) + n;
 #pragma unroll
   for (int k = 0; k < NPASS; ++k) {
     const int rr = rr0 + k * RSTEP, m = m0 + rr;
     f32x4 v0 = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + cc * 8);
     f32x4 v1 = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + cc * 8 + 4);
     if (Rg) {
-      v0 += f32x4{bflo(res[k].x), bfhi(res[k].x), bflo(res[k].y), bfhi(res[k].y)};
-      v1 += f32x4{bflo(res[k].z), bfhi(res[k].z), bflo(res[k].w), bfhi(res[k].w)};
+      v0 += f32x4{DT<T>::lo(res[k].x), DT<T>::hi(res[k].x), DT<T>::lo(res[k].y), DT<T>::hi(res[k].y)};
+      v1 += f32x4{DT<T>::lo(res[k].z), DT<T>::hi(res[k].z), DT<T>::lo(res[k].w), DT<T>::hi(res[k].w)};
     }
     if (col_ok && m < p.M) {
       int64_t mo = m;
       if (p.c_rpb) mo = (int64_t)(m / p.c_rpb) * p.c_bstride + (m % p.c_rpb);
       *reinterpret_cast<u32x4*>(cbase + mo * p.ldc) =
-          u32x4{pack_bf2(v0.x, v0.y), pack_bf2(v0.z, v0.w), pack_bf2(v1.x, v1.y), pack_bf2(v1.z, v1.w)};
+          u32x4{DT<T>::pack2(v0.x, v0.y), DT<T>::pack2(v0.z, v0.w), DT<T>::pack2(v1.x, v1.y), DT<T>::pack2(v1.z, v1.w)};
     }
   }
 }
@@ -437,8 +446,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
   stage_acc<BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q);
   __syncthreads();
 
-  if constexpr (!LN && std::is_same<T, bf16_t>::value) {
-    if (p.wide_store) { gemm_epilogue_bf16x8<BM, BN, NTHR>(p, Cs, m0, n0, tid); return; }
+  if constexpr (!LN && !std::is_same<T, float>::value) {
+    if (p.wide_store) { gemm_epilogue_bf16x8<T, BM, BN, NTHR>(p, Cs, m0, n0, tid); return; }
   }
   gemm_epilogue<T, BM, BN, LN, NTHR>(p, Cs, m0, n0, tid);
 }
@@ -619,8 +628,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_dma_kernel(const GemmPara
   float* Cs = reinterpret_cast<float*>(smem);
   stage_acc<BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q);
   __syncthreads();
-  if constexpr (!LN && std::is_same<T, bf16_t>::value) {
-    if (p.wide_store) { gemm_epilogue_bf16x8<BM, BN, NTHR>(p, Cs, m0, n0, tid); return; }
+  if constexpr (!LN && !std::is_same<T, float>::value) {
+    if (p.wide_store) { gemm_epilogue_bf16x8<T, BM, BN, NTHR>(p, Cs, m0, n0, tid); return; }
   }
   gemm_epilogue<T, BM, BN, LN, NTHR>(p, Cs, m0, n0, tid);
 }
@@ -865,9 +874,9 @@ using namespace moy;
 
 extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->W || !a->C) return MOY_EINVAL;
-  if (a->dtype != MOY_F32 && a->dtype != MOY_BF16) return MOY_EINVAL;
-  const int kpb = a->dtype == MOY_BF16 ? 8 : 4;
-  const int esz = a->dtype == MOY_BF16 ? 2 : 4;
+  if (a->dtype != MOY_F32 && a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_EINVAL;
+  const int kpb = a->dtype == MOY_F32 ? 4 : 8;
+  const int esz = a->dtype == MOY_F32 ? 4 : 2;
   const int bk = 4 * kpb * PANELS;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return MOY_EINVAL;
   if (a->N % 4) return MOY_EINVAL;
@@ -909,7 +918,7 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
   if (a->dot_n < 0 || a->dot_n > 8) return MOY_EINVAL;
   if (a->dot_n && (!ln || !a->dot_w || !a->dot_b || !a->dot_out || !aligned16(a->dot_w))) return MOY_EINVAL;
   p.dot_w = a->dot_w; p.dot_b = a->dot_b; p.dot_out = a->dot_out; p.dot_n = a->dot_n;
-  p.wide_store = a->dtype == MOY_BF16 && !a->out_f32 && !ln && a->N % 8 == 0 && (a->ldc % 8) == 0 && aligned16(a->C) &&
+  p.wide_store = a->dtype != MOY_F32 && !a->out_f32 && !ln && a->N % 8 == 0 && (a->ldc % 8) == 0 && aligned16(a->C) &&
                  (!a->R || ((a->ldr % 8) == 0 && aligned16(a->R)));
   if (a->ksize == 1) {
     if (a->K % kpb) return MOY_EINVAL;
@@ -936,15 +945,17 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
   // (16 rows x 64 B per load, 16 rows x 32 B per store) multiply the request count per byte.  Opt-in only.
   static const bool use_stream = [] { const char* e = getenv("MOY_GEMM_STREAM"); return e && e[0] == '1'; }();
   if (use_stream && a->ksize == 1 && !ln) {
-    const int rc = a->dtype == MOY_BF16 ? dispatch_stream<bf16_t>(p, st) : dispatch_stream<float>(p, st);
+    const int rc = a->dtype == MOY_BF16 ? dispatch_stream<bf16_t>(p, st) : a->dtype == MOY_F16 ? MOY_ENOSYS : dispatch_stream<float>(p, st);
     if (rc != MOY_ENOSYS) return rc;
   }
-  if (!a->A2 && use_dma) {   // the A + A2 prologue add needs the register-staged kernel
+  if (!a->A2 && use_dma && a->dtype != MOY_F16) {   // the A + A2 prologue add needs the register-staged kernel
     if (a->dtype == MOY_BF16)
       return a->ksize == 1 ? dispatch_dma<bf16_t, 1>(p, ln, st) : dispatch_dma<bf16_t, 3>(p, ln, st);
     return a->ksize == 1 ? dispatch_dma<float, 1>(p, ln, st) : dispatch_dma<float, 3>(p, ln, st);
   }
   if (a->dtype == MOY_BF16)
     return a->ksize == 1 ? dispatch_tile<bf16_t, 1>(p, ln, st) : dispatch_tile<bf16_t, 3>(p, ln, st);
+  if (a->dtype == MOY_F16)
+    return a->ksize == 1 ? dispatch_tile<f16_t, 1>(p, ln, st) : dispatch_tile<f16_t, 3>(p, ln, st);
   return a->ksize == 1 ? dispatch_tile<float, 1>(p, ln, st) : dispatch_tile<float, 3>(p, ln, st);
 }

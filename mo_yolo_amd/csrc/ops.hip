@@ -178,15 +178,20 @@ template <>
 __device__ __forceinline__ u32x4 max_chunk<float>(u32x4 a, u32x4 b) {
   return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(f32x4, a), __builtin_bit_cast(f32x4, b)));
 }
-template <>
-__device__ __forceinline__ u32x4 max_chunk<bf16_t>(u32x4 a, u32x4 b) {
+template <typename T>
+__device__ __forceinline__ u32x4 max_chunk16(u32x4 a, u32x4 b) {
+  using D = DT<T>;
   u32x4 r;
-  r.x = pack_bf2(fmaxf(bflo(a.x), bflo(b.x)), fmaxf(bfhi(a.x), bfhi(b.x)));
-  r.y = pack_bf2(fmaxf(bflo(a.y), bflo(b.y)), fmaxf(bfhi(a.y), bfhi(b.y)));
-  r.z = pack_bf2(fmaxf(bflo(a.z), bflo(b.z)), fmaxf(bfhi(a.z), bfhi(b.z)));
-  r.w = pack_bf2(fmaxf(bflo(a.w), bflo(b.w)), fmaxf(bfhi(a.w), bfhi(b.w)));
+  r.x = D::pack2(fmaxf(D::lo(a.x), D::lo(b.x)), fmaxf(D::hi(a.x), D::hi(b.x)));
+  r.y = D::pack2(fmaxf(D::lo(a.y), D::lo(b.y)), fmaxf(D::hi(a.y), D::hi(b.y)));
+  r.z = D::pack2(fmaxf(D::lo(a.z), D::lo(b.z)), fmaxf(D::hi(a.z), D::hi(b.z)));
+  r.w = D::pack2(fmaxf(D::lo(a.w), D::lo(b.w)), fmaxf(D::hi(a.w), D::hi(b.w)));
   return r;
 }
+template <>
+__device__ __forceinline__ u32x4 max_chunk<bf16_t>(u32x4 a, u32x4 b) { return max_chunk16<bf16_t>(a, b); }
+template <>
+__device__ __forceinline__ u32x4 max_chunk<f16_t>(u32x4 a, u32x4 b) { return max_chunk16<f16_t>(a, b); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void sppf_pool_kernel(const T* __restrict__ x, int64_t ldx, int H, int W, int C,
@@ -432,6 +437,10 @@ __device__ __forceinline__ void mma16<bf16_t>(f32x4& acc, u32x4 afrag, u32x4 bfr
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afrag), __builtin_bit_cast(bf16x8, bfrag), acc, 0, 0, 0);
 }
 template <>
+__device__ __forceinline__ void mma16<f16_t>(f32x4& acc, u32x4 afrag, u32x4 bfrag) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, afrag), __builtin_bit_cast(f16x8, bfrag), acc, 0, 0, 0);
+}
+template <>
 __device__ __forceinline__ void mma16<float>(f32x4& acc, u32x4 afrag, u32x4 bfrag) {
   const f32x4 a = __builtin_bit_cast(f32x4, afrag), b = __builtin_bit_cast(f32x4, bfrag);
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
@@ -467,7 +476,7 @@ __global__ __launch_bounds__(256) void mha_kernel(const T* __restrict__ qkv, int
     }
     const int pd = ch >> 2, c4 = ch & 3;
     *reinterpret_cast<u32x4*>(Ks + (pd * Lp + key) * 64 + swz16(key, c4) * 16) = kv;
-    if (BF) {
+    if constexpr (BF) {
       const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -527,12 +536,12 @@ __global__ __launch_bounds__(256) void mha_kernel(const T* __restrict__ qkv, int
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    if (BF) {
+    if constexpr (BF) {
 #pragma unroll
       for (int kb = 0; kb < (NKT + 1) / 2; ++kb)
         if (kb * 2 < nkt) {
           const f32x4 p0 = s[2 * kb], p1 = s[2 * kb + 1];
-          const u32x4 pf = {pack_bf2(p0.x, p0.y), pack_bf2(p0.z, p0.w), pack_bf2(p1.x, p1.y), pack_bf2(p1.z, p1.w)};
+          const u32x4 pf = {DT<T>::pack2(p0.x, p0.y), DT<T>::pack2(p0.z, p0.w), DT<T>::pack2(p1.x, p1.y), DT<T>::pack2(p1.z, p1.w)};
 #pragma unroll
           for (int dh = 0; dh < 2; ++dh) {
             const unsigned char* vr = Vt + (dh * 16 + r) * vstride + (kb * 32 + q4 * 4) * 2;
@@ -913,6 +922,7 @@ using namespace moy;
 #define MOY_DISPATCH_T(dtype, ...)                          \
   if ((dtype) == MOY_F32) { using T = float; __VA_ARGS__ }  \
   else if ((dtype) == MOY_BF16) { using T = bf16_t; __VA_ARGS__ } \
+  else if ((dtype) == MOY_F16) { using T = f16_t; __VA_ARGS__ } \
   else return MOY_EINVAL;
 
 extern "C" int moy_version(void) { return 100; }

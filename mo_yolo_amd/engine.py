@@ -52,7 +52,7 @@ class View:
 
 
 def _code(dtype):
-    return {torch.float32: L.F32, torch.bfloat16: L.BF16}[dtype]
+    return {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}[dtype]
 
 
 class TrackEngine:
@@ -92,7 +92,7 @@ class TrackEngine:
         return t
 
     def _kpad(self, K):
-        bk = 64 if self.dtype == torch.bfloat16 else 32
+        bk = 32 if self.dtype == torch.float32 else 64
         return (K + bk - 1) // bk * bk
 
     def _weight(self, w2d):
@@ -143,7 +143,7 @@ class TrackEngine:
         if dot is not None:
             a.dot_w, a.dot_b, a.dot_out, a.dot_n = dot[0].data_ptr(), dot[1].data_ptr(), dot[2].data_ptr(), dot[0].shape[0]
         self._keep.append(a)
-        esz = 2 if self.dtype == torch.bfloat16 else 4
+        esz = 4 if self.dtype == torch.float32 else 2
         if geom is not None:
             a_elems = geom[0] * geom[1] * geom[2] * geom[5]      # every input pixel read once
         else:

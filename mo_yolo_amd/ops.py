@@ -19,6 +19,8 @@ def _code(t: torch.Tensor):
         return L.F32
     if t.dtype == torch.bfloat16:
         return L.BF16
+    if t.dtype == torch.float16:
+        return L.F16
     raise TypeError(f"unsupported dtype {t.dtype}")
 
 
@@ -36,7 +38,7 @@ def _ld(t):
 
 def pad_weight(w2d: torch.Tensor, dtype) -> torch.Tensor:
     """[N, K] -> [N, Kpad] (Kpad multiple of 64 for bf16 / 32 for f32), zero padded, in `dtype`."""
-    bk = 64 if dtype == torch.bfloat16 else 32
+    bk = 32 if dtype == torch.float32 else 64
     N, K = w2d.shape
     out = torch.zeros(N, (K + bk - 1) // bk * bk, device=w2d.device, dtype=torch.float32)
     out[:, :K] = w2d.float()
@@ -202,9 +204,9 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     _, Lq, _, Lv, P, _ = sampling_loc.shape
     assert spatial_shapes.dtype == torch.int64 and level_start_index.dtype == torch.int64
     out = torch.empty(N, Lq, M * D, device=value.device, dtype=value.dtype)
-    fn = L.lib().moy_msda_fwd_f32 if value.dtype == torch.float32 else L.lib().moy_msda_fwd_bf16
     if value.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError("ms_deform_attn_forward: float32 / bfloat16 only")
+    fn = L.lib().moy_msda_fwd_f32 if value.dtype == torch.float32 else L.lib().moy_msda_fwd_bf16
     L.check(fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
                attn_weight.data_ptr(), N, S, M, D, Lv, Lq, P, out.data_ptr(), _st()), "moy_msda_fwd")
     return out

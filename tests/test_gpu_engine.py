@@ -130,6 +130,39 @@ def test_engine_fp32_c2_vs_reference_golden():
     assert float((out["boxes"].cpu() - r["dec_bboxes"]).abs().max()) < 1e-4
 
 
+def test_engine_fp16_c5_batched_sequences_graph():
+    """Config C5: fp16 activations/weights (the reference's own `half` switch, predictor.py:131), frames of
+    4 sequences batched into one hipGraph-captured step; boxes/scores vs the oracle per sequence."""
+    cfg, arch, sd = fixture("tiny")
+    nseq, per = 4, 2
+    eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=nseq * per, dtype=torch.float16)
+    fr = np.concatenate([frames_u8(cfg, 0, per, seq_id=s) for s in range(nseq)])
+    frd = torch.from_numpy(fr).to(DEV)
+    eng.forward(frd)
+    eng.capture()
+    out = eng.forward(frd)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        x = torch.cat([net_input(cfg, 0, per, seq_id=s) for s in range(nseq)])
+        r = O.forward(x, sd, arch)
+    # rows matched by selected token (fp16 reorders near-tied encoder scores)
+    tk, rk = out["topk_ind"].cpu().long(), r["topk_ind"]
+    ref_scores = r["dec_scores"].sigmoid().max(-1).values
+    db, ds, matched = 0.0, 0.0, 0
+    for b_ in range(nseq * per):
+        pos = {int(t): i for i, t in enumerate(rk[b_])}
+        for i, t in enumerate(tk[b_]):
+            j = pos.get(int(t))
+            if j is not None:
+                matched += 1
+                db = max(db, float((out["boxes"][b_, i].cpu() - r["dec_bboxes"][b_, j]).abs().max()))
+                ds = max(ds, float((out["scores"][b_, i].cpu() - ref_scores[b_, j]).abs()))
+    frac = matched / tk.numel()
+    print(f"[fp16 C5] token overlap {frac:.3f} box err {db:.4f} score err {ds:.4f}")
+    assert frac > 0.9
+    assert float(db) < 0.02 and float(ds) < 0.1
+
+
 @pytest.mark.parametrize("name", ["tiny", "c2"])
 def test_engine_bf16_close_to_oracle(name):
     """bf16 activations/weights with fp32 accumulation: not a parity path; stated bars on boxes and

@@ -17,11 +17,12 @@ from oracle import track_oracle as O
 from tests._util import golden
 
 DEV = "cuda"
-DT = [torch.float32, torch.bfloat16]
+DT = [torch.float32, torch.bfloat16, torch.float16]
 
 
 def tol(dt, f32=2e-5, bf=3e-2):
-    return f32 if dt == torch.float32 else bf
+    """fp32: tight; bf16 (8 mantissa bits): `bf`; fp16 (11 bits): bf / 4."""
+    return f32 if dt == torch.float32 else (bf if dt == torch.bfloat16 else bf / 4)
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -251,6 +252,8 @@ def test_msda_fused_vs_oracle(dt):
 def test_ms_deform_attn_forward_kats(dt):
     """The reference operator API on its own KAT construction (MOTR/models/ops/test.py:21-30),
     expected values produced by the reference's torch op in the build container."""
+    if dt == torch.float16:
+        pytest.skip("the generic operator entry is f32 / bf16 (the reference dispatches fp32/fp64 only)")
     g = golden("msda_kat")
     for name in ("kat_tiny", "kat_heads8", "kat_odd"):
         v, loc, aw = (torch.from_numpy(g[f"{name}.{k}"]) for k in ("value", "loc", "aw"))
