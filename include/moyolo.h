@@ -57,7 +57,7 @@ const char* moy_strerror(int code);
  *               (a gathered A must span < 2 GiB: it is addressed through one buffer descriptor)
  *   ksize == 3: m = (b, oy, ox) over [B, Hout, Wout]; k = (ky*3+kx)*Cin + c; the element is
  *               A[((b*Hin + oy*stride+ky-1)*Win + ox*stride+kx-1) * lda + c], 0 outside the image
- *               (pad = 1).  Cin must be a power of two >= 8 (bf16) / 4 (f32).
+ *               (pad = 1).  Cin % 8 == 0 (16-bit types) / % 4 (f32).
  *   A2 (optional, ksize 1 only): added element-wise to A before the product (q = k = x + pos).
  *   a_mask (optional, ksize 1 only): rows with a_mask[m % mask_period] == 0 read as zero
  *               (valid_mask * feats, head.py:1039).
@@ -230,6 +230,24 @@ int moy_track_state_update(const float* scores, const float* boxes, const int64_
 /* FSQM.reset (fsqm.py:182-190): zero memory, ids = -1, pool = 0..299. */
 int moy_fsqm_reset(float* mem, float* conf, int64_t* ids, float* fboxes, int32_t* low, int32_t* pool, int32_t pool_cap,
                    int32_t* pool_hc, void* stream);
+
+/* Config C1 (YOLOv8n detect).
+ * moy_detect_decode: Detect.forward decode for ONE pyramid level (nn/modules/head.py:60-77): DFL
+ * (softmax over 16 bins . arange, nn/modules/block.py:31-35) -> dist2bbox xywh (utils/tal.py:261-270,
+ * anchors at cell + 0.5) * stride, sigmoid(cls).  box T [B*h*w, >=64] (ld_box), cls T [B*h*w, >=nc];
+ * y fp32 [B, 4+nc, A] channel-major as the reference returns it; this level fills anchors
+ * [a_off, a_off + h*w). */
+int moy_detect_decode(const void* box, int64_t ld_box, const void* cls, int64_t ld_cls, int B, int h, int w, int nc,
+                      float stride, int a_off, int A, float* y, int dtype, void* stream);
+/* moy_nms: ops.non_max_suppression (utils/ops.py:148-283; single-label, class-aware via the
+ * max_wh class offset) + torchvision.ops.nms semantics (greedy by descending score, IoU > iou_thres
+ * suppresses; ties: lower anchor index first) + ops.scale_boxes / clip_boxes (utils/ops.py:99-129,
+ * 285-298) as DetectionPredictor.postprocess applies them (models/yolo/detect/predict.py:12-30).
+ *   y fp32 [B, 4+nc, A] -> rows fp32 [B, max_det, 6] = (x1, y1, x2, y2, conf, cls), n_rows int32 [B].
+ *   boxes are mapped back with (x - pad_x) / gain, (y - pad_y) / gain and clipped to [0, clip_w] x [0, clip_h]
+ *   (pass gain 1, pads 0, clip <= 0 to skip).  A <= 16384. */
+int moy_nms(const float* y, int B, int nc, int A, float conf_thres, float iou_thres, int max_det, float max_wh, float gain,
+            float pad_x, float pad_y, float clip_w, float clip_h, float* rows, int32_t* n_rows, void* stream);
 
 /* Elementwise helpers. */
 /* dst T [M, N] (ldd) = src T [rows[m], :] (lds): row gather (features[batch_ind, topk_ind], head.py:1096). N % 8 == 0. */

@@ -49,6 +49,8 @@ SIGNATURES = {
     "moy_assign_post": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, f32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "moy_track_state_update": (C.c_int, [vp, vp, vp, vp, i64, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, C.c_int, vp]),
     "moy_fsqm_reset": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, vp]),
+    "moy_detect_decode": (C.c_int, [vp, i64, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "moy_nms": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, f32, f32, C.c_int, f32, f32, f32, f32, f32, f32, vp, vp, vp]),
     "moy_gather_rows": (C.c_int, [vp, i64, vp, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
     "moy_cast_f32_to": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
     "moy_sigmoid_f32": (C.c_int, [vp, C.c_int, vp, vp]),

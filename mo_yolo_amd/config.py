@@ -42,6 +42,18 @@ _YOLO_TRACK = [
 ]
 HEAD_FROM = (15, 18, 21)
 
+# (from, repeats, kind, args) -- ultralytics/cfg/models/v8/yolov8.yaml:15-46 (config C1: YOLOv8n detect)
+_YOLO_V8 = [
+    (-1, 1, "Conv", (64, 3, 2)), (-1, 1, "Conv", (128, 3, 2)), (-1, 3, "C2f", (128, True)),
+    (-1, 1, "Conv", (256, 3, 2)), (-1, 6, "C2f", (256, True)), (-1, 1, "Conv", (512, 3, 2)),
+    (-1, 6, "C2f", (512, True)), (-1, 1, "Conv", (1024, 3, 2)), (-1, 3, "C2f", (1024, True)),
+    (-1, 1, "SPPF", (1024, 5)),
+    (-1, 1, "Upsample", ()), ((-1, 6), 1, "Concat", ()), (-1, 3, "C2f", (512, False)),
+    (-1, 1, "Upsample", ()), ((-1, 4), 1, "Concat", ()), (-1, 3, "C2f", (256, False)),
+    (-1, 1, "Conv", (256, 3, 2)), ((-1, 12), 1, "Concat", ()), (-1, 3, "C2f", (512, False)),
+    (-1, 1, "Conv", (512, 3, 2)), ((-1, 9), 1, "Concat", ()), (-1, 3, "C2f", (1024, False)),
+]
+
 
 def make_divisible(x, d=8):
     return int(math.ceil(x / d) * d)
@@ -73,28 +85,34 @@ class TrackArch:
     d_ffn: int = 1024
     layers: List[LayerSpec] = field(default_factory=list)
     head_ch: Tuple[int, ...] = ()
+    head_kind: str = "track"     # "track" (MOTRTrack, head.py:90) | "detect" (Detect, head.py:27)
 
     @property
     def nl(self):
         return len(self.head_ch)
 
 
-def build_arch(depth=0.33, width=0.50, nc=1, nq=300) -> TrackArch:
-    arch = TrackArch(depth=depth, width=width, nc=nc, nq=nq)
+def build_detect_arch(depth=0.33, width=0.25, nc=80, max_channels=1024) -> TrackArch:
+    """YOLOv8 detection graph at a `scales` entry of yolov8.yaml (default 'n': 0.33 / 0.25 / 1024)."""
+    return build_arch(depth, width, nc, nq=0, table=_YOLO_V8, max_channels=max_channels, head_kind="detect")
+
+
+def build_arch(depth=0.33, width=0.50, nc=1, nq=300, table=None, max_channels=float("inf"), head_kind="track") -> TrackArch:
+    arch = TrackArch(depth=depth, width=width, nc=nc, nq=nq, head_kind=head_kind)
     ch: List[int] = []
     c_prev = 3
-    for i, (f, n, kind, args) in enumerate(_YOLO_TRACK):
+    for i, (f, n, kind, args) in enumerate(table or _YOLO_TRACK):
         n = max(round(n * depth), 1) if n > 1 else n
         src = tuple((i - 1 if j == -1 else j) for j in ((f,) if isinstance(f, int) else f))
         c1 = c_prev if src[0] == i - 1 and i > 0 else (3 if i == 0 else ch[src[0]])
         if kind == "Conv":
-            c2 = make_divisible(args[0] * width)
+            c2 = make_divisible(min(args[0], max_channels) * width)      # tasks.py:911
             spec = LayerSpec(i, kind, src, c1, c2, k=args[1], s=args[2])
         elif kind == "C2f":
-            c2 = make_divisible(args[0] * width)
+            c2 = make_divisible(min(args[0], max_channels) * width)
             spec = LayerSpec(i, kind, src, c1, c2, n=n, shortcut=args[1])
         elif kind == "SPPF":
-            c2 = make_divisible(args[0] * width)
+            c2 = make_divisible(min(args[0], max_channels) * width)
             spec = LayerSpec(i, kind, src, c1, c2, k=args[1])
         elif kind == "Upsample":
             spec = LayerSpec(i, kind, src, c1, c1)
@@ -165,6 +183,16 @@ def param_shapes(arch: TrackArch) -> "OrderedDict[str, tuple]":
             _conv_bn(sd, p + ".cv2", c_ * 4, L.c2, 1)
     h = f"model.{len(arch.layers)}"
     hd, nc = arch.hd, arch.nc
+    if arch.head_kind == "detect":                            # Detect.__init__, head.py:35-47
+        c2, c3 = max(16, arch.head_ch[0] // 4, 64), max(arch.head_ch[0], min(nc, 100))
+        for name, cm, cout in (("cv2", c2, 64), ("cv3", c3, nc)):
+            for li, c in enumerate(arch.head_ch):
+                _conv_bn(sd, f"{h}.{name}.{li}.0", c, cm, 3)
+                _conv_bn(sd, f"{h}.{name}.{li}.1", cm, cm, 3)
+                sd[f"{h}.{name}.{li}.2.weight"] = (cout, cm, 1, 1)
+                sd[f"{h}.{name}.{li}.2.bias"] = (cout,)
+        sd[h + ".dfl.conv.weight"] = (1, 16, 1, 1)
+        return sd
     d = h + ".decoder"
     for li, c in enumerate(arch.head_ch):
         sd[f"{d}.input_proj.{li}.0.weight"] = (hd, c, 1, 1)

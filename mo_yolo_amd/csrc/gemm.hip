@@ -33,7 +33,8 @@ struct GemmParams {
   const void* W;
   int M, N, K, Kpad;
   int ksize, stride;
-  int Hin, Win, Hout, Wout, Cin, lgC;
+  int Hin, Win, Hout, Wout, Cin;
+  uint32_t cin_magic;   // ceil(2^32 / Cin): tap = umulhi(kc, magic) is exact for kc < 2^32 / Cin
   const float* scale;
   const float* shift;
   int act;
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
       }
     } else {
       const int kc = kt * BK + kc0;
-      const int tap = kc >> p.lgC, c = kc & (p.Cin - 1);
+      const int tap = (int)__umulhi((unsigned)kc, p.cin_magic), c = kc - tap * p.Cin;   // kc / Cin, kc % Cin (any Cin)
       const int ky = (tap * 11) >> 5, kx = tap - ky * 3;   // tap / 3 for tap < 16
       const uint32_t delta = (uint32_t)(((ky * p.Win + kx) * (int)p.lda + c) * ESZ);
 #pragma unroll
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_dma_kernel(const GemmPara
       if (KS == 1) {
         if (a_ok[j] && kc < p.K) src = Ag + a_off[j] + kc;
       } else {
-        const int tap = kc >> p.lgC, c = kc & (p.Cin - 1);
+        const int tap = (int)__umulhi((unsigned)kc, p.cin_magic), c = kc - tap * p.Cin;   // kc / Cin, kc % Cin (any Cin)
         const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
         const int iy = iy0[j] + ky, ix = ix0[j] + kx;
         if (a_ok[j] && tap < 9 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win)
@@ -924,15 +925,13 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
     if (a->K % kpb) return MOY_EINVAL;
   } else {
     const int C = a->Cin;
-    if (C < kpb || (C & (C - 1)) || a->K != 9 * C) return MOY_EINVAL;
+    if (C < kpb || (C % kpb) || a->K != 9 * C) return MOY_EINVAL;
     if (a->stride != 1 && a->stride != 2) return MOY_EINVAL;
     if (a->B <= 0 || a->Hin <= 0 || a->Win <= 0) return MOY_EINVAL;
     if (a->Hout != (a->Hin + 2 - 3) / a->stride + 1 || a->Wout != (a->Win + 2 - 3) / a->stride + 1) return MOY_EINVAL;
     if ((long)a->B * a->Hout * a->Wout != a->M) return MOY_EINVAL;
     p.Hin = a->Hin; p.Win = a->Win; p.Hout = a->Hout; p.Wout = a->Wout; p.Cin = C;
-    int lg = 0;
-    while ((1 << lg) < C) ++lg;
-    p.lgC = lg;
+    p.cin_magic = (uint32_t)(((1ull << 32) + (unsigned)C - 1) / (unsigned)C);
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   // Main-loop variant: register-staged (default) or LDS-DMA ring (MOY_GEMM_IMPL=dma).  Measured on

@@ -889,6 +889,126 @@ __global__ __launch_bounds__(256) void fsqm_reset_kernel(float* mem, float* conf
   if (t == 0) { pool_hc[0] = 0; pool_hc[1] = FSQM_SLOTS; pool_hc[2] = 0; }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Config C1: Detect decode + NMS.
+template <typename T>
+__global__ __launch_bounds__(256) void detect_decode_kernel(const T* __restrict__ box, int64_t ld_box, const T* __restrict__ cls,
+                                                            int64_t ld_cls, int B, int h, int w, int nc, float stride, int a_off,
+                                                            int A, float* __restrict__ y) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int hw = h * w;
+  if (t >= (long)B * hw) return;
+  const int b = (int)(t / hw), a = (int)(t - (long)b * hw);
+  const T* bp = box + t * ld_box;
+  float d[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {            // DFL: expectation of softmax over 16 bins
+    float v[16], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) {
+      const f32x4 q4 = DT<T>::load4(bp + s * 16 + k);
+      v[k] = q4.x; v[k + 1] = q4.y; v[k + 2] = q4.z; v[k + 3] = q4.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mx = fmaxf(mx, v[k]);
+    float den = 0.f, num = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const float e = expf(v[k] - mx); den += e; num += e * (float)k; }
+    d[s] = num / den;
+  }
+  const float ax = (float)(a % w) + 0.5f, ay = (float)(a / w) + 0.5f;
+  const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+  float* yb = y + (long)b * (4 + nc) * A + a_off + a;
+  yb[0] = (x1 + x2) / 2 * stride;
+  yb[(long)A] = (y1 + y2) / 2 * stride;
+  yb[2L * A] = (x2 - x1) * stride;
+  yb[3L * A] = (y2 - y1) * stride;
+  const T* cp = cls + t * ld_cls;
+  for (int c = 0; c < nc; ++c) yb[(long)(4 + c) * A] = sigmoidf_(DT<T>::load1(cp + c));
+}
+
+constexpr int NMS_THREADS = 1024;
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restrict__ y, int nc, int A, int P2, float conf_thres,
+                                                          float iou_thres, int max_det, float max_wh, float gain, float pad_x,
+                                                          float pad_y, float clip_w, float clip_h, float* __restrict__ rows,
+                                                          int32_t* __restrict__ n_rows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(dyn);     // [P2] (score desc, anchor asc)
+  unsigned char* dead = dyn + (size_t)P2 * 8;                                // [P2]
+  __shared__ int sh_n, sh_kept, sh_cur_alive;
+  __shared__ float cur[5];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* yb = y + (long)b * (4 + nc) * A;
+  if (tid == 0) { sh_n = 0; sh_kept = 0; }
+  for (int i = tid; i < P2; i += NMS_THREADS) { keys[i] = ~0ull; dead[i] = 0; }
+  __syncthreads();
+  // candidates: best class score > conf (ops.py:203, :232-233)
+  for (int a = tid; a < A; a += NMS_THREADS) {
+    float best = -INFINITY;
+    for (int c = 0; c < nc; ++c) best = fmaxf(best, yb[(long)(4 + c) * A + a]);
+    if (best > conf_thres) {
+      const int pos = atomicAdd(&sh_n, 1);
+      keys[pos] = ((unsigned long long)(~order_key(best)) << 32) | (unsigned)a;
+    }
+  }
+  __syncthreads();
+  const int n = sh_n;
+  for (int k = 2; k <= P2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P2; i += NMS_THREADS) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long u = keys[i], v = keys[ixj];
+          if ((u > v) == ((i & k) == 0)) { keys[i] = v; keys[ixj] = u; }
+        }
+      }
+      __syncthreads();
+    }
+  auto load_box = [&](int a, float* o) {          // xyxy + class offset (ops.py:206, :262-263), score, class
+    const float cx = yb[a], cy = yb[(long)A + a], w = yb[2L * A + a], h = yb[3L * A + a];
+    float best = -INFINITY; int bc = 0;
+    for (int c = 0; c < nc; ++c) { const float v = yb[(long)(4 + c) * A + a]; if (v > best) { best = v; bc = c; } }
+    o[0] = cx - w / 2; o[1] = cy - h / 2; o[2] = cx + w / 2; o[3] = cy + h / 2; o[4] = best; o[5] = (float)bc;
+  };
+  for (int i = 0; i < n; ++i) {
+    if (tid == 0) {
+      sh_cur_alive = !dead[i] && sh_kept < max_det;
+      if (sh_cur_alive) {
+        float o[6];
+        const int a = (int)(keys[i] & 0xffffffffu);
+        load_box(a, o);
+        const float off = o[5] * max_wh;
+        cur[0] = o[0] + off; cur[1] = o[1] + off; cur[2] = o[2] + off; cur[3] = o[3] + off;
+        cur[4] = (cur[2] - cur[0]) * (cur[3] - cur[1]);
+        float* r = rows + ((long)b * max_det + sh_kept) * 6;
+        float bx0 = (o[0] - pad_x) / gain, by0 = (o[1] - pad_y) / gain, bx1 = (o[2] - pad_x) / gain, by1 = (o[3] - pad_y) / gain;
+        if (clip_w > 0.f) { bx0 = fminf(fmaxf(bx0, 0.f), clip_w); bx1 = fminf(fmaxf(bx1, 0.f), clip_w);
+                            by0 = fminf(fmaxf(by0, 0.f), clip_h); by1 = fminf(fmaxf(by1, 0.f), clip_h); }
+        r[0] = bx0; r[1] = by0; r[2] = bx1; r[3] = by1; r[4] = o[4]; r[5] = o[5];
+        ++sh_kept;
+      }
+    }
+    __syncthreads();
+    if (sh_kept >= max_det && !sh_cur_alive) break;      // uniform: written by lane 0 before the barrier
+    if (sh_cur_alive) {
+      for (int j = i + 1 + tid; j < n; j += NMS_THREADS)
+        if (!dead[j]) {
+          float o[6];
+          load_box((int)(keys[j] & 0xffffffffu), o);
+          const float off = o[5] * max_wh;
+          const float x0 = o[0] + off, y0 = o[1] + off, x1 = o[2] + off, y1 = o[3] + off;
+          const float iw = fmaxf(fminf(cur[2], x1) - fmaxf(cur[0], x0), 0.f), ih = fmaxf(fminf(cur[3], y1) - fmaxf(cur[1], y0), 0.f);
+          const float inter = iw * ih;
+          if (inter / (cur[4] + (x1 - x0) * (y1 - y0) - inter) > iou_thres) dead[j] = 1;
+        }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) n_rows[b] = sh_kept;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, int64_t lds_, int M, int N4, T* __restrict__ dst,
                                                    int64_t ldd) {
@@ -1167,6 +1287,36 @@ extern "C" int moy_fsqm_reset(float* mem, float* conf, int64_t* ids, float* fbox
   if (!mem || !conf || !ids || !fboxes || !low || !pool || !pool_hc || pool_cap < FSQM_SLOTS) return MOY_EINVAL;
   hipLaunchKernelGGL(fsqm_reset_kernel, dim3(nblk(FSQM_SLOTS * FSQM_DIM)), dim3(256), 0, static_cast<hipStream_t>(stream), mem, conf,
                      ids, fboxes, low, pool, pool_cap, pool_hc);
+  return launch_status();
+}
+
+extern "C" int moy_detect_decode(const void* box, int64_t ld_box, const void* cls, int64_t ld_cls, int B, int h, int w, int nc,
+                                 float stride, int a_off, int A, float* y, int dtype, void* stream) {
+  if (!box || !cls || !y || B <= 0 || h <= 0 || w <= 0 || nc <= 0 || a_off < 0 || a_off + h * w > A) return MOY_EINVAL;
+  if (ld_box < 64 || (ld_box % 4) || ld_cls < nc) return MOY_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MOY_DISPATCH_T(dtype, {
+    if (reinterpret_cast<uintptr_t>(box) % (4 * sizeof(T))) return MOY_EINVAL;
+    hipLaunchKernelGGL((detect_decode_kernel<T>), dim3(nblk((long)B * h * w)), dim3(256), 0, st, static_cast<const T*>(box), ld_box,
+                       static_cast<const T*>(cls), ld_cls, B, h, w, nc, stride, a_off, A, y);
+    return launch_status();
+  })
+}
+
+extern "C" int moy_nms(const float* y, int B, int nc, int A, float conf_thres, float iou_thres, int max_det, float max_wh, float gain,
+                       float pad_x, float pad_y, float clip_w, float clip_h, float* rows, int32_t* n_rows, void* stream) {
+  if (!y || !rows || !n_rows || B <= 0 || nc <= 0 || A <= 0 || A > 16384 || max_det <= 0 || !(gain > 0.f)) return MOY_EINVAL;
+  int P2 = 1;
+  while (P2 < A) P2 <<= 1;
+  const size_t lds = (size_t)P2 * 9;
+  static bool attr_set = false;   // the kernel also has a few static __shared__ words: ask for what the largest A needs
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 9) != hipSuccess)
+      return MOY_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NMS_THREADS), lds, static_cast<hipStream_t>(stream), y, nc, A, P2, conf_thres, iou_thres,
+                     max_det, max_wh, gain, pad_x, pad_y, clip_w, clip_h, rows, n_rows);
   return launch_status();
 }
 

@@ -59,7 +59,7 @@ class TrackEngine:
     def __init__(self, arch: TrackArch, state_dict: Dict[str, torch.Tensor], H: int, W: int, batch: int = 1,
                  dtype: torch.dtype = torch.float32, device="cuda", input_format: str = "u8", conf: float = 0.25,
                  score_thresh: float = 0.4, scale_boxes: bool = True, head_only: bool = False,
-                 level_shapes_override=None, side_state: bool = False):
+                 level_shapes_override=None, side_state: bool = False, iou: float = 0.7, max_det: int = 300, orig_hw=None):
         if not torch.cuda.is_available():
             raise L.MoyoloError("TrackEngine needs a HIP device (no CPU path)")
         self.lib = L.lib()
@@ -69,6 +69,7 @@ class TrackEngine:
         self.conf, self.score_thresh = conf, score_thresh
         self.img_wh = (float(W), float(H)) if scale_boxes else (1.0, 1.0)
         self.head_only = head_only
+        self.iou, self.max_det, self.orig_hw = iou, max_det, orig_hw      # Detect head (config C1) only
         self.side_state = side_state     # keep the output-invisible tracker copy + FSQM memory on device
         self.shapes = [tuple(s) for s in level_shapes_override] if level_shapes_override else level_shapes(H, W)
         self.S = sum(h * w for h, w in self.shapes)
@@ -285,6 +286,9 @@ class TrackEngine:
 
             head_src = [(outv[j], hw[j]) for j in (15, 18, 21)]
         self._head_start = len(self._steps)
+        if arch.head_kind == "detect":
+            self._build_detect_head(head_src)
+            return
         # ---------------- head (MYDecoder)
         d = f"model.{nlayers}.decoder"
         hd, nq, nc, S, nl = arch.hd, arch.nq, arch.nc, self.S, arch.nl
@@ -428,6 +432,44 @@ class TrackEngine:
                       f["mem"].data_ptr(), f["conf"].data_ptr(), f["ids"].data_ptr(), f["boxes"].data_ptr(), f["low"].data_ptr(),
                       f["pool"].data_ptr(), f["pool"].numel(), f["pool_hc"].data_ptr(), code)
 
+    def _build_detect_head(self, head_src):
+        """Detect head of config C1 (nn/modules/head.py:27-78) + NMS / scale_boxes
+        (utils/ops.py:148-283, 99-129; models/yolo/detect/predict.py:12-30)."""
+        arch, B, sd, lib, code = self.arch, self.B, self.sd, self.lib, self.code
+        h = f"model.{len(arch.layers)}"
+        nc = arch.nc
+        c2, c3 = max(16, arch.head_ch[0] // 4, 64), max(arch.head_ch[0], min(nc, 100))
+        A = sum(hh * ww for _, (hh, ww) in head_src)
+        self.A = A
+        self.y = torch.zeros(B, 4 + nc, A, device=self.dev)
+        a_off = 0
+        for li, (x, (hh, ww)) in enumerate(head_src):
+            M = B * hh * ww
+            outs = {}
+            for name, cm, cout in (("cv2", c2, 64), ("cv3", c3, nc)):
+                t1, t2 = View(self._buf(M, cm)), View(self._buf(M, cm))
+                self._conv(f"{h}.{name}.{li}.0", x, (hh, ww), arch.head_ch[li], cm, 3, 1, t1)
+                self._conv(f"{h}.{name}.{li}.1", t1, (hh, ww), cm, cm, 3, 1, t2)
+                Wt = self._weight(sd[f"{h}.{name}.{li}.2.weight"].reshape(cout, cm))
+                o = View(self._buf(M, cout))
+                self._gemm(t2, Wt, cout, cm, o, M, shift=self._dev(sd[f"{h}.{name}.{li}.2.bias"]))
+                outs[name] = o
+            stride = float(self.H // hh)
+            self._add(lib.moy_detect_decode, outs["cv2"].ptr, outs["cv2"].ld, outs["cv3"].ptr, outs["cv3"].ld, B, hh, ww, nc,
+                      C.c_float(stride), a_off, A, self.y.data_ptr(), code)
+            a_off += hh * ww
+        self.rows = torch.zeros(B, self.max_det, 6, device=self.dev)
+        self.n_rows = torch.zeros(B, device=self.dev, dtype=torch.int32)
+        gain, padx, pady, cw, ch_ = 1.0, 0.0, 0.0, 0.0, 0.0
+        if self.orig_hw is not None:                     # ops.scale_boxes, utils/ops.py:116-128
+            oh, ow = self.orig_hw
+            gain = min(self.H / oh, self.W / ow)
+            padx, pady = round((self.W - ow * gain) / 2 - 0.1), round((self.H - oh * gain) / 2 - 0.1)
+            cw, ch_ = float(ow), float(oh)
+        self._add(lib.moy_nms, self.y.data_ptr(), B, nc, A, C.c_float(self.conf), C.c_float(self.iou), self.max_det,
+                  C.c_float(7680.0), C.c_float(gain), C.c_float(padx), C.c_float(pady), C.c_float(cw), C.c_float(ch_),
+                  self.rows.data_ptr(), self.n_rows.data_ptr())
+
     def reset_sequence(self):
         """FSQM.reset (fsqm.py:182-190): call at the start of a new video sequence."""
         if self.side_state:
@@ -496,6 +538,8 @@ class TrackEngine:
         return g
 
     def outputs(self):
+        if self.arch.head_kind == "detect":
+            return dict(y=self.y, rows=self.rows, n_rows=self.n_rows)
         B, nq = self.B, self.arch.nq
         return dict(y=self.y, scores=self.scores, obj_idxes=self.obj_idxes, rows=self.rows, track_id=self.track_id,
                     n_rows=self.n_rows, n_ids=self.n_ids, logits=self.logits.view(B, nq, -1),

@@ -102,3 +102,32 @@ class TrackPredictor:
                 results.append(TrackResults(rows[b, :n_rows[b]].copy(), t, self.imgsz,
                                             path=(paths[s + b] if paths else "")))
         return results
+
+
+class DetectionPredictor:
+    """Config C1 plumbing: `DetectionPredictor` of ultralytics/models/yolo/detect/predict.py:10-30 for
+    network-resolution frames: fused preprocess -> YOLOv8 backbone/neck -> Detect decode -> NMS ->
+    scale_boxes to the original image size, all inside one TrackEngine step.
+    Returns per frame a float32 [n, 6] array (x1, y1, x2, y2, conf, cls)."""
+
+    def __init__(self, arch, state_dict, imgsz=(640, 640), conf=0.25, iou=0.7, max_det=300, dtype=torch.float32,
+                 device="cuda", batch=1, orig_hw=None):
+        assert arch.head_kind == "detect"
+        self.batch = batch
+        self.eng = TrackEngine(arch, state_dict, imgsz[0], imgsz[1], batch=batch, dtype=dtype, device=device, conf=conf,
+                               iou=iou, max_det=max_det, orig_hw=orig_hw or imgsz)
+
+    @torch.no_grad()
+    def __call__(self, frames_u8) -> List[np.ndarray]:
+        x = torch.as_tensor(np.stack(frames_u8) if not isinstance(frames_u8, (np.ndarray, torch.Tensor)) else frames_u8)
+        x = x.to(self.eng.dev)
+        res = []
+        for s in range(0, x.shape[0], self.batch):
+            chunk = x[s:s + self.batch]
+            k = chunk.shape[0]
+            if k < self.batch:
+                chunk = torch.cat([chunk, chunk[-1:].expand(self.batch - k, *chunk.shape[1:])], 0)
+            out = self.eng.forward(chunk.contiguous())
+            rows, n = out["rows"].cpu().numpy(), out["n_rows"].cpu().numpy()
+            res += [rows[b, :n[b]].copy() for b in range(k)]
+        return res

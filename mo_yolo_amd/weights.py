@@ -23,6 +23,7 @@ import torch
 from .config import TrackArch, param_shapes
 
 _DATA = os.path.join(os.path.dirname(__file__), "data")
+DETECT_CLS_BIAS = 8.9     # Detect class-logit offset of the C1 fixture (a few % of the anchors above conf 0.25)
 
 
 def _u(rng, shape, a):
@@ -61,9 +62,13 @@ def make_fixture_state_dict(arch: TrackArch, seed: int = 0) -> "OrderedDict[str,
             v = _u(rng, shp, 0.17)
         elif leaf == "running_var":
             v = _ur(rng, shp, 0.8, 1.2)
+        elif k.endswith("dfl.conv.weight"):                   # DFL: fixed arange(16) (block.py:24-26)
+            v = np.arange(16, dtype=np.float32).reshape(shp)
         elif len(shp) == 4:                                   # conv weight: He-uniform
             fan_in = shp[1] * shp[2] * shp[3]
             v = _u(rng, shp, math.sqrt(6.0 / fan_in))
+            if (".cv2." in k or ".cv3." in k) and k.endswith(".2.weight"):
+                v = v * np.float32(20.0)                      # Detect output convs: spread the DFL / class logits
         elif ".bn." in k or ".input_proj." in k or "norm" in k or k.endswith("enc_output.1.weight") \
                 or k.endswith("enc_output.1.bias"):
             v = _ur(rng, shp, 0.8, 1.2) if leaf == "weight" else _u(rng, shp, 0.17)
@@ -83,6 +88,8 @@ def make_fixture_state_dict(arch: TrackArch, seed: int = 0) -> "OrderedDict[str,
             v = _u(rng, shp, s3 / math.sqrt(shp[1]))
             if ("bbox_head" in k and k.endswith("layers.2.weight")):
                 v = v * np.float32(0.05)
+        elif leaf == "bias" and ".cv3." in k:               # Detect class bias: keep most anchors below conf 0.25
+            v = _u(rng, shp, 0.05) - np.float32(DETECT_CLS_BIAS)
         elif leaf == "bias":
             v = _u(rng, shp, 0.05)
             if ("bbox_head" in k and k.endswith("layers.2.bias")):
@@ -93,9 +100,10 @@ def make_fixture_state_dict(arch: TrackArch, seed: int = 0) -> "OrderedDict[str,
     # Masked-token guard: every masked token has the feature
     # LN(enc_output.bias); anti-align that bias with the score direction so the constant
     # masked-token score ranks below the valid tokens and top-k never selects a +inf anchor.
-    d = f"model.{len(arch.layers)}.decoder"
-    w = sd[d + ".enc_score_head.weight"]
-    sd[d + ".enc_output.0.bias"] = (-0.02 * w.mean(0)).contiguous()
+    if arch.head_kind == "track":
+        d = f"model.{len(arch.layers)}.decoder"
+        w = sd[d + ".enc_score_head.weight"]
+        sd[d + ".enc_output.0.bias"] = (-0.02 * w.mean(0)).contiguous()
     return sd
 
 

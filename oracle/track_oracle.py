@@ -453,3 +453,87 @@ def txt_lines(rows, tid, orig_hw, save_conf=False):
         line = (int(tid[j]), int(c), *xywhn) + ((float(cf),) if save_conf else ())
         out.append(("%g " * len(line)).rstrip() % line)
     return out
+
+
+# ----------------------------------------------------------------------------- config C1: YOLOv8n detect
+def detect_head(feats_in, sd, h, nc, strides=(8, 16, 32)):
+    """Detect.forward nn/modules/head.py:48-78 (eval): per level cat(cv2, cv3); DFL (block.py:31-35:
+    softmax over 16 bins . arange); dist2bbox xywh (utils/tal.py:261-270) * stride; sigmoid(cls).
+    Returns y [B, 4+nc, A]."""
+    outs, anchors, strs = [], [], []
+    for li, f in enumerate(feats_in):
+        def branch(name):
+            t = conv_bn_act(f, sd, f"{h}.{name}.{li}.0", 3, 1)
+            t = conv_bn_act(t, sd, f"{h}.{name}.{li}.1", 3, 1)
+            return F.conv2d(t, sd[f"{h}.{name}.{li}.2.weight"], sd[f"{h}.{name}.{li}.2.bias"])
+        x = torch.cat((branch("cv2"), branch("cv3")), 1)
+        B, _, hh, ww = x.shape
+        outs.append(x.view(B, 64 + nc, -1))
+        sy, sx = torch.meshgrid(torch.arange(hh, dtype=f.dtype) + 0.5, torch.arange(ww, dtype=f.dtype) + 0.5, indexing="ij")
+        anchors.append(torch.stack((sx, sy), -1).view(-1, 2))                  # make_anchors, tal.py:246-258
+        strs.append(torch.full((hh * ww, 1), float(strides[li]), dtype=f.dtype))
+    xc = torch.cat(outs, 2)
+    anc, st = torch.cat(anchors).T.unsqueeze(0), torch.cat(strs).T
+    box, cls = xc[:, :64], xc[:, 64:]
+    B, _, A = box.shape
+    dist = (box.view(B, 4, 16, A).softmax(2) * torch.arange(16, dtype=box.dtype).view(1, 1, 16, 1)).sum(2)
+    lt, rb = dist[:, :2], dist[:, 2:]
+    x1y1, x2y2 = anc - lt, anc + rb
+    dbox = torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * st
+    return torch.cat((dbox, cls.sigmoid()), 1)
+
+
+def detect_forward(x, sd, arch):
+    """DetectionModel eval forward for network-resolution input (tasks.py:34-47, 223-296)."""
+    return detect_head(backbone_neck(x, sd, arch), sd, f"model.{len(arch.layers)}", arch.nc)
+
+
+def nms_greedy(boxes, scores, iou_thres):
+    """torchvision.ops.nms semantics: visit boxes by descending score, drop those whose IoU with a
+    kept box exceeds the threshold; returns kept indices in score order."""
+    order = torch.argsort(scores, descending=True, stable=True)
+    b = boxes[order]
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    dead = torch.zeros(len(b), dtype=torch.bool)
+    keep = []
+    for i in range(len(b)):
+        if dead[i]:
+            continue
+        keep.append(int(order[i]))
+        xx1 = torch.maximum(b[i, 0], b[i + 1:, 0]); yy1 = torch.maximum(b[i, 1], b[i + 1:, 1])
+        xx2 = torch.minimum(b[i, 2], b[i + 1:, 2]); yy2 = torch.minimum(b[i, 3], b[i + 1:, 3])
+        inter = (xx2 - xx1).clamp(min=0) * (yy2 - yy1).clamp(min=0)
+        dead[i + 1:] |= inter / (area[i] + area[i + 1:] - inter) > iou_thres
+    return torch.tensor(keep, dtype=torch.long)
+
+
+def non_max_suppression(y, conf_thres=0.25, iou_thres=0.7, max_det=300, max_wh=7680):
+    """ops.non_max_suppression utils/ops.py:148-283, single-label / class-aware path as called by
+    DetectionPredictor.postprocess (models/yolo/detect/predict.py:14-19).  y [B, 4+nc, A] -> list of [n, 6]."""
+    out = []
+    for p in y.transpose(-1, -2):
+        cand = p[:, 4:].amax(1) > conf_thres
+        p = p[cand]
+        if not p.shape[0]:
+            out.append(torch.zeros((0, 6)))
+            continue
+        box = xywh2xyxy(p[:, :4])
+        conf, j = p[:, 4:].max(1, keepdim=True)
+        x = torch.cat((box, conf, j.float()), 1)[conf.view(-1) > conf_thres]
+        c = x[:, 5:6] * max_wh
+        keep = nms_greedy(x[:, :4] + c, x[:, 4], iou_thres)[:max_det]
+        out.append(x[keep])
+    return out
+
+
+def scale_boxes(img1_hw, boxes, img0_hw):
+    """ops.scale_boxes utils/ops.py:99-129 + clip_boxes :285-298 (letterbox-aware)."""
+    gain = min(img1_hw[0] / img0_hw[0], img1_hw[1] / img0_hw[1])
+    pad = (round((img1_hw[1] - img0_hw[1] * gain) / 2 - 0.1), round((img1_hw[0] - img0_hw[0] * gain) / 2 - 0.1))
+    b = boxes.clone()
+    b[:, [0, 2]] -= pad[0]
+    b[:, [1, 3]] -= pad[1]
+    b[:, :4] /= gain
+    b[:, 0].clamp_(0, img0_hw[1]); b[:, 1].clamp_(0, img0_hw[0])
+    b[:, 2].clamp_(0, img0_hw[1]); b[:, 3].clamp_(0, img0_hw[0])
+    return b

@@ -306,6 +306,66 @@ def predictor_rows(m, seq, cfg):
     return out
 
 
+def _pure_torch_nms(boxes, scores, iou_threshold):
+    """Stand-in for torchvision.ops.nms (absent in the build container): the published
+    algorithm -- greedy by descending score, IoU > threshold suppresses."""
+    order = torch.argsort(scores, descending=True, stable=True)
+    keep, dead = [], torch.zeros(len(order), dtype=torch.bool)
+    b = boxes[order]
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    for i in range(len(b)):
+        if dead[i]:
+            continue
+        keep.append(order[i])
+        lt = torch.maximum(b[i, :2], b[i + 1:, :2]); rb = torch.minimum(b[i, 2:], b[i + 1:, 2:])
+        wh = (rb - lt).clamp(min=0)
+        inter = wh[:, 0] * wh[:, 1]
+        dead[i + 1:] |= inter / (area[i] + area[i + 1:] - inter) > iou_threshold
+    return torch.stack(keep) if keep else torch.zeros(0, dtype=torch.long)
+
+
+def dump_c1():
+    """Config C1: YOLOv8n (yolov8n.yaml scale n) detect predict, 640x640 -> y [1,84,8400] + post-NMS rows
+    through DetectionPredictor.postprocess."""
+    ref_shim.install()
+    from types import SimpleNamespace
+    from ultralytics.nn.tasks import DetectionModel, yaml_model_load
+    from ultralytics.models.yolo.detect.predict import DetectionPredictor
+    import ultralytics.utils.ops as uops
+    uops.torchvision.ops.nms = _pure_torch_nms      # patch AFTER ultralytics imported its torchvision stub modules
+    uops.time.time = (lambda t0=[0.0]: 0.0)          # the pure-python NMS must not trip the wall-clock limit (ops.py:277-279)
+    from mo_yolo_amd.config import build_detect_arch
+    arch = build_detect_arch()
+    sd = make_fixture_state_dict(arch, 5)
+    cfg = yaml_model_load(os.path.join(ref_shim.REF_ROOT, "ultralytics/cfg/models/v8/yolov8n.yaml"))
+    m = DetectionModel(cfg, ch=3, nc=80, verbose=False).eval()
+    m.load_state_dict(sd, strict=True)
+    seq = SyntheticSequence(0, 640, 640, "mot17")
+    out = {"weights_sha256": np.array(state_dict_digest(sd))}
+    ys = []
+    for t in range(2):
+        fr = seq.frames(t, 1)
+        x = to_network_input(fr)
+        with torch.no_grad():
+            y, feats = m(x)
+        ys.append(y[0].numpy())
+        p = DetectionPredictor.__new__(DetectionPredictor)
+        p.args = SimpleNamespace(conf=0.25, iou=0.7, agnostic_nms=False, max_det=300, classes=None)
+        p.model = SimpleNamespace(names={i: str(i) for i in range(80)})
+        p.batch = ["f.jpg"]
+        orig = np.zeros((480, 600, 3), np.uint8)         # a different original size exercises scale_boxes (letterbox-aware)
+        r_same = p.postprocess(y.clone(), x, [fr[0]])[0].boxes.data.numpy()
+        r_other = p.postprocess(y.clone(), x, [orig])[0].boxes.data.numpy()
+        out[f"post.{t}.rows"] = r_same
+        out[f"post.{t}.rows_480x600"] = r_other
+        print(f"[c1] frame {t}: candidates {(y[0, 4:].amax(0) > 0.25).sum().item()} -> {len(r_same)} rows")
+    out["y_sum"] = np.array([float(np.float64(v).sum()) for v in ys])
+    idx = sample_idx(ys[0].size, 4096)
+    out["y0.idx"], out["y0.val"] = idx, ys[0].reshape(-1)[idx]
+    out["y0.shape"] = np.array(ys[0].shape)
+    np.savez_compressed(os.path.join(HERE, "c1.npz"), **out)
+
+
 def dump_msda():
     """KATs in the style of MOTR/models/ops/test.py:21-30 on the op actually on the path."""
     ref_shim.install()
@@ -404,7 +464,7 @@ def dump_hota():
 
 
 def main():
-    which = sys.argv[1:] or ["tiny", "tiny3", "c2", "c4", "msda", "qim", "hota"]
+    which = sys.argv[1:] or ["tiny", "tiny3", "c2", "c4", "c1", "msda", "qim", "hota"]
     cal = {}
     for name in which:
         if name in CONFIGS:
@@ -412,6 +472,8 @@ def main():
             c = calibrate(cfg)
             save_calib({f"{name}/{k}": v for k, v in c.items()})
             dump_config(cfg, full=name.startswith("tiny"))
+    if "c1" in which:
+        dump_c1()
     if "msda" in which:
         dump_msda()
     if "qim" in which:

@@ -300,3 +300,34 @@ def test_engine_fp32_c4_vs_reference_golden():
     assert np.allclose(out["y"][0].cpu().numpy(), g["y"][0][perm], atol=1e-3)
     ids_expected = O.assign_ids(torch.from_numpy(g["scores"][0][perm])).numpy()
     assert np.array_equal(out["obj_idxes"][0].cpu().numpy(), ids_expected)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_c1_yolov8n_detect_engine(dt):
+    """Config C1 on the device: same backbone kernels + Detect decode + NMS + scale_boxes, vs the
+    reference rows (fp32: exact row set/order, boxes 1e-2 px) and vs the oracle (bf16: stated bar)."""
+    from mo_yolo_amd.config import build_detect_arch
+    from mo_yolo_amd.synth import SyntheticSequence
+    from mo_yolo_amd.weights import make_fixture_state_dict
+    g = golden("c1")
+    arch = build_detect_arch()
+    sd = make_fixture_state_dict(arch, 5)
+    seq = SyntheticSequence(0, 640, 640, "mot17")
+    fr = torch.from_numpy(seq.frames(0, 2)).to(DEV)
+    for key, hw in (("rows", (640, 640)), ("rows_480x600", (480, 600))):
+        eng = TrackEngine(arch, sd, 640, 640, batch=2, dtype=dt, conf=0.25, iou=0.7, max_det=300, orig_hw=hw)
+        out = eng.forward(fr)
+        torch.cuda.synchronize()
+        assert tuple(out["y"].shape) == (2, 84, 8400)
+        if dt == torch.float32:
+            assert np.allclose(out["y"][0].cpu().numpy().reshape(-1)[g["y0.idx"]], g["y0.val"], atol=2e-3, rtol=1e-4)
+        for t in range(2):
+            want = g[f"post.{t}.{key}"]
+            n = int(out["n_rows"][t])
+            got = out["rows"][t, :n].cpu().numpy()
+            if dt == torch.float32:
+                assert n == len(want)
+                assert np.array_equal(got[:, 5], want[:, 5])
+                assert np.allclose(got[:, :5], want[:, :5], atol=2e-2, rtol=1e-4)
+            else:
+                assert abs(n - len(want)) <= max(3, len(want) // 10)

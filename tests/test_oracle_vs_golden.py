@@ -138,3 +138,28 @@ def test_hota_restatement_vs_reference_evaluator():
                             [g[f"{case}.sim.{t}"] for t in range(T)], int(g[f"{case}.num_gt_ids"]), int(g[f"{case}.num_tracker_ids"]))
         for k in ("HOTA", "DetA", "AssA", "DetRe", "DetPr", "AssRe", "AssPr", "LocA", "OWTA", "HOTA_TP", "HOTA_FN", "HOTA_FP"):
             assert np.allclose(r[k], g[f"{case}.res.{k}"], atol=1e-7), (case, k)
+
+
+def test_c1_yolov8n_detect_vs_reference():
+    """Config C1 (YOLOv8n detect, 640x640): Detect decode, NMS and scale_boxes restatements vs the
+    reference DetectionModel + DetectionPredictor.postprocess outputs (tests/golden/c1.npz)."""
+    from mo_yolo_amd.config import build_detect_arch
+    from mo_yolo_amd.synth import SyntheticSequence, to_network_input
+    from mo_yolo_amd.weights import make_fixture_state_dict, state_dict_digest
+    g = golden("c1")
+    arch = build_detect_arch()
+    sd = make_fixture_state_dict(arch, 5)
+    assert state_dict_digest(sd) == str(g["weights_sha256"])
+    seq = SyntheticSequence(0, 640, 640, "mot17")
+    for t in range(2):
+        with torch.no_grad():
+            y = O.detect_forward(to_network_input(seq.frames(t, 1)), sd, arch)
+        assert tuple(y.shape) == (1, 84, 8400)
+        if t == 0:
+            assert np.allclose(y[0].numpy().reshape(-1)[g["y0.idx"]], g["y0.val"], atol=5e-4, rtol=1e-5)
+        rows = O.non_max_suppression(y, 0.25, 0.7, 300)[0]
+        for key, hw in ((f"post.{t}.rows", (640, 640)), (f"post.{t}.rows_480x600", (480, 600))):
+            r = rows.clone()
+            r[:, :4] = O.scale_boxes((640, 640), r[:, :4], hw)
+            assert r.shape == g[key].shape
+            assert np.allclose(r.numpy(), g[key], atol=2e-3, rtol=1e-5)
