@@ -615,17 +615,11 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const T* __restrict__ v
   const f32x4 rb = *reinterpret_cast<const f32x4*>(ref + (long)row * 4);
   const T* vb = value + (long)b * S * ldv + m * 32 + sub * 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  // Per level: first all 16 (tap offset, weight) pairs, then 16 branch-free loads back to back
-  // (out-of-range taps read a clamped address with weight 0), then the accumulation.  The first
-  // version guarded every load with its own bounds branch; hipcc then waited for each tap before
-  // issuing the next one and a query took ~48 dependent L2 round trips.
 #pragma unroll
   for (int l = 0; l < 4; ++l)
     if (l < L) {
       const int H = lv.H[l], W = lv.W[l];
       const T* vl = vb + (long)lv.start[l] * ldv;
-      int off[16];
-      float wgt[16];
 #pragma unroll
       for (int pnt = 0; pnt < 4; ++pnt) {
         const int i = l * 4 + pnt;
@@ -636,21 +630,15 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const T* __restrict__ v
         const float aw = logit[i] * inv_den;
         const float xf = floorf(x), yf = floorf(y);
         const float fx = x - xf, fy = y - yf;
-        const int x0 = (int)fmaxf(fminf(xf, 1e6f), -1e6f), y0 = (int)fmaxf(fminf(yf, 1e6f), -1e6f);
+        const int x0 = (int)xf, y0 = (int)yf;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
-          const bool ok = (unsigned)xi < (unsigned)W && (unsigned)yi < (unsigned)H;
-          const float wv = ((t & 1) ? fx : 1.f - fx) * ((t >> 1) ? fy : 1.f - fy) * aw;
-          wgt[pnt * 4 + t] = ok ? wv : 0.f;
-          off[pnt * 4 + t] = ok ? (yi * W + xi) : 0;
+          const float wgt = ((t & 1) ? fx : 1.f - fx) * ((t >> 1) ? fy : 1.f - fy) * aw;
+          if ((unsigned)xi < (unsigned)W && (unsigned)yi < (unsigned)H)
+            acc += DT<T>::load4(vl + ((long)yi * W + xi) * ldv) * wgt;
         }
       }
-      f32x4 v[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] = DT<T>::load4(vl + (long)off[k] * ldv);
-#pragma unroll
-      for (int k = 0; k < 16; ++k) acc += v[k] * wgt[k];
     }
   DT<T>::store4(out + (long)row * ldo + m * 32 + sub * 4, acc);
 }
