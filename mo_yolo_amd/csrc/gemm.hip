@@ -1,20 +1,20 @@
 // Fused implicit-GEMM for gfx950: 1x1 / 3x3 convolutions and linears with BN/bias, activation,
 // residual and LayerNorm epilogues (see moy_gemm in include/moyolo.h).
 //
-// Structure (wave64, 256 threads = 4 waves):
+// Structure (wave64; 256 or 512 threads = 4 or 8 waves per block):
 //   * block tile BM x BN, k advanced PANELS panels of 64 bytes per stage
 //     (bf16: 32 k per panel -> one v_mfma_f32_16x16x32_bf16 per 16x16 sub-tile and panel;
 //      f32 : 16 k per panel -> four v_mfma_f32_16x16x4_f32, the exact-fp32 matrix op);
-//   * global -> registers (16-byte chunks, prefetched one stage ahead) -> LDS, two LDS stages,
+//   * global -> registers (buffer loads, 16-byte chunks, 8 rows x 128 B per wave instruction, prefetched
+//     one stage ahead) -> LDS, two LDS stages,
 //     one barrier per stage; LDS rows are 64 B with the 16-B column XOR-swizzled by the row group
 //     so the ds_read_b128 fragment reads are bank-conflict free;
 //   * MFMA operands are swapped (weights as A, activations as B) so each lane ends up with four
 //     consecutive output channels of one pixel -> 16-byte LDS stores of the accumulator tile;
-//   * epilogue: accumulators -> LDS (fp32 tile) -> row-wise pass (scale/shift, act, residual,
-//     optional LayerNorm with wave shuffles) -> coalesced vector stores.
+//   * epilogue: scale/shift/activation on the accumulators -> LDS (fp32 tile) -> fully unrolled
+//     row-wise pass (residual, optional LayerNorm / narrow head with wave shuffles) -> 16-byte stores.
 //   * blockIdx is remapped so that the column tiles of one row tile run on the same XCD (they
 //     re-read the same activation rows from that XCD's L2).
-#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -453,384 +453,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
   gemm_epilogue<T, BM, BN, LN, NTHR>(p, Cs, m0, n0, tid);
 }
 
-// =================================================================================================
-// LDS-DMA variant of the main loop (global_load_lds_dwordx4, no staging registers):
-//   * NST-deep ring of LDS stages; the DMA for stage kt+NST-1 is issued while stage kt is computed,
-//     so NST-1 stages (tens of KB per CU) are in flight continuously -- these GEMMs have K of only
-//     64..2304 and stream M rows once, so bytes in flight, not MFMA rate, set their speed;
-//   * a wave instruction writes 1 KiB of LDS linearly (16 rows x 64 B of one panel); the XOR
-//     swizzle is applied on the SOURCE address (lane i fetches the chunk that belongs at its linear
-//     slot), and the ds_read side applies the same involution;
-//   * out-of-image taps, M / N tails, masked rows and K padding are fetched from a 16-byte zero page;
-//   * one raw s_barrier per stage with a counted s_waitcnt vmcnt (never __syncthreads in the loop,
-//     which would drain the DMA queue).
-// The epilogue is shared with the register-staged kernel.
-__device__ __attribute__((aligned(16))) uint32_t g_zero_page[4] = {0u, 0u, 0u, 0u};
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-template <typename T, int BM, int BN, int NST>
-constexpr int gemm_dma_lds_bytes() {
-  constexpr int stage = NST * (BM + BN) * PANELS * 64;
-  constexpr int epi = BM * (BN + 4) * 4;
-  return stage > epi ? stage : epi;
-}
-
-template <typename T, int BM, int BN, int WGM, int WGN, bool LN, int KS, int NST>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_dma_kernel(const GemmParams p) {
-  constexpr int NW = WGM * WGN, NTHR = 64 * NW;
-  constexpr int KPB = DT<T>::KPB, BKP = 4 * KPB, BK = BKP * PANELS;
-  constexpr int TM = BM / WGM, TN = BN / WGN, MT = TM / 16, NT = TN / 16;
-  constexpr int A_BYTES = BM * PANELS * 64, B_BYTES = BN * PANELS * 64, ST_BYTES = A_BYTES + B_BYTES;
-  constexpr int RGA = BM / 16, RGB = BN / 16;               // 16-row groups per panel
-  constexpr int PA = RGA * PANELS, PB = RGB * PANELS;       // 1-KiB pieces per stage
-  constexpr int PPA = (PA + NW - 1) / NW, PPB = (PB + NW - 1) / NW;   // pieces per wave
-  constexpr int NPW = PPA + PPB;                            // DMA instructions per wave and stage
-  static_assert(PA % NW == 0 && PB % NW == 0, "pieces must divide over the waves");
-  static_assert(!LN || BN == 256, "LayerNorm epilogue needs the whole row in one tile");
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int wm = wave / WGN, wn = wave % WGN;
-
-  int bid = blockIdx.x;
-  {
-    const int nb = p.nblocks, qd = nb >> 3, rm = nb & 7, x = bid & 7;
-    bid = (x < rm ? x * (qd + 1) : rm * (qd + 1) + (x - rm) * qd) + (bid >> 3);
-  }
-  const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const T* __restrict__ Ag = static_cast<const T*>(p.A);
-  const T* __restrict__ Wg = static_cast<const T*>(p.W);
-  const T* zero = reinterpret_cast<const T*>(g_zero_page);
-
-  // ---- per-lane, per-piece source coordinates (loop invariant)
-  const int lrow = lane >> 2, lcol = lane & 3;
-  int64_t a_off[PPA];
-  int iy0[PPA], ix0[PPA], a_q[PPA];
-  bool a_ok[PPA];
-#pragma unroll
-  for (int j = 0; j < PPA; ++j) {
-    const int pc = wave + NW * j, rg = pc % RGA;
-    const int row = rg * 16 + lrow, m = m0 + row;
-    a_q[j] = swz(row, lcol);                 // chunk that lives at this lane's linear LDS slot
-    a_ok[j] = m < p.M;
-    a_off[j] = 0; iy0[j] = ix0[j] = 0;
-    if (a_ok[j]) {
-      if (KS == 1) {
-        if (p.a_mask && p.a_mask[m % p.mask_period] == 0) a_ok[j] = false;
-        const int64_t rowi = p.a_rows ? (int64_t)p.a_rows[m] : (int64_t)m;
-        a_off[j] = rowi * p.lda;
-      } else {
-        const int hw = p.Hout * p.Wout;
-        const int b = m / hw, rem = m - b * hw;
-        const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-        iy0[j] = oy * p.stride - 1; ix0[j] = ox * p.stride - 1;
-        a_off[j] = (int64_t)b * p.Hin * p.Win * p.lda;
-      }
-    }
-  }
-  int64_t b_off[PPB];
-  int b_q[PPB];
-  bool b_ok[PPB];
-#pragma unroll
-  for (int j = 0; j < PPB; ++j) {
-    const int pc = wave + NW * j, rg = pc % RGB;
-    const int row = rg * 16 + lrow, n = n0 + row;
-    b_q[j] = swz(row, lcol);
-    b_ok[j] = n < p.N;
-    b_off[j] = (int64_t)n * p.Kpad;
-  }
-
-  auto issue_stage = [&](int kt, int buf) {
-    unsigned char* As = smem + buf * ST_BYTES;
-    unsigned char* Bs = As + A_BYTES;
-#pragma unroll
-    for (int j = 0; j < PPA; ++j) {
-      const int pc = wave + NW * j, pn = pc / RGA, rg = pc % RGA;
-      const int kc = kt * BK + pn * BKP + a_q[j] * KPB;
-      const T* src = zero;
-      if (KS == 1) {
-        if (a_ok[j] && kc < p.K) src = Ag + a_off[j] + kc;
-      } else {
-        const int tap = (int)__umulhi((unsigned)kc, p.cin_magic), c = kc - tap * p.Cin;   // kc / Cin, kc % Cin (any Cin)
-        const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
-        const int iy = iy0[j] + ky, ix = ix0[j] + kx;
-        if (a_ok[j] && tap < 9 && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win)
-          src = Ag + a_off[j] + ((int64_t)iy * p.Win + ix) * p.lda + c;
-      }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(As + (pn * BM + rg * 16) * 64), 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < PPB; ++j) {
-      const int pc = wave + NW * j, pn = pc / RGB, rg = pc % RGB;
-      const int kc = kt * BK + pn * BKP + b_q[j] * KPB;
-      const T* src = b_ok[j] ? Wg + b_off[j] + kc : zero;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(Bs + (pn * BN + rg * 16) * 64), 16, 0, 0);
-    }
-  };
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = p.Kpad / BK;
-  // prologue: NST-1 stages in flight
-#pragma unroll
-  for (int s = 0; s < NST - 1; ++s)
-    if (s < nk) issue_stage(s, s);
-  int buf = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // stage kt must have landed; the (up to NST-2) younger stages stay in flight
-    const int younger = min(NST - 2, nk - 1 - kt);
-    if (NST >= 4 && younger == 2) wait_vmcnt<2 * NPW>();
-    else if (NST >= 3 && younger == 1) wait_vmcnt<NPW>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (kt + NST - 1 < nk) {
-      int nb = buf + NST - 1;
-      if (nb >= NST) nb -= NST;
-      issue_stage(kt + NST - 1, nb);
-    }
-    const unsigned char* As = smem + buf * ST_BYTES;
-    const unsigned char* Bs = As + A_BYTES;
-#pragma unroll
-    for (int pn = 0; pn < PANELS; ++pn) {
-      u32x4 af[MT], wf[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int row = wm * TM + i * 16 + r;
-        af[i] = *reinterpret_cast<const u32x4*>(As + (pn * BM + row) * 64 + swz(row, q) * 16);
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int row = wn * TN + j * 16 + r;
-        wf[j] = *reinterpret_cast<const u32x4*>(Bs + (pn * BN + row) * 64 + swz(row, q) * 16);
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) mma_panel<T>(acc[i][j], wf[j], af[i]);
-    }
-    if (++buf == NST) buf = 0;
-  }
-  __syncthreads();   // all waves done with the ring before it is reused as the fp32 output tile
-
-  float* Cs = reinterpret_cast<float*>(smem);
-  stage_acc<BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q);
-  __syncthreads();
-  if constexpr (!LN && !std::is_same<T, float>::value) {
-    if (p.wide_store) { gemm_epilogue_bf16x8<T, BM, BN, NTHR>(p, Cs, m0, n0, tid); return; }
-  }
-  gemm_epilogue<T, BM, BN, LN, NTHR>(p, Cs, m0, n0, tid);
-}
-
-template <typename T, int BM, int BN, int WGM, int WGN, bool LN, int KS, int NST>
-static int launch_dma(GemmParams& p, hipStream_t st) {
-  const int tiles_m = (p.M + BM - 1) / BM;
-  p.tiles_n = (p.N + BN - 1) / BN;
-  p.nblocks = tiles_m * p.tiles_n;
-  constexpr int lds = gemm_dma_lds_bytes<T, BM, BN, NST>();
-  static_assert(lds <= 160 * 1024, "LDS");
-  auto kern = gemm_dma_kernel<T, BM, BN, WGM, WGN, LN, KS, NST>;
-  static bool attr_set = false;
-  if (lds > 65536 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return MOY_ELAUNCH;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(64 * WGM * WGN), lds, st, p);
-  return launch_status();
-}
-
-template <typename T, int KS>
-static int dispatch_dma(GemmParams& p, bool ln, hipStream_t st) {
-  if (ln) return launch_dma<T, 64, 256, 1, 4, true, KS, 3>(p, st);
-  const long big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  if (p.N > 64) {
-    if (big >= 384) return launch_dma<T, 128, 128, 2, 2, false, KS, 3>(p, st);
-    return launch_dma<T, 64, 128, 2, 2, false, KS, 3>(p, st);
-  }
-  const long mid = (long)((p.M + 127) / 128);
-  if (mid >= 384) return launch_dma<T, 128, 64, 2, 2, false, KS, 3>(p, st);
-  return launch_dma<T, 64, 64, 2, 2, false, KS, 3>(p, st);
-}
-
-
-// =================================================================================================
-// Streaming GEMM for 1x1 convs / linears (ksize 1, no LayerNorm) whose weight tile fits in LDS:
-//   * a block owns BN output columns; its [BN, Kpad] weight tile is loaded into LDS ONCE and stays
-//     there while the block walks over row tiles (persistent along M) -> no weight re-staging;
-//   * activations never touch LDS: each lane loads its MFMA operand chunks (16 B) straight from
-//     global memory, a whole row tile (all of K) per wave is in flight at once, and the NEXT row
-//     tile is prefetched into a second register set while the current one is multiplied;
-//   * waves are independent after the one barrier that publishes the weight tile: no barrier in
-//     the main loop;
-//   * epilogue straight from the accumulators (each lane owns 4 consecutive output channels of a
-//     row): scale/shift, activation, residual, 8/16-byte stores.
-// These GEMMs stream M rows once against a small weight matrix; the design keeps tens of KB per
-// CU continuously in flight instead of alternating load / LDS-write / barrier / compute phases.
-template <typename T, int BN, int MT, int NPMAX>
-__global__ __launch_bounds__(256) void gemm_stream_kernel(const GemmParams p, int row_groups) {
-  constexpr int KPB = DT<T>::KPB, BKP = 4 * KPB;
-  constexpr int NT = BN / 16;
-  constexpr int ROWS_W = MT * 16, ROWS_B = 4 * ROWS_W;      // rows per wave / per block iteration
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int np = p.Kpad / BKP;
-
-  int bid = blockIdx.x;
-  {
-    const int nb = p.nblocks, qd = nb >> 3, rm = nb & 7, x = bid & 7;
-    bid = (x < rm ? x * (qd + 1) : rm * (qd + 1) + (x - rm) * qd) + (bid >> 3);
-  }
-  const int tile_n = bid % p.tiles_n, rg = bid / p.tiles_n;
-  const int n0 = tile_n * BN;
-
-  const T* __restrict__ Ag = static_cast<const T*>(p.A);
-  const T* __restrict__ A2g = static_cast<const T*>(p.A2);
-  const T* __restrict__ Wg = static_cast<const T*>(p.W);
-  const T* __restrict__ Rg = static_cast<const T*>(p.R);
-
-  // ---- weight tile -> LDS, [panel][BN][64 B], 16-B columns swizzled
-  for (int c = tid; c < np * BN * 4; c += 256) {
-    const int pn = c / (BN * 4), rem = c - pn * BN * 4, row = rem >> 2, cq = rem & 3;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (n0 + row < p.N) v = *reinterpret_cast<const u32x4*>(Wg + (int64_t)(n0 + row) * p.Kpad + pn * BKP + cq * KPB);
-    *reinterpret_cast<u32x4*>(smem + (pn * BN + row) * 64 + swz(row, cq) * 16) = v;
-  }
-  __syncthreads();
-
-  const int n_row_tiles = (p.M + ROWS_B - 1) / ROWS_B;
-  u32x4 areg[2][NPMAX][MT];
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
-  auto load_tile = [&](int rt, auto set_c) {
-    constexpr int SET = decltype(set_c)::value;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int m = rt * ROWS_B + wave * ROWS_W + i * 16 + r;
-      bool ok = m < p.M;
-      if (ok && p.a_mask && p.a_mask[m % p.mask_period] == 0) ok = false;
-      const int64_t off = ok ? (p.a_rows ? (int64_t)p.a_rows[m] : (int64_t)m) * p.lda + q * KPB : 0;
-#pragma unroll
-      for (int pn = 0; pn < NPMAX; ++pn) {
-        u32x4 v = zero4;
-        if (pn < np && ok && pn * BKP + q * KPB < p.K) {
-          v = *reinterpret_cast<const u32x4*>(Ag + off + pn * BKP);
-          if (A2g) v = add_chunks<T>(v, *reinterpret_cast<const u32x4*>(A2g + off + pn * BKP));
-        }
-        areg[SET][pn][i] = v;
-      }
-    }
-  };
-
-  auto compute_tile = [&](int rt, auto set_c) {
-    constexpr int SET = decltype(set_c)::value;
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int pn = 0; pn < NPMAX; ++pn)
-      if (pn < np) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int row = j * 16 + r;
-          const u32x4 wf = *reinterpret_cast<const u32x4*>(smem + (pn * BN + row) * 64 + swz(row, q) * 16);
-#pragma unroll
-          for (int i = 0; i < MT; ++i) mma_panel<T>(acc[i][j], wf, areg[SET][pn][i]);
-        }
-      }
-    // epilogue from registers: lane owns channels n .. n+3 of row m
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + j * 16 + q * 4;
-      if (n < p.N) {
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int m = rt * ROWS_B + wave * ROWS_W + i * 16 + r;
-          if (m < p.M) {
-            f32x4 v = acc[i][j] * sc + sh;
-            v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
-            v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
-            if (Rg) v += DT<T>::load4(Rg + (int64_t)m * p.ldr + n);
-            const int64_t mo = p.c_rpb ? (int64_t)(m / p.c_rpb) * p.c_bstride + (m % p.c_rpb) : (int64_t)m;
-            if (p.out_f32)
-              *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + mo * p.ldc + n) = v;
-            else
-              DT<T>::store4(static_cast<T*>(p.C) + mo * p.ldc + n, v);
-          }
-        }
-      }
-    }
-  };
-
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, 1>;
-  int rt = rg;
-  if (rt < n_row_tiles) load_tile(rt, S0{});
-  while (rt < n_row_tiles) {
-    const int rt1 = rt + row_groups;
-    if (rt1 < n_row_tiles) load_tile(rt1, S1{});
-    compute_tile(rt, S0{});
-    if (rt1 >= n_row_tiles) break;
-    const int rt2 = rt1 + row_groups;
-    if (rt2 < n_row_tiles) load_tile(rt2, S0{});
-    compute_tile(rt1, S1{});
-    rt = rt2;
-  }
-}
-
-template <typename T, int BN, int MT, int NPMAX>
-static int launch_stream(GemmParams& p, hipStream_t st) {
-  constexpr int BKP = 4 * DT<T>::KPB;
-  const int np = p.Kpad / BKP;
-  const int lds = np * BN * 64;
-  p.tiles_n = (p.N + BN - 1) / BN;
-  const int n_row_tiles = (p.M + 64 * MT - 1) / (64 * MT);
-  // about two resident blocks per CU (512) so that the weight tile is loaded few times and row
-  // tiles are spread evenly
-  int row_groups = (512 + p.tiles_n - 1) / p.tiles_n;
-  if (row_groups > n_row_tiles) row_groups = n_row_tiles;
-  p.nblocks = row_groups * p.tiles_n;
-  auto kern = gemm_stream_kernel<T, BN, MT, NPMAX>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
-      return MOY_ELAUNCH;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds, st, p, row_groups);
-  return launch_status();
-}
-
-// Returns MOY_ENOSYS when the shape does not fit the streaming kernel (caller falls back).
-template <typename T>
-static int dispatch_stream(GemmParams& p, hipStream_t st) {
-  constexpr int BKP = 4 * DT<T>::KPB;
-  const int np = p.Kpad / BKP;
-  if (np <= 4) return launch_stream<T, 128, 2, 4>(p, st);
-  if (np <= 8) return launch_stream<T, 128, 2, 8>(p, st);
-  if (np <= 16) return launch_stream<T, 64, 2, 16>(p, st);
-  return MOY_ENOSYS;
-}
-
 template <typename T, int BM, int BN, int WGM, int WGN, bool LN, int KS>
 static int launch_cfg(GemmParams& p, hipStream_t st) {
   const int tiles_m = (p.M + BM - 1) / BM;
@@ -851,21 +473,17 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
 
 template <typename T, int KS>
 static int dispatch_tile(GemmParams& p, bool ln, hipStream_t st) {
-  static const bool w8 = [] { const char* e = getenv("MOY_GEMM_W8"); return !(e && e[0] == '0'); }();
-  if (ln) return w8 ? launch_cfg<T, 64, 256, 2, 4, true, KS>(p, st) : launch_cfg<T, 64, 256, 1, 4, true, KS>(p, st);
-  // Tile choice: fill >= ~2 blocks per CU when the problem allows it, keep tiles large otherwise.
+  if (ln) return launch_cfg<T, 64, 256, 2, 4, true, KS>(p, st);
+  // Tile choice (measured, tools/bench_gemm.py): 8-wave blocks for the large tiles; fill >= ~2 blocks
+  // per CU when the problem allows it, keep tiles large otherwise.
   const long big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  static const int force = [] { const char* e = getenv("MOY_GEMM_TILE"); return e ? atoi(e) : 0; }();
-  if (force == 1 && !ln) return launch_cfg<T, 128, 64, 4, 2, false, KS>(p, st);
-  if (force == 2 && !ln) return launch_cfg<T, 64, 128, 2, 2, false, KS>(p, st);
-  if (force == 3 && !ln) return launch_cfg<T, 64, 64, 2, 2, false, KS>(p, st);
   if (p.N > 64) {
-    if (big >= 384) return w8 ? launch_cfg<T, 128, 128, 2, 4, false, KS>(p, st) : launch_cfg<T, 128, 128, 2, 2, false, KS>(p, st);
+    if (big >= 384) return launch_cfg<T, 128, 128, 2, 4, false, KS>(p, st);
     return launch_cfg<T, 64, 128, 2, 2, false, KS>(p, st);
   }
   const long mid = (long)((p.M + 127) / 128);
   if (p.N <= 32 && mid >= 384) return launch_cfg<T, 128, 32, 4, 1, false, KS>(p, st);   // no half-empty 64-wide tile
-  if (mid >= 384) return w8 ? launch_cfg<T, 128, 64, 4, 2, false, KS>(p, st) : launch_cfg<T, 128, 64, 2, 2, false, KS>(p, st);
+  if (mid >= 384) return launch_cfg<T, 128, 64, 4, 2, false, KS>(p, st);
   return launch_cfg<T, 64, 64, 2, 2, false, KS>(p, st);
 }
 
@@ -934,24 +552,10 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
     p.cin_magic = (uint32_t)(((1ull << 32) + (unsigned)C - 1) / (unsigned)C);
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // Main-loop variant: register-staged (default) or LDS-DMA ring (MOY_GEMM_IMPL=dma).  Measured on
-  // MI355X (tools/bench_gemm.py, round 1): the DMA ring needs 72-120 KB of LDS per block, i.e. 1-2
-  // blocks per CU, and loses 20-50 % to the register-staged kernel at 2-3 blocks per CU on every
-  // shape of this path -- these short-K GEMMs hide latency with occupancy, not with ring depth.
-  static const bool use_dma = [] { const char* e = getenv("MOY_GEMM_IMPL"); return e && e[0] == 'd'; }();
-  // Streaming variant (weights resident in LDS, activations straight to registers): measured 1.5-2.3x
-  // SLOWER than the LDS-staged kernel (value GEMM 2533 vs 1120 us): its fragment-shaped accesses
-  // (16 rows x 64 B per load, 16 rows x 32 B per store) multiply the request count per byte.  Opt-in only.
-  static const bool use_stream = [] { const char* e = getenv("MOY_GEMM_STREAM"); return e && e[0] == '1'; }();
-  if (use_stream && a->ksize == 1 && !ln) {
-    const int rc = a->dtype == MOY_BF16 ? dispatch_stream<bf16_t>(p, st) : a->dtype == MOY_F16 ? MOY_ENOSYS : dispatch_stream<float>(p, st);
-    if (rc != MOY_ENOSYS) return rc;
-  }
-  if (!a->A2 && use_dma && a->dtype != MOY_F16) {   // the A + A2 prologue add needs the register-staged kernel
-    if (a->dtype == MOY_BF16)
-      return a->ksize == 1 ? dispatch_dma<bf16_t, 1>(p, ln, st) : dispatch_dma<bf16_t, 3>(p, ln, st);
-    return a->ksize == 1 ? dispatch_dma<float, 1>(p, ln, st) : dispatch_dma<float, 3>(p, ln, st);
-  }
+  // Variants that were built and measured slower on every shape of this path (round 1, see DESIGN.md
+  // section 4): an LDS-DMA ring (global_load_lds, 1-2 blocks/CU), weights-resident-in-LDS with
+  // activations straight to registers (16 rows x 64 B request shape), prefetch distance 2, a persistent
+  // tile loop, a direct-from-register epilogue.  They are not kept in the tree.
   if (a->dtype == MOY_BF16)
     return a->ksize == 1 ? dispatch_tile<bf16_t, 1>(p, ln, st) : dispatch_tile<bf16_t, 3>(p, ln, st);
   if (a->dtype == MOY_F16)
