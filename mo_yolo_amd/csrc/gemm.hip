@@ -257,7 +257,10 @@ __device__ __forceinline__ void gemm_epilogue_bf16x8(const GemmParams& p, const 
   }
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, bool LN, int KS>
+// NSET = 2: global loads run two stages ahead of the MFMAs (K of more than two stages); NSET = 1: one
+// stage ahead.  A compile-time choice: with both paths in one kernel hipcc's register allocation and
+// wait placement degrade for both (measured).
+template <typename T, int BM, int BN, int WGM, int WGN, bool LN, int KS, int NSET>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p) {
   constexpr int KPB = DT<T>::KPB;      // elements per 16-B chunk
   constexpr int BKP = 4 * KPB;         // elements per 64-B panel
@@ -360,20 +363,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
     b_voff[j] = n < p.N ? (uint32_t)(((int64_t)(srow + j * RPP) * p.Kpad + kc0) * ESZ) : OOB;
   }
 
-  u32x4 areg[RA2], breg[RB2];
+  u32x4 areg[NSET][RA2], breg[NSET][RB2];
 
-  auto load_stage = [&](int kt) {
+  auto load_stage = [&](int kt, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
     const int soff = kt * BK * ESZ;            // wave-uniform k advance in bytes
     if (KS == 1) {
       const bool ktail = kt * BK + kc0 >= p.K; // only the zero-padded tail of K (Kpad > K)
 #pragma unroll
-      for (int j = 0; j < RA2; ++j) areg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ktail ? OOB : a_voff[j], soff, 0);
+      for (int j = 0; j < RA2; ++j) areg[SET][j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ktail ? OOB : a_voff[j], soff, 0);
       if (A2g) {                                // prologue add (q = k = x + pos): second stream, same offsets
         u32x4 t2[RA2];
 #pragma unroll
         for (int j = 0; j < RA2; ++j) t2[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA2, ktail ? OOB : a_voff[j], soff, 0);
 #pragma unroll
-        for (int j = 0; j < RA2; ++j) areg[j] = add_chunks<T>(areg[j], t2[j]);
+        for (int j = 0; j < RA2; ++j) areg[SET][j] = add_chunks<T>(areg[SET][j], t2[j]);
       }
     } else {
       const int kc = kt * BK + kc0;
@@ -383,25 +387,26 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
 #pragma unroll
       for (int j = 0; j < RA2; ++j) {
         const uint32_t vo = ((a_taps[j] >> tap) & 1u) ? a_voff[j] + delta : OOB;   // tap >= 9 never set
-        areg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0);
+        areg[SET][j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0);
       }
     }
 #pragma unroll
-    for (int j = 0; j < RB2; ++j) breg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, b_voff[j], soff, 0);
+    for (int j = 0; j < RB2; ++j) breg[SET][j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, b_voff[j], soff, 0);
   };
 
-  auto store_stage = [&](int buf) {
+  auto store_stage = [&](int buf, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
     unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
     unsigned char* Bs = As + A_BYTES;
 #pragma unroll
     for (int j = 0; j < RA2; ++j) {
       const int row = srow + j * RPP;
-      *reinterpret_cast<u32x4*>(As + (spn * BM + row) * 64 + swz(row, sq) * 16) = areg[j];
+      *reinterpret_cast<u32x4*>(As + (spn * BM + row) * 64 + swz(row, sq) * 16) = areg[SET][j];
     }
 #pragma unroll
     for (int j = 0; j < RB2; ++j) {
       const int row = srow + j * RPP;
-      *reinterpret_cast<u32x4*>(Bs + (spn * BN + row) * 64 + swz(row, sq) * 16) = breg[j];
+      *reinterpret_cast<u32x4*>(Bs + (spn * BN + row) * 64 + swz(row, sq) * 16) = breg[SET][j];
     }
   };
 
@@ -411,13 +416,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.Kpad / BK;
-  load_stage(0);
-  store_stage(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_stage(kt + 1);
+  auto compute_stage = [&](int buf) {
     const unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
     const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
@@ -438,7 +437,53 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
 #pragma unroll
         for (int j = 0; j < NT; ++j) mma_panel<T>(acc[i][j], wf[j], af[i]);
     }
-    if (kt + 1 < nk) store_stage(buf ^ 1);
+  };
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, NSET - 1>;
+  const int nk = p.Kpad / BK;
+  if constexpr (NSET == 1) {
+    load_stage(0, S0{});
+    store_stage(0, S0{});
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) load_stage(kt + 1, S0{});
+      compute_stage(buf);
+      if (kt + 1 < nk) store_stage(buf ^ 1, S0{});
+      __syncthreads();
+    }
+  } else {
+    load_stage(0, S0{});
+    if (nk > 1) load_stage(1, S1{});
+    store_stage(0, S0{});
+    __syncthreads();
+    int kt = 0;
+    // steady state: straight-line body (no branch around the prefetch), so the compiler's counted
+    // vmcnt leaves the newest stage in flight while the older one is written to LDS
+    for (; kt + 3 < nk; kt += 2) {
+      load_stage(kt + 2, S0{});                      // set 0 was stored to LDS as stage kt
+      compute_stage(0);
+      store_stage(1, S1{});
+      __syncthreads();
+      load_stage(kt + 3, S1{});
+      compute_stage(1);
+      store_stage(0, S0{});
+      __syncthreads();
+    }
+    // tail: 1..3 stages left; LDS buffer 0 holds stage kt, set 1 holds stage kt+1 (if any)
+    if (kt + 2 < nk) load_stage(kt + 2, S0{});
+    compute_stage(0);
+    if (kt + 1 < nk) {
+      store_stage(1, S1{});
+      __syncthreads();
+      compute_stage(1);
+      if (kt + 2 < nk) {
+        store_stage(0, S0{});
+        __syncthreads();
+        compute_stage(0);
+      }
+    }
     __syncthreads();
   }
 
@@ -453,13 +498,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
   gemm_epilogue<T, BM, BN, LN, NTHR>(p, Cs, m0, n0, tid);
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, bool LN, int KS>
-static int launch_cfg(GemmParams& p, hipStream_t st) {
-  const int tiles_m = (p.M + BM - 1) / BM;
-  p.tiles_n = (p.N + BN - 1) / BN;
-  p.nblocks = tiles_m * p.tiles_n;
+template <typename T, int BM, int BN, int WGM, int WGN, bool LN, int KS, int NSET>
+static int launch_inst(GemmParams& p, hipStream_t st) {
   constexpr int lds = gemm_lds_bytes<BM, BN>();
-  auto kern = gemm_kernel<T, BM, BN, WGM, WGN, LN, KS>;
+  auto kern = gemm_kernel<T, BM, BN, WGM, WGN, LN, KS, NSET>;
   static bool attr_set = false;   // > 64 KiB dynamic LDS needs the opt-in once per kernel symbol
   if (lds > 65536 && !attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
@@ -469,6 +511,17 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
   }
   hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(64 * WGM * WGN), lds, st, p);
   return launch_status();
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, bool LN, int KS>
+static int launch_cfg(GemmParams& p, hipStream_t st) {
+  const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  p.nblocks = tiles_m * p.tiles_n;
+  constexpr int bk = 4 * DT<T>::KPB * PANELS;
+  // prefetch distance 2 pays from three k-stages on and for tiles at least 64 columns wide (measured)
+  if (BN >= 64 && p.Kpad / bk > 2) return launch_inst<T, BM, BN, WGM, WGN, LN, KS, 2>(p, st);
+  return launch_inst<T, BM, BN, WGM, WGN, LN, KS, 1>(p, st);
 }
 
 template <typename T, int KS>
