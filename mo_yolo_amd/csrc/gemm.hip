@@ -123,18 +123,30 @@ template <int ACT, int BN, int TM, int TN, int MT, int NT>
 __device__ __forceinline__ void stage_acc_act(const GemmParams& p, f32x4 (&acc)[MT][NT], float* Cs, int n0, int wm, int wn, int r,
                                               int q) {
   constexpr int LDC = BN + 4;
+  // All scale/shift loads are issued back to back from always-valid addresses (clamped column; a
+  // missing vector reads the weight buffer and is replaced by 1 / 0 afterwards).  With the loads
+  // under `if (p.scale)` branches hipcc waited for each one separately: 2*NT dependent L2 round
+  // trips per tile in front of the output pass.
+  const bool has_sc = p.scale != nullptr, has_sh = p.shift != nullptr;
+  const float* scp = has_sc ? p.scale : static_cast<const float*>(p.W);
+  const float* shp = has_sh ? p.shift : static_cast<const float*>(p.W);
+  f32x4 sc[NT], sh[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int nl = wn * TN + j * 16 + q * 4, n = n0 + nl;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (n < p.N) {
-      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-    }
+    const int n = n0 + wn * TN + j * 16 + q * 4;
+    const int ncl = n < p.N ? n : 0;
+    sc[j] = *reinterpret_cast<const f32x4*>(scp + ncl);
+    sh[j] = *reinterpret_cast<const f32x4*>(shp + ncl);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    if (!has_sc) sc[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (!has_sh) sh[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nl = wn * TN + j * 16 + q * 4;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int ml = wm * TM + i * 16 + r;     // D[n_local = q*4 + reg][m_local = r]
-      *reinterpret_cast<f32x4*>(Cs + ml * LDC + nl) = act4<ACT>(acc[i][j] * sc + sh);
+      *reinterpret_cast<f32x4*>(Cs + ml * LDC + nl) = act4<ACT>(acc[i][j] * sc[j] + sh[j]);
     }
   }
 }
