@@ -526,10 +526,13 @@ __global__ __launch_bounds__(256) void mha_kernel(const T* __restrict__ qkv, int
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
+    constexpr float L2E = 1.4426950408889634f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       f32x4 e;
-      e.x = expf(s[kt].x - mx); e.y = expf(s[kt].y - mx); e.z = expf(s[kt].z - mx); e.w = expf(s[kt].w - mx);
+      // v_exp_f32 (1 ulp): libm expf cost ~40 VALU ops per score and dominated the kernel
+      e.x = __builtin_amdgcn_exp2f((s[kt].x - mx) * L2E); e.y = __builtin_amdgcn_exp2f((s[kt].y - mx) * L2E);
+      e.z = __builtin_amdgcn_exp2f((s[kt].z - mx) * L2E); e.w = __builtin_amdgcn_exp2f((s[kt].w - mx) * L2E);
       s[kt] = e;                                  // exp(-inf) = 0 for masked / unused tiles
       sum += (e.x + e.y) + (e.z + e.w);
     }
