@@ -182,13 +182,43 @@ int moy_msda_fused(const void* value, int64_t ldv, int B, int S, const int32_t* 
  * src/cuda/ms_deform_im2col_cuda.cuh:237-299), same argument meaning:
  *   value [N, S, M, D], spatial_shapes int64 [L, 2] (H, W) and level_start_index int64 [L] in
  *   DEVICE memory, sampling_loc [N, Lq, M, L, P, 2], attn_weight [N, Lq, M, L, P] -> out [N, Lq, M*D].
- * The reference dispatches fp32/fp64 only (ms_deform_attn_cuda.cu:64); bf16 is added here. */
+ * The reference dispatches fp32/fp64 (ms_deform_attn_cuda.cu:64); bf16 is added here. */
 int moy_msda_fwd_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                      const float* sampling_loc, const float* attn_weight, int N, int S, int M, int D, int L, int Lq,
                      int P, float* out, void* stream);
 int moy_msda_fwd_bf16(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                       const void* sampling_loc, const void* attn_weight, int N, int S, int M, int D, int L, int Lq,
                       int P, void* out, void* stream);
+int moy_msda_fwd_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                     const double* sampling_loc, const double* attn_weight, int N, int S, int M, int D, int L, int Lq,
+                     int P, double* out, void* stream);
+
+/* MultiScaleDeformableAttention.ms_deform_attn_backward (MOTR/models/ops/src/vision.cpp:13-16,
+ * src/ms_deform_attn.h:42-62, host src/cuda/ms_deform_attn_cuda.cu:81-153, kernels
+ * src/cuda/ms_deform_im2col_cuda.cuh:301-400 + the col2im kernels :403-1326).  Inputs as the forward
+ * plus grad_output [N, Lq, M*D]; outputs grad_value [N, S, M, D] (CLEARED by the callee on `stream`,
+ * then accumulated with hardware atomics: summation order, hence the last ulp, is not deterministic --
+ * as in the reference), grad_sampling_loc [N, Lq, M, L, P, 2] and grad_attn_weight [N, Lq, M, L, P]
+ * (every element written).  A sample contributes only if -1 < h_im < H and -1 < w_im < W (cuh:339).
+ * fp32 / fp64 as the reference (its own test drives fp64 through gradcheck, ops/test.py:66-86);
+ * `im2col_step` has no counterpart here: the op is not chunked. */
+int moy_msda_bwd_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                     const float* sampling_loc, const float* attn_weight, const float* grad_output, int N, int S,
+                     int M, int D, int L, int Lq, int P, float* grad_value, float* grad_sampling_loc,
+                     float* grad_attn_weight, void* stream);
+int moy_msda_bwd_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                     const double* sampling_loc, const double* attn_weight, const double* grad_output, int N, int S,
+                     int M, int D, int L, int Lq, int P, double* grad_value, double* grad_sampling_loc,
+                     double* grad_attn_weight, void* stream);
+
+/* Stretch resize of uint8 BGR HWC frames to the network resolution: what TrackPredictor.pre_transform does before
+ * the path (ultralytics/models/MOTRtrack/predict.py:96-105 -> LetterBox scaleFill branch, data/augment.py:573-576:
+ * `cv2.resize(img, (Wd, Hd), interpolation=cv2.INTER_LINEAR)`, no padding).  Bit-exact restatement of OpenCV's 8-bit
+ * INTER_LINEAR (11-bit fixed-point taps; exact 2x shrink -> INTER_AREA).  src [B, Hs, Ws, 3] with explicit row / image
+ * pitches in bytes, dst [B, Hd, Wd, 3] dense, Wd % 4 == 0 (network widths are multiples of 32).  The channel order is
+ * untouched: BGR->RGB, CHW and /255 stay fused in moy_stem_conv*. */
+int moy_resize_linear_u8(const uint8_t* src, int B, int Hs, int Ws, int64_t src_row_bytes, int64_t src_img_bytes,
+                         uint8_t* dst, int Hd, int Wd, void* stream);
 
 /* Per-frame ID assignment + predictor rows.  Replaces the host state machine
  * MOTRTrack._post_process_single_image / RuntimeTrackerBase.update (head.py:300-323,1232-1237) in

@@ -43,6 +43,16 @@ struct DT<float> {
   static __device__ __forceinline__ void store1(float* p, float v) { *p = v; }
 };
 template <>
+struct DT<double> {   // operator-API entries only (the reference's native op dispatches fp32/fp64: ms_deform_attn_cuda.cu:64)
+  static constexpr int KPB = 2;
+  static __device__ __forceinline__ double load1(const double* p) { return *p; }
+  static __device__ __forceinline__ void store1(double* p, double v) { *p = v; }
+};
+template <typename T>
+struct AccOf { typedef float type; };
+template <>
+struct AccOf<double> { typedef double type; };
+template <>
 struct DT<f16_t> {
   static constexpr int KPB = 8;
   static constexpr int code = MOY_F16;

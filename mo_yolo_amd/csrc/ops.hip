@@ -646,12 +646,85 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const T* __restrict__ v
   DT<T>::store4(out + (long)row * ldo + m * 32 + sub * 4, acc);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stretch resize of uint8 HWC frames = cv2.resize(img, (Wd, Hd), interpolation=cv2.INTER_LINEAR), the only thing
+// LetterBox does on the tracking path (scaleFill branch, data/augment.py:573-576, called from
+// MOTRtrack/predict.py:96-105).  cv2 is a third-party dependency absent from the reference tree (requirements.txt:
+// opencv-python>=4.6.0); this restates its published 8-bit algorithm (imgproc/resize.cpp: HResizeLinear<uchar,int,short,2048>
+// + VResizeLinear<uchar,...,FixedPtCast<int,uchar,22>>): 11-bit fixed-point taps, horizontal pass in int32, vertical pass
+// ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2; an exact 2x2 shrink is rerouted to INTER_AREA ((sum+2)>>2).
+// One thread makes 4 output pixels (12 bytes = 3 dword stores); HBM-bound: reads the source once, writes the target once.
+__device__ __forceinline__ void lin_tap(int d, double scale, int n_src, int& s0, int& s1, int& a0, int& a1, bool is_x) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (is_x) {                                         // resize.cpp: x taps are clamped with the weight forced to 0
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= n_src - 1) { f = 0.f; s = n_src - 1; }
+    s0 = s;
+    s1 = min(s + 1, n_src - 1);
+  } else {                                            // y taps keep their weights, rows are clipped
+    s0 = min(max(s, 0), n_src - 1);
+    s1 = min(max(s + 1, 0), n_src - 1);
+  }
+  a0 = max(-32768, min(32767, __float2int_rn((1.f - f) * 2048.f)));
+  a1 = max(-32768, min(32767, __float2int_rn(f * 2048.f)));
+}
+
+__global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __restrict__ src, int B, int Hs, int Ws, long src_row_bytes,
+                                                               long src_img_bytes, uint8_t* __restrict__ dst, int Hd, int Wd,
+                                                               double scale_x, double scale_y, int area2) {
+  const int wq = Wd >> 2;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)B * Hd * wq) return;
+  const int xq = (int)(t % wq);
+  const int dy = (int)((t / wq) % Hd);
+  const int b = (int)(t / ((long)wq * Hd));
+  const uint8_t* img = src + (long)b * src_img_bytes;
+  uint32_t out[3] = {0u, 0u, 0u};
+  if (area2) {
+    const uint8_t* r0 = img + (long)(2 * dy) * src_row_bytes;
+    const uint8_t* r1 = r0 + src_row_bytes;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int sx = (xq * 4 + i) * 2 * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const uint32_t v = ((uint32_t)r0[sx + c] + r0[sx + 3 + c] + r1[sx + c] + r1[sx + 3 + c] + 2u) >> 2;
+        const int byte = i * 3 + c;
+        out[byte >> 2] |= v << ((byte & 3) * 8);
+      }
+    }
+  } else {
+    int y0, y1, b0, b1;
+    lin_tap(dy, scale_y, Hs, y0, y1, b0, b1, false);
+    const uint8_t* r0 = img + (long)y0 * src_row_bytes;
+    const uint8_t* r1 = img + (long)y1 * src_row_bytes;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int x0, x1, a0, a1;
+      lin_tap(xq * 4 + i, scale_x, Ws, x0, x1, a0, a1, true);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int h0 = (int)r0[x0 * 3 + c] * a0 + (int)r0[x1 * 3 + c] * a1;
+        const int h1 = (int)r1[x0 * 3 + c] * a0 + (int)r1[x1 * 3 + c] * a1;
+        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        const int byte = i * 3 + c;
+        out[byte >> 2] |= (uint32_t)min(max(v, 0), 255) << ((byte & 3) * 8);
+      }
+    }
+  }
+  uint32_t* o = reinterpret_cast<uint32_t*>(dst + (((long)b * Hd + dy) * Wd + xq * 4) * 3);
+  o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
+}
+
 // Generic operator form (reference plugin API): one thread per output scalar, d fastest.
 template <typename T>
 __global__ __launch_bounds__(256) void msda_generic_kernel(const T* __restrict__ value, const int64_t* __restrict__ shapes,
                                                            const int64_t* __restrict__ lstart, const T* __restrict__ loc,
                                                            const T* __restrict__ aw, int N, int S, int M, int D, int L,
                                                            int Lq, int P, T* __restrict__ out) {
+  typedef typename AccOf<T>::type A;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const long total = (long)N * Lq * M * D;
   if (t >= total) return;
@@ -662,29 +735,87 @@ __global__ __launch_bounds__(256) void msda_generic_kernel(const T* __restrict__
   const int n = (int)(r / Lq);
   const T* lp = loc + ((((long)n * Lq + q) * M + m) * L) * P * 2;
   const T* ap = aw + ((((long)n * Lq + q) * M + m) * L) * P;
-  float acc = 0.f;
+  A acc = 0;
   for (int l = 0; l < L; ++l) {
     const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
     const T* vl = value + (((long)n * S + lstart[l]) * M + m) * D + d;
     for (int p = 0; p < P; ++p) {
-      const float x = DT<T>::load1(lp + (l * P + p) * 2) * W - 0.5f;
-      const float y = DT<T>::load1(lp + (l * P + p) * 2 + 1) * H - 0.5f;
-      const float w = DT<T>::load1(ap + l * P + p);
-      const float xf = floorf(x), yf = floorf(y);
-      const float fx = x - xf, fy = y - yf;
+      const A x = (A)DT<T>::load1(lp + (l * P + p) * 2) * W - (A)0.5;
+      const A y = (A)DT<T>::load1(lp + (l * P + p) * 2 + 1) * H - (A)0.5;
+      const A w = DT<T>::load1(ap + l * P + p);
+      const A xf = __builtin_elementwise_floor(x), yf = __builtin_elementwise_floor(y);
+      const A fx = x - xf, fy = y - yf;
       const int x0 = (int)xf, y0 = (int)yf;
-      float s = 0.f;
+      A s = 0;
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         const int xi = x0 + (tt & 1), yi = y0 + (tt >> 1);
         if ((unsigned)xi < (unsigned)W && (unsigned)yi < (unsigned)H)
-          s += ((tt & 1) ? fx : 1.f - fx) * ((tt >> 1) ? fy : 1.f - fy) *
-               DT<T>::load1(vl + ((long)yi * W + xi) * (long)M * D);
+          s += ((tt & 1) ? fx : 1 - fx) * ((tt >> 1) ? fy : 1 - fy) *
+               (A)DT<T>::load1(vl + ((long)yi * W + xi) * (long)M * D);
       }
       acc += w * s;
     }
   }
   DT<T>::store1(out + t, acc);
+}
+
+// Operator backward (ms_deform_attn_backward, ms_deform_attn.h:42-62; arithmetic of ms_deform_im2col_cuda.cuh:301-400
+// `ms_deform_attn_col2im_bilinear`): a group of G lanes owns one sample (n, q, m, l, p) and strides the D channels, so
+// grad_sampling_loc / grad_attn_weight are a shuffle reduction and a plain store (the reference needs shared-memory
+// reductions or atomics for them); grad_value is scattered with hardware float/double atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void msda_bwd_kernel(const T* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                       const int64_t* __restrict__ lstart, const T* __restrict__ loc,
+                                                       const T* __restrict__ aw, const T* __restrict__ gout, int N, int S, int M,
+                                                       int D, int L, int Lq, int P, int G, T* __restrict__ gvalue,
+                                                       T* __restrict__ gloc, T* __restrict__ gaw) {
+  const long total = (long)N * Lq * M * L * P;
+  const long sid = (long)blockIdx.x * (256 / G) + threadIdx.x / G;
+  const int lane = threadIdx.x % G;
+  const bool live = sid < total;                       // dead groups still take part in the shuffles
+  long r = live ? sid : total - 1;
+  const long smp = r;
+  r /= P;
+  const int l = (int)(r % L); r /= L;
+  const int m = (int)(r % M); r /= M;
+  const int q = (int)(r % Lq);
+  const int n = (int)(r / Lq);
+  const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+  const T x = loc[smp * 2] * W - (T)0.5, y = loc[smp * 2 + 1] * H - (T)0.5;
+  const T w = aw[smp];
+  T gw = 0, gh = 0, ga = 0;
+  if (live && y > -1 && x > -1 && y < H && x < W) {   // the reference's sample gate (cuh:339, :285 forward)
+    const T xf = __builtin_elementwise_floor(x), yf = __builtin_elementwise_floor(y);
+    const T lx = x - xf, ly = y - yf, hx = 1 - lx, hy = 1 - ly;
+    const int x0 = (int)xf, y0 = (int)yf;
+    const bool okx0 = x0 >= 0, okx1 = x0 + 1 < W, oky0 = y0 >= 0, oky1 = y0 + 1 < H;
+    const long cs = (long)M * D;                        // stride between neighbouring cells of one head
+    const long base = (((long)n * S + lstart[l]) * M + m) * D;
+    const long i00 = base + ((long)y0 * W + x0) * cs, i01 = i00 + cs, i10 = i00 + (long)W * cs, i11 = i10 + cs;
+    const T* go = gout + (((long)n * Lq + q) * M + m) * D;
+    for (int d = lane; d < D; d += G) {
+      const T g = go[d], tg = g * w;
+      T v00 = 0, v01 = 0, v10 = 0, v11 = 0;
+      if (oky0 && okx0) { v00 = value[i00 + d]; unsafeAtomicAdd(gvalue + i00 + d, hy * hx * tg); }
+      if (oky0 && okx1) { v01 = value[i01 + d]; unsafeAtomicAdd(gvalue + i01 + d, hy * lx * tg); }
+      if (oky1 && okx0) { v10 = value[i10 + d]; unsafeAtomicAdd(gvalue + i10 + d, ly * hx * tg); }
+      if (oky1 && okx1) { v11 = value[i11 + d]; unsafeAtomicAdd(gvalue + i11 + d, ly * lx * tg); }
+      ga += g * (hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11));
+      gw += tg * (hy * (v01 - v00) + ly * (v11 - v10));
+      gh += tg * (hx * (v10 - v00) + lx * (v11 - v01));
+    }
+  }
+  for (int o = G >> 1; o > 0; o >>= 1) {
+    gw += __shfl_xor(gw, o, 64);
+    gh += __shfl_xor(gh, o, 64);
+    ga += __shfl_xor(ga, o, 64);
+  }
+  if (live && lane == 0) {
+    gloc[smp * 2] = gw * W;
+    gloc[smp * 2 + 1] = gh * H;
+    gaw[smp] = ga;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1257,6 +1388,59 @@ extern "C" int moy_msda_fwd_bf16(const void* value, const int64_t* spatial_shape
                                  const void* sampling_loc, const void* attn_weight, int N, int S, int M, int D, int L, int Lq,
                                  int P, void* out, void* stream) {
   return msda_generic<bf16_t>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, stream);
+}
+
+extern "C" int moy_msda_fwd_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                const double* sampling_loc, const double* attn_weight, int N, int S, int M, int D, int L, int Lq,
+                                int P, double* out, void* stream) {
+  return msda_generic<double>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, stream);
+}
+
+template <typename T>
+static int msda_bwd(const T* value, const int64_t* shapes, const int64_t* lstart, const T* loc, const T* aw, const T* gout, int N, int S,
+                    int M, int D, int L, int Lq, int P, T* gvalue, T* gloc, T* gaw, void* stream) {
+  if (!value || !shapes || !lstart || !loc || !aw || !gout || !gvalue || !gloc || !gaw) return MOY_EINVAL;
+  if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return MOY_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // grad_value accumulates: the reference allocates it with zeros_like (ms_deform_attn_cuda.cu:107); here the callee clears it
+  if (hipMemsetAsync(gvalue, 0, sizeof(T) * (size_t)N * S * M * D, st) != hipSuccess) return MOY_ELAUNCH;
+  int G = 1;
+  while (G < D && G < 64) G <<= 1;
+  const long total = (long)N * Lq * M * L * P;
+  const long per_block = 256 / G;
+  hipLaunchKernelGGL((msda_bwd_kernel<T>), dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), 0, st, value, shapes, lstart,
+                     loc, aw, gout, N, S, M, D, L, Lq, P, G, gvalue, gloc, gaw);
+  return launch_status();
+}
+
+extern "C" int moy_msda_bwd_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                const float* sampling_loc, const float* attn_weight, const float* grad_output, int N, int S, int M,
+                                int D, int L, int Lq, int P, float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
+                                void* stream) {
+  return msda_bwd<float>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, N, S, M, D, L, Lq, P,
+                         grad_value, grad_sampling_loc, grad_attn_weight, stream);
+}
+
+extern "C" int moy_msda_bwd_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                const double* sampling_loc, const double* attn_weight, const double* grad_output, int N, int S, int M,
+                                int D, int L, int Lq, int P, double* grad_value, double* grad_sampling_loc, double* grad_attn_weight,
+                                void* stream) {
+  return msda_bwd<double>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, N, S, M, D, L, Lq, P,
+                          grad_value, grad_sampling_loc, grad_attn_weight, stream);
+}
+
+extern "C" int moy_resize_linear_u8(const uint8_t* src, int B, int Hs, int Ws, int64_t src_row_bytes, int64_t src_img_bytes,
+                                    uint8_t* dst, int Hd, int Wd, void* stream) {
+  if (!src || !dst || B <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0 || (Wd & 3)) return MOY_EINVAL;
+  if (src_row_bytes < (int64_t)Ws * 3 || src_img_bytes < src_row_bytes * Hs) return MOY_EINVAL;
+  if (reinterpret_cast<uintptr_t>(dst) & 3) return MOY_EINVAL;
+  // cv::resize: inv_scale = dsize / ssize (double), scale = 1 / inv_scale
+  const double scale_x = 1.0 / ((double)Wd / (double)Ws), scale_y = 1.0 / ((double)Hd / (double)Hs);
+  const int area2 = (Ws == 2 * Wd && Hs == 2 * Hd) ? 1 : 0;      // INTER_LINEAR -> INTER_AREA for the exact 2x shrink
+  const long total = (long)B * Hd * (Wd >> 2);
+  hipLaunchKernelGGL(resize_linear_u8_kernel, dim3(nblk(total)), dim3(256), 0, static_cast<hipStream_t>(stream), src, B, Hs, Ws,
+                     (long)src_row_bytes, (long)src_img_bytes, dst, Hd, Wd, scale_x, scale_y, area2);
+  return launch_status();
 }
 
 extern "C" int moy_assign_post(const float* logits, const float* boxes, int B, int nq, int nc, float score_thresh, float conf,

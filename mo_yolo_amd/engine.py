@@ -67,7 +67,9 @@ class TrackEngine:
         self.dtype, self.code, self.dev = dtype, _code(dtype), torch.device(device)
         self.input_format = input_format
         self.conf, self.score_thresh = conf, score_thresh
-        self.img_wh = (float(W), float(H)) if scale_boxes else (1.0, 1.0)
+        # rows are scaled to the ORIGINAL frame (predict.py:61-76); it differs from (H, W) when the predictor stretch-resized
+        oh, ow = orig_hw if (orig_hw is not None and arch.head_kind != "detect") else (H, W)
+        self.img_wh = (float(ow), float(oh)) if scale_boxes else (1.0, 1.0)
         self.head_only = head_only
         self.iou, self.max_det, self.orig_hw = iou, max_det, orig_hw      # Detect head (config C1) only
         self.side_state = side_state     # keep the output-invisible tracker copy + FSQM memory on device

@@ -285,6 +285,26 @@ def multi_scale_deformable_attn_pytorch(value, value_spatial_shapes, sampling_lo
                                       attention_weights.contiguous(), 64)
 
 
+class MSDeformAttnFunction(torch.autograd.Function):
+    """MOTR/models/ops/functions/ms_deform_attn_func.py:24-41: the autograd wrapper of the native op
+    (forward + `ms_deform_attn_backward`); gradients for value, sampling locations and attention weights."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights, im2col_step):
+        ctx.im2col_step = im2col_step
+        output = ops.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                            attention_weights, ctx.im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights)
+        return output
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, lsi, loc, aw = ctx.saved_tensors
+        gv, gl, ga = ops.ms_deform_attn_backward(value, shapes, lsi, loc, aw, grad_output.contiguous(), ctx.im2col_step)
+        return gv, None, None, gl, ga, None
+
+
 class MSDeformAttn(nn.Module):
     """transformer.py:193-287 (d_model 256, 8 heads, 4 points, <= 4 levels, 4-d reference boxes)."""
 

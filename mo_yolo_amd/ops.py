@@ -192,23 +192,65 @@ def msda_fused(value, B, S, shapes, offaw, ref, Lq):
     return out
 
 
+def _msda_check(tensors, value, im2col_step):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError("Not implemented on the CPU")      # ms_deform_attn.h:39,61
+        if not t.is_contiguous():
+            raise RuntimeError("tensor has to be contiguous")     # ms_deform_attn_cuda.cu:28-32,91-96
+    step = min(value.shape[0], int(im2col_step))
+    if value.shape[0] % step:
+        raise RuntimeError(f"batch({value.shape[0]}) must divide im2col_step({step})")   # ms_deform_attn_cuda.cu:49,118
+
+
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
     """Same call as MultiScaleDeformableAttention.ms_deform_attn_forward (MOTR/models/ops/src/vision.cpp:13-16,
-    ms_deform_attn.h:21-40).  `im2col_step` is accepted for signature compatibility (no chunking needed)."""
-    for t in (value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
-        if not t.is_cuda:
-            raise RuntimeError("Not implemented on the CPU")
-        if not t.is_contiguous():
-            raise RuntimeError("tensor has to be contiguous")     # ms_deform_attn_cuda.cu:28-32
+    ms_deform_attn.h:21-40).  `im2col_step` is checked like the reference does and otherwise unused (no chunking)."""
+    _msda_check((value, spatial_shapes, level_start_index, sampling_loc, attn_weight), value, im2col_step)
     N, S, M, D = value.shape
     _, Lq, _, Lv, P, _ = sampling_loc.shape
     assert spatial_shapes.dtype == torch.int64 and level_start_index.dtype == torch.int64
+    fn = {torch.float32: "moy_msda_fwd_f32", torch.bfloat16: "moy_msda_fwd_bf16", torch.float64: "moy_msda_fwd_f64"}.get(value.dtype)
+    if fn is None or sampling_loc.dtype != value.dtype or attn_weight.dtype != value.dtype:
+        raise TypeError("ms_deform_attn_forward: float32 / float64 / bfloat16, one dtype for value, locations and weights")
     out = torch.empty(N, Lq, M * D, device=value.device, dtype=value.dtype)
-    if value.dtype not in (torch.float32, torch.bfloat16):
-        raise TypeError("ms_deform_attn_forward: float32 / bfloat16 only")
-    fn = L.lib().moy_msda_fwd_f32 if value.dtype == torch.float32 else L.lib().moy_msda_fwd_bf16
-    L.check(fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
-               attn_weight.data_ptr(), N, S, M, D, Lv, Lq, P, out.data_ptr(), _st()), "moy_msda_fwd")
+    L.check(getattr(L.lib(), fn)(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                                 attn_weight.data_ptr(), N, S, M, D, Lv, Lq, P, out.data_ptr(), _st()), fn)
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step=64):
+    """MultiScaleDeformableAttention.ms_deform_attn_backward (vision.cpp:13-16, ms_deform_attn.h:42-62):
+    -> [grad_value, grad_sampling_loc, grad_attn_weight], fp32 / fp64 like the reference."""
+    _msda_check((value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output), value, im2col_step)
+    N, S, M, D = value.shape
+    _, Lq, _, Lv, P, _ = sampling_loc.shape
+    assert spatial_shapes.dtype == torch.int64 and level_start_index.dtype == torch.int64
+    fn = {torch.float32: "moy_msda_bwd_f32", torch.float64: "moy_msda_bwd_f64"}.get(value.dtype)
+    if fn is None or any(t.dtype != value.dtype for t in (sampling_loc, attn_weight, grad_output)):
+        raise TypeError("ms_deform_attn_backward: float32 / float64, one dtype for all floating tensors")
+    if grad_output.numel() != N * Lq * M * D:
+        raise RuntimeError("grad_output must hold N*Lq*M*D elements")
+    gv, gl, ga = torch.empty_like(value), torch.empty_like(sampling_loc), torch.empty_like(attn_weight)
+    L.check(getattr(L.lib(), fn)(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                                 attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, Lv, Lq, P, gv.data_ptr(), gl.data_ptr(),
+                                 ga.data_ptr(), _st()), fn)
+    return [gv, gl, ga]
+
+
+def resize_linear_u8(frames, out_hw, out=None):
+    """uint8 [B, Hs, Ws, 3] -> [B, Hd, Wd, 3], cv2.resize(..., INTER_LINEAR) semantics (LetterBox scaleFill,
+    data/augment.py:573-576)."""
+    _need_gpu(frames)
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3 or frames.stride(3) != 1 or frames.stride(2) != 3:
+        raise ValueError("frames must be uint8 [B, H, W, 3] with dense pixels")
+    B, Hs, Ws, _ = frames.shape
+    Hd, Wd = out_hw
+    if out is None:
+        out = torch.empty(B, Hd, Wd, 3, device=frames.device, dtype=torch.uint8)
+    assert out.is_contiguous() and tuple(out.shape) == (B, Hd, Wd, 3) and out.dtype == torch.uint8
+    L.check(L.lib().moy_resize_linear_u8(frames.data_ptr(), B, Hs, Ws, frames.stride(1), frames.stride(0), out.data_ptr(), Hd, Wd,
+                                         _st()), "moy_resize_linear_u8")
     return out
 
 

@@ -13,6 +13,7 @@ from typing import List, Sequence
 import numpy as np
 import torch
 
+from . import ops
 from .engine import TrackEngine
 
 
@@ -54,21 +55,23 @@ class TrackPredictor:
         self.batch, self.graph = batch, graph
         self._engines = {}
 
-    def _engine(self, fmt):
-        if fmt not in self._engines:
+    def _engine(self, fmt, orig_hw=None):
+        key = (fmt, tuple(orig_hw or self.imgsz))
+        if key not in self._engines:
             H, W = self.imgsz
             eng = TrackEngine(self.arch, self.sd, H, W, batch=self.batch, dtype=self.dtype, device=self.device,
-                              input_format=fmt, conf=self.conf, scale_boxes=(fmt == "u8"))
+                              input_format=fmt, conf=self.conf, scale_boxes=(fmt == "u8"), orig_hw=key[1])
             if self.graph:
                 eng.forward(torch.zeros_like(eng.input))
                 eng.capture()
-            self._engines[fmt] = eng
-        return self._engines[fmt]
+            self._engines[key] = eng
+        return self._engines[key]
 
     def preprocess(self, im):
-        """List of uint8 BGR HWC frames (at network resolution) or float [B,3,H,W] in [0,1].
-        The BGR->RGB / CHW / float / 255 arithmetic of predictor.py:125-133 is fused into the stem
-        kernel, so 'preprocess' only validates and uploads."""
+        """List of uint8 BGR HWC frames (any size) or float [B,3,H,W] in [0,1] at network resolution.
+        Frames of another size are stretch-resized on the device like `pre_transform` does with
+        LetterBox(scaleFill) (MOTRtrack/predict.py:96-105, data/augment.py:573-576: cv2 INTER_LINEAR, no padding);
+        the BGR->RGB / CHW / float / 255 arithmetic of predictor.py:125-133 is fused into the stem kernel."""
         if isinstance(im, torch.Tensor):
             if im.dim() != 4 or im.shape[1] != 3 or tuple(im.shape[2:]) != self.imgsz:
                 raise ValueError(f"tensor source must be [B,3,{self.imgsz[0]},{self.imgsz[1]}]")
@@ -77,16 +80,14 @@ class TrackPredictor:
             return im.to(self.device, torch.float32), "f32"
         arr = np.stack(im) if not isinstance(im, np.ndarray) else im
         if arr.dtype != np.uint8 or arr.ndim != 4 or arr.shape[3] != 3:
-            raise ValueError("frame source must be uint8 [B,H,W,3] BGR")
-        if tuple(arr.shape[1:3]) != self.imgsz:
-            raise NotImplementedError("stretch-resize (LetterBox scaleFill, predict.py:96-105) is not part of this round: "
-                                      "feed frames at network resolution (SURVEY H7)")
-        return torch.from_numpy(arr).to(self.device), "u8"
+            raise ValueError("frame source must be uint8 [B,H,W,3] BGR (frames of one size)")
+        return torch.from_numpy(np.ascontiguousarray(arr)).to(self.device), "u8"
 
     @torch.no_grad()
     def __call__(self, source, paths: Sequence[str] | None = None) -> List[TrackResults]:
         x, fmt = self.preprocess(source)
-        eng = self._engine(fmt)
+        orig_hw = tuple(x.shape[1:3]) if fmt == "u8" else self.imgsz
+        eng = self._engine(fmt, orig_hw)
         results: List[TrackResults] = []
         n = x.shape[0]
         for s in range(0, n, self.batch):
@@ -94,12 +95,16 @@ class TrackPredictor:
             k = chunk.shape[0]
             if k < self.batch:                                     # ragged tail: pad with the last frame
                 chunk = torch.cat([chunk, chunk[-1:].expand(self.batch - k, *chunk.shape[1:])], 0)
-            out = eng.forward(chunk.contiguous())
+            if fmt == "u8" and orig_hw != self.imgsz:
+                ops.resize_linear_u8(chunk.contiguous(), self.imgsz, out=eng.input)
+                out = eng.forward(None)
+            else:
+                out = eng.forward(chunk.contiguous())
             rows, tid = out["rows"].cpu().numpy(), out["track_id"].cpu().numpy()
             n_rows, n_ids = out["n_rows"].cpu().numpy(), out["n_ids"].cpu().numpy()
             for b in range(k):
                 t = None if n_ids[b] < 0 else tid[b, :n_ids[b]].copy()
-                results.append(TrackResults(rows[b, :n_rows[b]].copy(), t, self.imgsz,
+                results.append(TrackResults(rows[b, :n_rows[b]].copy(), t, orig_hw,
                                             path=(paths[s + b] if paths else "")))
         return results
 

@@ -204,6 +204,52 @@ def msda_core(value, shapes, loc, aw):
     return out.reshape(B, Lq, M * D)
 
 
+def msda_core_backward(value, shapes, loc, aw, grad_out):
+    """Analytic gradients of `msda_core`, restating the reference's native backward
+    (MOTR/models/ops/src/cuda/ms_deform_im2col_cuda.cuh:301-400 `ms_deform_attn_col2im_bilinear`;
+    host MOTR/models/ops/src/cuda/ms_deform_attn_cuda.cu:81-153):
+      a sample (n,q,m,l,p) counts only if -1 < h_im < H and -1 < w_im < W (cuh:339);
+      grad_value[corner] += bilinear_w(corner) * aw * g;   grad_aw = sum_d g * sampled;
+      grad_loc_x = W * sum_d aw*g * (hh*(v01-v00) + lh*(v11-v10)),  grad_loc_y = H * sum_d aw*g * (hw*(v10-v00) + lw*(v11-v01)).
+    grad_out [B,Lq,M*D] -> (grad_value [B,S,M,D], grad_loc [B,Lq,M,L,P,2], grad_aw [B,Lq,M,L,P])."""
+    B, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    g = grad_out.reshape(B, Lq, M, 1, D)
+    gv = torch.zeros_like(value)
+    gl = torch.zeros_like(loc)
+    ga = torch.zeros_like(aw)
+    bidx = torch.arange(B).view(B, 1, 1, 1).expand(B, Lq, M, P)
+    midx = torch.arange(M).view(1, 1, M, 1).expand(B, Lq, M, P)
+    start = 0
+    for l, (H, W) in enumerate(shapes):
+        x = loc[:, :, :, l, :, 0] * W - 0.5                     # [B, Lq, M, P]
+        y = loc[:, :, :, l, :, 1] * H - 0.5
+        live = (y > -1) & (x > -1) & (y < H) & (x < W)
+        x0 = torch.floor(x); y0 = torch.floor(y)
+        lx = x - x0; ly = y - y0
+        x0 = x0.long(); y0 = y0.long()
+        a = aw[:, :, :, l, :]
+        tg = g * a[..., None]                                    # [B, Lq, M, P, D]
+        vals = {}
+        for dy, wy in ((0, 1 - ly), (1, ly)):
+            for dx, wx in ((0, 1 - lx), (1, lx)):
+                xi = x0 + dx; yi = y0 + dy
+                ok = live & (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+                cell = start + yi.clamp(0, H - 1) * W + xi.clamp(0, W - 1)
+                v = value[bidx, cell, midx] * ok[..., None]      # [B, Lq, M, P, D]
+                vals[(dy, dx)] = v
+                contrib = tg * (wy * wx * ok)[..., None]
+                gv.index_put_((bidx.reshape(-1), cell.reshape(-1), midx.reshape(-1)), contrib.reshape(-1, D), accumulate=True)
+        v00, v01, v10, v11 = vals[(0, 0)], vals[(0, 1)], vals[(1, 0)], vals[(1, 1)]
+        hx = (1 - lx)[..., None]; hy = (1 - ly)[..., None]; lxe = lx[..., None]; lye = ly[..., None]
+        sampled = hy * (hx * v00 + lxe * v01) + lye * (hx * v10 + lxe * v11)
+        ga[:, :, :, l, :] = (g * sampled).sum(-1)
+        gl[:, :, :, l, :, 0] = W * (tg * (hy * (v01 - v00) + lye * (v11 - v10))).sum(-1)
+        gl[:, :, :, l, :, 1] = H * (tg * (hx * (v10 - v00) + lxe * (v11 - v01))).sum(-1)
+        start += H * W
+    return gv, gl, ga
+
+
 def msda(query, refer_bbox, feats, shapes, sd, p, nh, npnt, value=None):
     """MSDeformAttn.forward transformer.py:246-287, 4-d reference boxes (:280-282)."""
     B, Lq, C = query.shape

@@ -394,6 +394,15 @@ def dump_msda():
         out[name + ".value"] = value.numpy(); out[name + ".loc"] = loc.numpy(); out[name + ".aw"] = aw.numpy()
         out[name + ".shapes"] = np.array(c["shapes"], dtype=np.int64)
         out[name + ".out"] = o.numpy(); out[name + ".out_f64"] = o64.numpy()
+        # backward vectors (§8f rank 4): autograd through the reference's torch op, the check its own
+        # ops/test.py:66-86 makes with gradcheck, for a seeded grad_output
+        go = torch.rand(o.shape, generator=g) - 0.5
+        for tag, dt in (("", torch.float32), ("_f64", torch.float64)):
+            v_, l_, a_ = (t.to(dt).clone().requires_grad_(True) for t in (value, loc, aw))
+            ref(v_, c["shapes"], l_, a_).backward(go.to(dt))
+            out[name + ".gvalue" + tag], out[name + ".gloc" + tag], out[name + ".gaw" + tag] = \
+                v_.grad.numpy(), l_.grad.numpy(), a_.grad.numpy()
+        out[name + ".gout"] = go.numpy()
     np.savez_compressed(os.path.join(HERE, "msda_kat.npz"), **out)
     print("[msda] wrote", list(cases))
 

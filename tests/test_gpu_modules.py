@@ -149,6 +149,29 @@ def test_predictor_stream_rows_and_txt(name):
         assert np.allclose(res_t[t].boxes, g[f"post.{t}.boxes_tensor_src"], atol=2e-4)
 
 
+def test_predictor_stretch_resizes_foreign_frame_sizes():
+    """Frames that are not at network resolution go through LetterBox(scaleFill) first (MOTRtrack/predict.py:96-105):
+    device resize == oracle resize (bit-exact input), rows come back in ORIGINAL pixels (predict.py:61-76)."""
+    from oracle.preprocess_oracle import resize_linear_u8
+    cfg, arch, sd = fixture("tiny")
+    H, W = cfg["H"], cfg["W"]
+    oh, ow = 90, 150
+    src = np.random.default_rng(5).integers(0, 256, (3, oh, ow, 3), dtype=np.uint8)
+    pred = TrackPredictor(arch, sd, imgsz=(H, W), conf=0.25, batch=2)
+    got = pred(list(src))
+    want = pred([resize_linear_u8(f, (H, W)) for f in src])            # network-resolution path, pinned by the goldens above
+    assert pred._engines[("u8", (oh, ow))].input.shape == (2, H, W, 3)
+    for r, w in zip(got, want):
+        assert r.orig_shape == (oh, ow) and len(r) == len(w) and len(w) > 0
+        scale = np.array([ow / W, oh / H, ow / W, oh / H, 1, 1], np.float32)
+        assert np.allclose(r.boxes, w.boxes * scale, atol=1e-3)
+        assert (r.track_id is None) == (w.track_id is None)
+        if r.track_id is not None:
+            assert np.array_equal(r.track_id, w.track_id)
+            assert np.allclose([[float(v) for v in l.split()] for l in r.txt_lines()],
+                               [[float(v) for v in l.split()] for l in w.txt_lines()], atol=1e-5)
+
+
 def test_batched_frames_equal_single_frames():
     """Batching frames is result-neutral (no cross-frame state in the shipped path)."""
     from mo_yolo_amd.engine import TrackEngine

@@ -268,6 +268,83 @@ def test_ms_deform_attn_forward_kats(dt):
             assert torch.allclose(y.float().cpu(), want, atol=3e-4, rtol=3e-2)
 
 
+def _kat(g, name, dt):
+    v, loc, aw = (torch.from_numpy(g[f"{name}.{k}"]).to(dt) for k in ("value", "loc", "aw"))
+    shapes = torch.from_numpy(g[name + ".shapes"])
+    lsi = torch.cat((shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]))
+    return v, loc, aw, shapes, lsi
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_ms_deform_attn_backward_kats(dt):
+    """ms_deform_attn_backward (ms_deform_attn.h:42-62) vs autograd through the reference's torch op, fixtures from
+    tests/golden/make_golden.py; fp64 is the precision the reference's own gradcheck runs in (ops/test.py:66-86)."""
+    g = golden("msda_kat")
+    tag, atol = ("", 2e-7) if dt == torch.float32 else ("_f64", 1e-14)
+    for name in ("kat_tiny", "kat_heads8", "kat_odd"):
+        v, loc, aw, shapes, lsi = _kat(g, name, dt)
+        go = torch.from_numpy(g[name + ".gout"]).to(dt)
+        if dt == torch.float64:     # fp64 forward of the operator API too
+            y = ops.ms_deform_attn_forward(v.to(DEV), shapes.to(DEV), lsi.to(DEV), loc.to(DEV), aw.to(DEV), 64)
+            assert torch.allclose(y.cpu(), torch.from_numpy(g[name + ".out_f64"]), atol=1e-14, rtol=1e-10)
+        got = ops.ms_deform_attn_backward(v.to(DEV), shapes.to(DEV), lsi.to(DEV), loc.to(DEV), aw.to(DEV), go.to(DEV), 64)
+        for k, t in zip(("gvalue", "gloc", "gaw"), got):
+            assert torch.allclose(t.cpu(), torch.from_numpy(g[f"{name}.{k}{tag}"]), atol=atol, rtol=1e-5), (name, k)
+
+
+@pytest.mark.parametrize("D", [30, 32, 64, 71, 1025])
+def test_ms_deform_attn_backward_channels(D):
+    """The channel counts the reference's gradient test sweeps (ops/test.py:86; 2048/3096 left out for time), against the
+    oracle's analytic backward in fp64, through the autograd Function (functions/ms_deform_attn_func.py:24-41)."""
+    from mo_yolo_amd.modules import MSDeformAttnFunction
+    N, M, Lq, P = 2, 2, 5, 3
+    shapes_l = [(6, 4), (3, 2)]
+    S = sum(h * w for h, w in shapes_l)
+    gen = torch.Generator().manual_seed(D)
+    value = torch.rand(N, S, M, D, generator=gen, dtype=torch.float64) * 0.01
+    loc = torch.rand(N, Lq, M, 2, P, 2, generator=gen, dtype=torch.float64) * 1.3 - 0.15
+    aw = torch.rand(N, Lq, M, 2, P, generator=gen, dtype=torch.float64) + 1e-5
+    aw = aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    go = torch.rand(N, Lq, M * D, generator=gen, dtype=torch.float64) - 0.5
+    shapes = torch.tensor(shapes_l, dtype=torch.int64)
+    lsi = torch.cat((shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]))
+    v_, l_, a_ = (t.to(DEV).requires_grad_(True) for t in (value, loc, aw))
+    y = MSDeformAttnFunction.apply(v_, shapes.to(DEV), lsi.to(DEV), l_, a_, 2)
+    assert torch.allclose(y.detach().cpu(), O.msda_core(value, shapes_l, loc, aw), atol=1e-14, rtol=1e-10)
+    y.backward(go.to(DEV))
+    for t, w in zip((v_.grad, l_.grad, a_.grad), O.msda_core_backward(value, shapes_l, loc, aw, go)):
+        assert torch.allclose(t.cpu(), w, atol=1e-13, rtol=1e-9)
+
+
+def test_ms_deform_attn_errors():
+    """Error behaviour of the operator: CPU tensors and batch % im2col_step (ms_deform_attn.h:39, ms_deform_attn_cuda.cu:49)."""
+    g = golden("msda_kat")
+    v, loc, aw, shapes, lsi = _kat(g, "kat_heads8", torch.float32)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        ops.ms_deform_attn_forward(v, shapes, lsi, loc, aw, 64)
+    v3 = torch.cat((v, v[:1])).to(DEV)
+    with pytest.raises(RuntimeError, match="must divide"):
+        ops.ms_deform_attn_forward(v3, shapes.to(DEV), lsi.to(DEV), torch.cat((loc, loc[:1])).to(DEV), torch.cat((aw, aw[:1])).to(DEV), 2)
+
+
+@pytest.mark.parametrize("src_hw,dst_hw", [((1080, 1920), (608, 1088)), ((480, 640), (608, 1088)), ((1216, 2176), (608, 1088)),
+                                           ((37, 53), (64, 96)), ((64, 96), (64, 96)), ((3, 2), (32, 32)), ((700, 1), (32, 64))])
+def test_resize_linear_u8_bit_exact(src_hw, dst_hw):
+    """moy_resize_linear_u8 vs the oracle's restatement of cv2.resize INTER_LINEAR (LetterBox scaleFill, augment.py:573-576):
+    byte work, bit-exact; shrink, enlarge, the 2x INTER_AREA reroute, unit scale, degenerate 1-pixel-wide sources."""
+    from oracle.preprocess_oracle import resize_linear_u8 as ref
+    B = 2
+    src = np.random.default_rng(src_hw[0]).integers(0, 256, (B, *src_hw, 3), dtype=np.uint8)
+    got = ops.resize_linear_u8(torch.from_numpy(src).to(DEV), dst_hw).cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(got[b], ref(src[b], dst_hw)), b
+    # a pitched source (a crop of a wider frame): explicit row / image strides
+    if src_hw[1] > 8:
+        crop = torch.from_numpy(src).to(DEV)[:, :, 4:]
+        got = ops.resize_linear_u8(crop, dst_hw).cpu().numpy()
+        assert np.array_equal(got[1], ref(np.ascontiguousarray(src[1, :, 4:]), dst_hw))
+
+
 def test_assign_post_semantics():
     B, nq, nc = 4, 300, 2
     logits = rnd(B, nq, nc, seed=1, scale=4.0)

@@ -109,6 +109,18 @@ def test_msda_core_kats():
         assert torch.allclose(o64, torch.from_numpy(g[name + ".out_f64"]), atol=1e-12, rtol=1e-9), name
 
 
+def test_msda_backward_kats():
+    """Oracle backward (restating ms_deform_im2col_cuda.cuh:301-400) vs autograd through the reference's torch op
+    (the comparison its ops/test.py:66-86 makes with gradcheck)."""
+    g = golden("msda_kat")
+    for name in ("kat_tiny", "kat_heads8", "kat_odd"):
+        shapes = [tuple(s) for s in g[name + ".shapes"]]
+        for tag, dt, tol in (("", torch.float32, 2e-7), ("_f64", torch.float64, 1e-15)):
+            v, loc, aw, go = (torch.from_numpy(g[f"{name}.{k}"]).to(dt) for k in ("value", "loc", "aw", "gout"))
+            for k, t in zip(("gvalue", "gloc", "gaw"), O.msda_core_backward(v, shapes, loc, aw, go)):
+                assert torch.allclose(t, torch.from_numpy(g[f"{name}.{k}{tag}"]), atol=tol, rtol=1e-5), (name, k, tag)
+
+
 def test_qim_isolated():
     g = golden("qim")
     _, arch, sd = fixture("tiny")
@@ -163,3 +175,18 @@ def test_c1_yolov8n_detect_vs_reference():
             r[:, :4] = O.scale_boxes((640, 640), r[:, :4], hw)
             assert r.shape == g[key].shape
             assert np.allclose(r.numpy(), g[key], atol=2e-3, rtol=1e-5)
+
+
+def test_resize_oracle_known_answers():
+    """cv2 is absent (parity unpinned, see oracle/preprocess_oracle.py): known answers of OpenCV's 8-bit INTER_LINEAR."""
+    from oracle.preprocess_oracle import letterbox_scalefill, resize_linear_u8
+    assert resize_linear_u8(np.array([[[0], [255]]], np.uint8), (1, 4))[0, :, 0].tolist() == [0, 64, 191, 255]
+    r = np.random.default_rng(0).integers(0, 256, (14, 18, 3), dtype=np.uint8)
+    assert np.array_equal(resize_linear_u8(r, (14, 18)), r)                           # unit scale: taps (2048, 0)
+    assert letterbox_scalefill(r, (14, 18)) is r                                       # augment.py:586 no-op
+    assert (resize_linear_u8(np.full((5, 7, 3), 77, np.uint8), (32, 64)) == 77).all()  # constants survive the fixed point
+    area = resize_linear_u8(r, (7, 9))                                                 # exact 2x shrink -> INTER_AREA
+    v = r.astype(np.int64)
+    assert np.array_equal(area, ((v[0::2, 0::2] + v[0::2, 1::2] + v[1::2, 0::2] + v[1::2, 1::2] + 2) >> 2))
+    up = resize_linear_u8(r, (33, 40))
+    assert up.shape == (33, 40, 3) and up.min() >= r.min() and up.max() <= r.max()     # convex taps stay in range
