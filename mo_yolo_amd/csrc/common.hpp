@@ -87,15 +87,32 @@ struct DT<bf16_t> {
   static __device__ __forceinline__ void store1(bf16_t* p, float v) { p->v = f2bf(v); }
 };
 
+// Wave-wide reductions on the VALU (DPP), result broadcast through an SGPR.  `__shfl_xor` compiles to ds_bpermute_b32: six
+// dependent trips through the LDS crossbar per reduction, which made the LayerNorm epilogue (3 reductions per row) LDS-bound.
+// quad_perm [1,0,3,2] / [2,3,0,1] -> quad sums; row_shr:4, row_shr:8 -> the row total in lanes 12..15 of each row of 16;
+// row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3) -> the wave total in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float identity, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v), CTRL,
+                                                               ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f<0xb1, 0xf>(0.f, v);
+  v += dpp_f<0x4e, 0xf>(0.f, v);
+  v += dpp_f<0x114, 0xf>(0.f, v);
+  v += dpp_f<0x118, 0xf>(0.f, v);
+  v += dpp_f<0x142, 0xa>(0.f, v);
+  v += dpp_f<0x143, 0xc>(0.f, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_f<0xb1, 0xf>(v, v));
+  v = fmaxf(v, dpp_f<0x4e, 0xf>(v, v));
+  v = fmaxf(v, dpp_f<0x114, 0xf>(v, v));
+  v = fmaxf(v, dpp_f<0x118, 0xf>(v, v));
+  v = fmaxf(v, dpp_f<0x142, 0xa>(v, v));
+  v = fmaxf(v, dpp_f<0x143, 0xc>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // accurate forms (feed thresholds / final outputs)
