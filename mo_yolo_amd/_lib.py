@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmoyolo.so")
+LIB_PATH = os.environ.get("MOYOLO_LIB") or os.path.join(HERE, "libmoyolo.so")   # override: A/B runs of two builds on one device
 
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3

@@ -22,6 +22,24 @@ namespace moy {
 
 constexpr int PANELS = 2;
 
+// Division by a launch-time constant: q = (n * M) >> (32 + s) with M = ceil(2^(32+s) / d), s = ceil(log2 d), exact for
+// every 32-bit n (Granlund & Montgomery); M = 2^32 + magic.  A 32-bit divide by a runtime value costs ~35 VALU ops and
+// the tile set-up (pixel coordinates of every staged row) did five of them before the first load could issue.
+struct FastDiv {
+  uint32_t magic, shift, d;
+};
+static FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f{0u, 0u, d ? d : 1u};
+  d = f.d;
+  while ((1ull << f.shift) < d) ++f.shift;
+  f.magic = (uint32_t)((((1ull << f.shift) - d) << 32) / d + 1);   // ceil(2^(32+s)/d) - 2^32
+  if (d == 1) f.magic = 0;
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+  return (uint32_t)(((uint64_t)__umulhi(n, f.magic) + n) >> f.shift);
+}
+
 struct GemmParams {
   const void* A;
   const void* A2;
@@ -52,6 +70,7 @@ struct GemmParams {
   int dot_n;
   int wide_store;   // bf16 output, N % 8 == 0, 16-byte aligned rows: 8 columns per store
   int tiles_n, nblocks;
+  FastDiv fd_tiles_n, fd_hw, fd_wout, fd_mask, fd_rpb;
 };
 
 // 16-B column swizzle: lanes of one ds_read_b128 lane group hit distinct bank quartets.
@@ -119,7 +138,7 @@ __device__ __forceinline__ f32x4 act4(f32x4 v) {
   return v;
 }
 
-template <int ACT, int BN, int TM, int TN, int MT, int NT>
+template <typename T, bool HALF, int ACT, int BN, int TM, int TN, int MT, int NT>
 __device__ __forceinline__ void stage_acc_act(const GemmParams& p, f32x4 (&acc)[MT][NT], float* Cs, int n0, int wm, int wn, int r,
                                               int q) {
   constexpr int LDC = BN + 4;
@@ -146,18 +165,29 @@ __device__ __forceinline__ void stage_acc_act(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int ml = wm * TM + i * 16 + r;     // D[n_local = q*4 + reg][m_local = r]
-      *reinterpret_cast<f32x4*>(Cs + ml * LDC + nl) = act4<ACT>(acc[i][j] * sc[j] + sh[j]);
+      const f32x4 v = act4<ACT>(acc[i][j] * sc[j] + sh[j]);
+      if constexpr (HALF) {
+        // the tile goes to LDS already rounded to the output type: half the ds_write traffic (the VGPR->LDS path, ~80 B/clk
+        // per CU, is the scarcest resource of the kernel) and no conversion in the output pass.  Row stride BN + 4 halves:
+        // the 16 rows of a ds_write_b64 lane group fall on 16 distinct bank pairs.
+        if constexpr (!std::is_same<T, float>::value) {
+          unsigned char* ch = reinterpret_cast<unsigned char*>(Cs) + ((size_t)ml * (BN + 4) + nl) * 2;
+          *reinterpret_cast<u32x2*>(ch) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+        }
+      } else {
+        *reinterpret_cast<f32x4*>(Cs + ml * LDC + nl) = v;
+      }
     }
   }
 }
 
-template <int BN, int TM, int TN, int MT, int NT>
+template <typename T, bool HALF, int BN, int TM, int TN, int MT, int NT>
 __device__ __forceinline__ void stage_acc(const GemmParams& p, f32x4 (&acc)[MT][NT], float* Cs, int n0, int wm, int wn, int r, int q) {
   switch (p.act) {   // wave-uniform: one branch, not one per element
-    case MOY_ACT_SILU: stage_acc_act<MOY_ACT_SILU, BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q); break;
-    case MOY_ACT_RELU: stage_acc_act<MOY_ACT_RELU, BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q); break;
-    case MOY_ACT_SIGMOID: stage_acc_act<MOY_ACT_SIGMOID, BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q); break;
-    default: stage_acc_act<MOY_ACT_NONE, BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q); break;
+    case MOY_ACT_SILU: stage_acc_act<T, HALF, MOY_ACT_SILU, BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q); break;
+    case MOY_ACT_RELU: stage_acc_act<T, HALF, MOY_ACT_RELU, BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q); break;
+    case MOY_ACT_SIGMOID: stage_acc_act<T, HALF, MOY_ACT_SIGMOID, BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q); break;
+    default: stage_acc_act<T, HALF, MOY_ACT_NONE, BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q); break;
   }
 }
 
@@ -219,7 +249,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const float* 
     }
     if (col_ok && m < p.M) {
       int64_t mo = m;
-      if (p.c_rpb) mo = (int64_t)(m / p.c_rpb) * p.c_bstride + (m % p.c_rpb);   // wave-uniform rare path
+      if (p.c_rpb) { const int bq = (int)fdiv(m, p.fd_rpb); mo = (int64_t)bq * p.c_bstride + (m - bq * p.c_rpb); }   // wave-uniform rare path
       unsigned char* cp = cbase + mo * p.ldc * out_esz;
       if (p.out_f32)
         *reinterpret_cast<f32x4*>(cp) = v;
@@ -262,9 +292,33 @@ __device__ __forceinline__ void gemm_epilogue_bf16x8(const GemmParams& p, const 
     }
     if (col_ok && m < p.M) {
       int64_t mo = m;
-      if (p.c_rpb) mo = (int64_t)(m / p.c_rpb) * p.c_bstride + (m % p.c_rpb);
+      if (p.c_rpb) { const int bq = (int)fdiv(m, p.fd_rpb); mo = (int64_t)bq * p.c_bstride + (m - bq * p.c_rpb); }
       *reinterpret_cast<u32x4*>(cbase + mo * p.ldc) =
           u32x4{DT<T>::pack2(v0.x, v0.y), DT<T>::pack2(v0.z, v0.w), DT<T>::pack2(v1.x, v1.y), DT<T>::pack2(v1.z, v1.w)};
+    }
+  }
+}
+
+// 16-bit output, no residual, no LayerNorm: the LDS tile is already in the output type (stage_acc HALF): two 8-byte LDS
+// reads (rows are 8- but not 16-byte aligned) -> one 16-byte store.
+template <typename T, int BM, int BN, int NTHR>
+__device__ __forceinline__ void gemm_epilogue_half(const GemmParams& p, const float* Cs, int m0, int n0, int tid) {
+  constexpr int CPR = BN / 8, RSTEP = NTHR / CPR, NPASS = BM / RSTEP;
+  static_assert(BM % RSTEP == 0, "tile vs threads");
+  const int cc = tid % CPR, rr0 = tid / CPR;
+  const int n = n0 + cc * 8;
+  const bool col_ok = n < p.N;                       // N % 8 == 0 on this path (host-checked)
+  const unsigned char* ch = reinterpret_cast<const unsigned char*>(Cs);
+  T* cbase = static_cast<T*>(p.C) + n;
+#pragma unroll
+  for (int k = 0; k < NPASS; ++k) {
+    const int rr = rr0 + k * RSTEP, m = m0 + rr;
+    const u32x2 lo = *reinterpret_cast<const u32x2*>(ch + ((size_t)rr * (BN + 4) + cc * 8) * 2);
+    const u32x2 hi = *reinterpret_cast<const u32x2*>(ch + ((size_t)rr * (BN + 4) + cc * 8 + 4) * 2);
+    if (col_ok && m < p.M) {
+      int64_t mo = m;
+      if (p.c_rpb) { const int bq = (int)fdiv(m, p.fd_rpb); mo = (int64_t)bq * p.c_bstride + (m - bq * p.c_rpb); }
+      *reinterpret_cast<u32x4*>(cbase + mo * p.ldc) = u32x4{lo.x, lo.y, hi.x, hi.y};
     }
   }
 }
@@ -299,7 +353,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
     const int nb = p.nblocks, qd = nb >> 3, rm = nb & 7, x = bid & 7;
     bid = (x < rm ? x * (qd + 1) : rm * (qd + 1) + (x - rm) * qd) + (bid >> 3);
   }
-  const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+  const int tile_m = (int)fdiv(bid, p.fd_tiles_n), tile_n = bid - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const T* __restrict__ Ag = static_cast<const T*>(p.A);
@@ -328,7 +382,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
   if (KS == 1) {
     if (!p.a_rows) a_base = (int64_t)m0 * p.lda;
   } else {
-    b0 = m0 / (p.Hout * p.Wout);
+    b0 = (int)fdiv(m0, p.fd_hw);
     a_base = (int64_t)b0 * p.Hin * p.Win * p.lda;
   }
   const int64_t a_left = p.a_bytes - a_base * ESZ;
@@ -349,13 +403,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
     a_taps[j] = 0;
     if (m < p.M) {
       if (KS == 1) {
-        const bool masked = p.a_mask && p.a_mask[m % p.mask_period] == 0;
+        const bool masked = p.a_mask && p.a_mask[m - (int)fdiv(m, p.fd_mask) * p.mask_period] == 0;
         const int64_t row = p.a_rows ? (int64_t)p.a_rows[m] : (int64_t)(m - m0);
         if (!masked) a_voff[j] = (uint32_t)((row * p.lda + kc0) * ESZ);
       } else {
         const int hw = p.Hout * p.Wout;
-        const int b = m / hw, rem = m - b * hw;
-        const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+        const int b = (int)fdiv(m, p.fd_hw), rem = m - b * hw;
+        const int oy = (int)fdiv(rem, p.fd_wout), ox = rem - oy * p.Wout;
         const int iy0 = oy * p.stride - 1, ix0 = ox * p.stride - 1;
         a_voff[j] = (uint32_t)((((int64_t)(b - b0) * p.Hin + iy0) * p.Win + ix0) * p.lda * ESZ);   // may wrap below 0: fixed by the tap delta
         uint32_t msk = 0;
@@ -499,14 +553,24 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
     __syncthreads();
   }
 
-  // ---- epilogue: accumulators -> LDS fp32 tile [BM][BN+4]
+  // ---- epilogue: accumulators -> LDS tile [BM][BN+4] (fp32, or the output type when nothing else is added)
   float* Cs = reinterpret_cast<float*>(smem);
-  stage_acc<BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q);
-  __syncthreads();
-
   if constexpr (!LN && !std::is_same<T, float>::value) {
-    if (p.wide_store) { gemm_epilogue_bf16x8<T, BM, BN, NTHR>(p, Cs, m0, n0, tid); return; }
+    if (p.wide_store) {
+      if (!p.R) {
+        stage_acc<T, true, BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q);
+        __syncthreads();
+        gemm_epilogue_half<T, BM, BN, NTHR>(p, Cs, m0, n0, tid);
+      } else {
+        stage_acc<T, false, BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q);
+        __syncthreads();
+        gemm_epilogue_bf16x8<T, BM, BN, NTHR>(p, Cs, m0, n0, tid);
+      }
+      return;
+    }
   }
+  stage_acc<T, false, BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q);
+  __syncthreads();
   gemm_epilogue<T, BM, BN, LN, NTHR>(p, Cs, m0, n0, tid);
 }
 
@@ -530,6 +594,7 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   p.nblocks = tiles_m * p.tiles_n;
+  p.fd_tiles_n = make_fastdiv(p.tiles_n);
   constexpr int bk = 4 * DT<T>::KPB * PANELS;
   // prefetch distance 2 pays from three k-stages on and for tiles at least 64 columns wide (measured)
   if (BN >= 64 && p.Kpad / bk > 2) return launch_inst<T, BM, BN, WGM, WGN, LN, KS, 2>(p, st);
@@ -599,6 +664,8 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
   p.ln_g = a->ln_g; p.ln_b = a->ln_b; p.C = a->C; p.ldc = a->ldc; p.out_f32 = a->out_f32;
   if (a->c_rows_per_batch < 0 || (a->c_rows_per_batch > 0 && a->c_batch_stride < a->c_rows_per_batch)) return MOY_EINVAL;
   p.c_rpb = a->c_rows_per_batch; p.c_bstride = a->c_batch_stride;
+  p.fd_rpb = make_fastdiv(p.c_rpb);
+  p.fd_mask = make_fastdiv(a->mask_period > 0 ? a->mask_period : 1);
   if (a->dot_n < 0 || a->dot_n > 8) return MOY_EINVAL;
   if (a->dot_n && (!ln || !a->dot_w || !a->dot_b || !a->dot_out || !aligned16(a->dot_w))) return MOY_EINVAL;
   p.dot_w = a->dot_w; p.dot_b = a->dot_b; p.dot_out = a->dot_out; p.dot_n = a->dot_n;
@@ -615,6 +682,8 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
     if ((long)a->B * a->Hout * a->Wout != a->M) return MOY_EINVAL;
     p.Hin = a->Hin; p.Win = a->Win; p.Hout = a->Hout; p.Wout = a->Wout; p.Cin = C;
     p.cin_magic = (uint32_t)(((1ull << 32) + (unsigned)C - 1) / (unsigned)C);
+    p.fd_hw = make_fastdiv((uint32_t)(a->Hout * a->Wout));
+    p.fd_wout = make_fastdiv((uint32_t)a->Wout);
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   // Variants that were built and measured slower on every shape of this path (round 1, see DESIGN.md
