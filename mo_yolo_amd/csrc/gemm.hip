@@ -333,6 +333,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
   constexpr int BK = BKP * PANELS;     // elements per stage
   constexpr int TM = BM / WGM, TN = BN / WGN;
   constexpr int MT = TM / 16, NT = TN / 16;
+  // Panel 1 of each operand stores row R in the slot of row R ^ 1: the 8 lanes of one ds_write_b128 group are the two
+  // panels of ONE row (4 x 16 B each) and would otherwise fall on the same 16 of the 32 store banks (BM*64 B = 0 mod
+  // 128 B) -- every staging store was a 2-way conflict (SQ_LDS_BANK_CONFLICT = 29 % of SQ_LDS_IDX_ACTIVE,
+  // profiles/r01_e_pmc_gemm.txt).  The fragment reads stay conflict-free: ^1 permutes rows inside a quad.
+  // Not for the 128x64 tile: there the two extra address registers push hipcc from 77 to 90 VGPRs, past the 84 that
+  // three resident blocks need, and the kernel loses 12 % instead of gaining 5-8 % (same-device A/B, tools/ab_gemm.sh).
+  constexpr int SKEW = (BM == 128 && BN == 64) ? 0 : 1;
   constexpr int A_BYTES = BM * PANELS * 64, B_BYTES = BN * PANELS * 64;
   constexpr int NW = WGM * WGN, NTHR = 64 * NW;
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
@@ -467,12 +474,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
 #pragma unroll
     for (int j = 0; j < RA2; ++j) {
       const int row = srow + j * RPP;
-      *reinterpret_cast<u32x4*>(As + (spn * BM + row) * 64 + swz(row, sq) * 16) = areg[SET][j];
+      *reinterpret_cast<u32x4*>(As + (spn * BM + (row ^ (spn * SKEW))) * 64 + swz(row, sq) * 16) = areg[SET][j];
     }
 #pragma unroll
     for (int j = 0; j < RB2; ++j) {
       const int row = srow + j * RPP;
-      *reinterpret_cast<u32x4*>(Bs + (spn * BN + row) * 64 + swz(row, sq) * 16) = breg[SET][j];
+      *reinterpret_cast<u32x4*>(Bs + (spn * BN + (row ^ (spn * SKEW))) * 64 + swz(row, sq) * 16) = breg[SET][j];
     }
   };
 
@@ -491,12 +498,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int row = wm * TM + i * 16 + r;
-        af[i] = *reinterpret_cast<const u32x4*>(As + (pn * BM + row) * 64 + swz(row, q) * 16);
+        af[i] = *reinterpret_cast<const u32x4*>(As + (pn * BM + (row ^ (pn * SKEW))) * 64 + swz(row, q) * 16);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int row = wn * TN + j * 16 + r;
-        wf[j] = *reinterpret_cast<const u32x4*>(Bs + (pn * BN + row) * 64 + swz(row, q) * 16);
+        wf[j] = *reinterpret_cast<const u32x4*>(Bs + (pn * BN + (row ^ (pn * SKEW))) * 64 + swz(row, q) * 16);
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
