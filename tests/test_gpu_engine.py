@@ -205,6 +205,25 @@ def test_engine_graph_replay_matches_eager():
         assert torch.equal(a[k], b[k]), k
 
 
+def test_streamed_engines_equal_single_engine():
+    """Sub-batches on separate HIP streams + graphs (engine.StreamedEngines) give the frames' own results."""
+    from mo_yolo_amd.engine import StreamedEngines
+    cfg, arch, sd = fixture("tiny")
+    fr = torch.from_numpy(frames_u8(cfg, 0, 3)).to(DEV)
+    fr = torch.cat([fr, fr[:1]], 0)                                   # 4 frames -> 2 streams x 2
+    ref = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=4, dtype=torch.float32)
+    want = {k: v.clone() for k, v in ref.forward(fr).items()}
+    pipe = StreamedEngines(arch, sd, cfg["H"], cfg["W"], batch=4, streams=2, graph=True, dtype=torch.float32)
+    for _ in range(3):                                               # first call captures, later calls replay
+        pipe.forward(fr)
+    pipe.synchronize()
+    got = pipe.outputs()
+    assert torch.equal(got["obj_idxes"], want["obj_idxes"])
+    assert torch.equal(got["topk_ind"], want["topk_ind"])
+    assert torch.allclose(got["y"], want["y"], atol=1e-6)
+    assert torch.equal(got["n_rows"], want["n_rows"])
+
+
 def test_hota_parity_on_synthetic_stream():
     """BASELINE metric, HOTA half: HOTA of the build's tracks vs HOTA of the oracle's tracks on the
     same synthetic ground truth, with the reference evaluator's algorithm.  fp32: identical;
