@@ -220,6 +220,13 @@ int moy_msda_bwd_f64(const double* value, const int64_t* spatial_shapes, const i
 int moy_resize_linear_u8(const uint8_t* src, int B, int Hs, int Ws, int64_t src_row_bytes, int64_t src_img_bytes,
                          uint8_t* dst, int Hd, int Wd, void* stream);
 
+/* Pairwise IoU similarity of pixel x0y0x1y1 boxes for the HOTA evaluator: TrackValidator._calculate_box_ious
+ * (ultralytics/models/MOTRtrack/val.py:517-553, box_format 'x0y0x1y1') for T frames at once.
+ *   a fp32 [T, n, 4] (ground truth), b fp32 [T, K, 4] (tracker), padded; na / nb int32 [T] = valid rows per frame
+ *   (NULL: all n / K); out fp32 [T, n, K], zero beyond a frame's counts.  Degenerate boxes (area <= eps) give 0. */
+int moy_box_iou(const float* a, const float* b, int T, int n, int K, const int32_t* na, const int32_t* nb, float* out,
+                void* stream);
+
 /* Per-frame ID assignment + predictor rows.  Replaces the host state machine
  * MOTRTrack._post_process_single_image / RuntimeTrackerBase.update (head.py:300-323,1232-1237) in
  * its shipped per-frame-reset semantics and TrackPredictor.postprocess

@@ -50,6 +50,7 @@ SIGNATURES = {
     "moy_msda_bwd_f32": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp, vp, vp, vp]),
     "moy_msda_bwd_f64": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp, vp, vp, vp]),
     "moy_resize_linear_u8": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, i64, vp, C.c_int, C.c_int, vp]),
+    "moy_box_iou": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "moy_assign_post": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, f32, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "moy_track_state_update": (C.c_int, [vp, vp, vp, vp, i64, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, C.c_int, vp]),
     "moy_fsqm_reset": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, vp]),

@@ -718,6 +718,34 @@ __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __
   o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pairwise IoU of pixel x0y0x1y1 boxes, the similarity the validator feeds to HOTA
+// (TrackValidator._calculate_box_ious, models/MOTRtrack/val.py:517-553, box_format 'x0y0x1y1', do_ioa False):
+// intersection zeroed where either area or the union is <= eps, union forced to 1 there.  T frames padded to
+// [T, n, 4] x [T, K, 4] with optional per-frame counts; pairs beyond a frame's counts are written as 0.
+__global__ __launch_bounds__(256) void box_iou_kernel(const float* __restrict__ a, const float* __restrict__ b, int T, int n, int K,
+                                                      const int32_t* __restrict__ na, const int32_t* __restrict__ nb,
+                                                      float* __restrict__ out) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)T * n * K) return;
+  const int j = (int)(t % K);
+  const int i = (int)((t / K) % n);
+  const int f = (int)(t / ((long)K * n));
+  float r = 0.f;
+  if (i < (na ? na[f] : n) && j < (nb ? nb[f] : K)) {
+    const f32x4 p = *reinterpret_cast<const f32x4*>(a + ((long)f * n + i) * 4);
+    const f32x4 q = *reinterpret_cast<const f32x4*>(b + ((long)f * K + j) * 4);
+    constexpr float EPS = 2.220446049250313e-16f;      // np.finfo('float').eps as the reference compares it
+    float inter = fmaxf(fminf(p.z, q.z) - fmaxf(p.x, q.x), 0.f) * fmaxf(fminf(p.w, q.w) - fmaxf(p.y, q.y), 0.f);
+    const float a1 = (p.z - p.x) * (p.w - p.y), a2 = (q.z - q.x) * (q.w - q.y);
+    float uni = a1 + a2 - inter;
+    if (a1 <= EPS || a2 <= EPS || uni <= EPS) inter = 0.f;
+    if (uni <= EPS) uni = 1.f;
+    r = inter / uni;
+  }
+  out[t] = r;
+}
+
 // Generic operator form (reference plugin API): one thread per output scalar, d fastest.
 template <typename T>
 __global__ __launch_bounds__(256) void msda_generic_kernel(const T* __restrict__ value, const int64_t* __restrict__ shapes,
@@ -1440,6 +1468,15 @@ extern "C" int moy_resize_linear_u8(const uint8_t* src, int B, int Hs, int Ws, i
   const long total = (long)B * Hd * (Wd >> 2);
   hipLaunchKernelGGL(resize_linear_u8_kernel, dim3(nblk(total)), dim3(256), 0, static_cast<hipStream_t>(stream), src, B, Hs, Ws,
                      (long)src_row_bytes, (long)src_img_bytes, dst, Hd, Wd, scale_x, scale_y, area2);
+  return launch_status();
+}
+
+extern "C" int moy_box_iou(const float* a, const float* b, int T, int n, int K, const int32_t* na, const int32_t* nb, float* out,
+                           void* stream) {
+  if (!a || !b || !out || T <= 0 || n <= 0 || K <= 0) return MOY_EINVAL;
+  if (!aligned16(a) || !aligned16(b)) return MOY_EINVAL;
+  hipLaunchKernelGGL(box_iou_kernel, dim3(nblk((long)T * n * K)), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, T, n, K, na, nb,
+                     out);
   return launch_status();
 }
 

@@ -254,6 +254,20 @@ def resize_linear_u8(frames, out_hw, out=None):
     return out
 
 
+def box_iou(a, b, na=None, nb=None):
+    """a fp32 [T, n, 4], b fp32 [T, K, 4] pixel x0y0x1y1 -> IoU fp32 [T, n, K] (val.py:517-553); na / nb int32 [T]."""
+    _need_gpu(a, b)
+    T, n, _ = a.shape
+    K = b.shape[1]
+    out = torch.empty(T, n, K, device=a.device, dtype=torch.float32)
+    if n == 0 or K == 0:
+        return out
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous()
+    L.check(L.lib().moy_box_iou(a.data_ptr(), b.data_ptr(), T, n, K, na.data_ptr() if na is not None else None,
+                                nb.data_ptr() if nb is not None else None, out.data_ptr(), _st()), "moy_box_iou")
+    return out
+
+
 def assign_post(logits, boxes, score_thresh=0.4, conf=0.25, img_wh=(1.0, 1.0)):
     _need_gpu(logits, boxes)
     B, nq, nc = logits.shape

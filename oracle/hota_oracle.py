@@ -89,22 +89,26 @@ def eval_sequence(gt_ids, tracker_ids, sims, num_gt_ids, num_tracker_ids):
         if K == 0:
             res["HOTA_FN"] += n
             continue
-        score = np.squeeze(align[g2[:, None], 0:K]) * sim
-        if score.ndim != 2:
-            score = score.reshape(n, K)
-        rows, cols = linear_sum_assignment(-score)
-        for a, alpha in enumerate(ALPHAS):
-            ok = sim[rows, cols] >= alpha - EPS
-            r_, c_ = rows[ok], cols[ok]
-            m = len(r_)
+        score = np.squeeze(align[g2[:, None], 0:K]) * sim          # hota.py:118-119: squeeze drops every unit axis
+        try:                                                       # hota.py:122-131
+            rows, cols = linear_sum_assignment(-score)
+        except ValueError:
+            score = np.squeeze(score)
             try:
-                if m > 0:
-                    loc = float(np.sum(sim[r_, c_]))
-                    matches[a][g2[r_], tr[c_]] += 1
-                    res["LocA"][a] += loc
+                rows, cols = linear_sum_assignment(-score)
+            except ValueError:
+                rows, cols = linear_sum_assignment(-score[0, :, :])
+        for a, alpha in enumerate(ALPHAS):
+            try:                                                   # statement order of hota.py:134-149
+                ok = sim[rows, cols] >= alpha - EPS
+                r_, c_ = rows[ok], cols[ok]
+                m = len(r_)
                 res["HOTA_TP"][a] += m
                 res["HOTA_FN"][a] += n - m
                 res["HOTA_FP"][a] += K - m
+                if m > 0:
+                    res["LocA"][a] += sum(sim[r_, c_])
+                    matches[a][g2[r_], tr[c_]] += 1
             except IndexError:
                 res["HOTA_FN"][a] += n
                 res["HOTA_FP"][a] += K
@@ -116,3 +120,17 @@ def eval_sequence(gt_ids, tracker_ids, sims, num_gt_ids, num_tracker_ids):
         res["AssPr"][a] = np.sum(mc * (mc / np.maximum(1, t_cnt))) / tp
     res["LocA"] = np.maximum(1e-10, res["LocA"]) / np.maximum(1e-10, res["HOTA_TP"])
     return _final_fields(res)
+
+
+def box_ious_xyxy(b1, b2):
+    """`TrackValidator._calculate_box_ious(..., box_format='x0y0x1y1')`, models/MOTRtrack/val.py:517-553."""
+    b1 = np.asarray(b1, dtype=np.float32).reshape(-1, 4); b2 = np.asarray(b2, dtype=np.float32).reshape(-1, 4)
+    mn = np.minimum(b1[:, None, :], b2[None, :, :]); mx = np.maximum(b1[:, None, :], b2[None, :, :])
+    inter = np.maximum(mn[..., 2] - mx[..., 0], 0) * np.maximum(mn[..., 3] - mx[..., 1], 0)
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1]); a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    union = a1[:, None] + a2[None, :] - inter
+    inter[a1 <= EPS, :] = 0
+    inter[:, a2 <= EPS] = 0
+    inter[union <= EPS] = 0
+    union[union <= EPS] = 1
+    return inter / union

@@ -437,7 +437,9 @@ def dump_hota():
     ref_shim.install()
     from ultralytics.utils.hota import HOTA
     out = {}
-    for case, (nobj, T, noise, drop) in {"easy": (5, 6, 2.0, 0.0), "hard": (12, 20, 6.0, 0.15)}.items():
+    # "sparse": frames with one or no tracker row (the K == 1 / n == 1 branches of the patched evaluator)
+    for case, (nobj, T, noise, drop) in {"easy": (5, 6, 2.0, 0.0), "hard": (12, 20, 6.0, 0.15), "sparse": (2, 10, 3.0, 0.5),
+                                         "single": (1, 5, 2.0, 0.2)}.items():
         rng = np.random.Generator(np.random.PCG64(42 + nobj))
         seq = SyntheticSequence(3, 608, 1088, "mot17", n_obj=nobj)
         gt_ids, tr_ids, sims, gtb, trb = [], [], [], [], []

@@ -1,5 +1,7 @@
 """GPU parity of the drop-in module surface (mo_yolo_amd.modules / predictor) against the oracle
 and the reference goldens: these tests read like the reference's own module calls."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -170,6 +172,62 @@ def test_predictor_stretch_resizes_foreign_frame_sizes():
             assert np.array_equal(r.track_id, w.track_id)
             assert np.allclose([[float(v) for v in l.split()] for l in r.txt_lines()],
                                [[float(v) for v in l.split()] for l in w.txt_lines()], atol=1e-5)
+
+
+def test_box_iou_vs_validator_formula():
+    """moy_box_iou vs `_calculate_box_ious` (val.py:517-553) incl. degenerate boxes, ragged frames and empty sides."""
+    from mo_yolo_amd import ops
+    from mo_yolo_amd.evaluate import similarity_scores
+    from oracle import hota_oracle as H
+    rng = np.random.default_rng(0)
+    gtb, trb = [], []
+    for t, (n, k) in enumerate([(5, 7), (1, 1), (0, 3), (4, 0), (9, 2), (3, 3)]):
+        a = rng.uniform(0, 900, (n, 2)); b = rng.uniform(0, 900, (k, 2))
+        ga = np.concatenate([a, a + rng.uniform(5, 300, (n, 2))], 1).astype(np.float32)
+        tb = np.concatenate([b, b + rng.uniform(5, 300, (k, 2))], 1).astype(np.float32)
+        if n > 2:
+            ga[1, 2:] = ga[1, :2]                                        # zero-area ground-truth box
+            tb[:1] = ga[:1] if k else tb[:1]                             # an exact overlap
+        gtb.append(ga); trb.append(tb)
+    got = similarity_scores(gtb, trb)
+    for t in range(len(gtb)):
+        want = H.box_ious_xyxy(gtb[t], trb[t])
+        assert got[t].shape == want.shape
+        assert np.allclose(got[t], want, atol=1e-6), t
+    full = ops.box_iou(torch.from_numpy(gtb[0])[None].to(DEV), torch.from_numpy(trb[0])[None].to(DEV))   # no counts
+    assert np.allclose(full[0].cpu().numpy(), H.box_ious_xyxy(gtb[0], trb[0]), atol=1e-6)
+
+
+def test_track_validator_hota_vs_oracle_pipeline():
+    """TrackValidator (val.py:185-507 counterpart) on two synthetic sequences: device IoU + product HOTA == the oracle's
+    restatement of the reference evaluator fed with the same predictor rows; MOT txt is written per sequence."""
+    import tempfile
+    from mo_yolo_amd.evaluate import TrackValidator
+    from mo_yolo_amd.synth import SyntheticSequence
+    from oracle import hota_oracle as H
+    from tests._util import hota_of_tracks
+    cfg, arch, sd = fixture("tiny")
+    pred = TrackPredictor(arch, sd, imgsz=(cfg["H"], cfg["W"]), conf=0.25, batch=2)
+    T = 5
+    seqs = []
+    for sid in (0, 1):
+        seq = SyntheticSequence(sid, cfg["H"], cfg["W"], cfg["style"])
+        gts = [seq.boxes(t) for t in range(T)]
+        seqs.append(dict(name=f"seq{sid}", frames=seq.frames(0, T), gt_boxes=[g[0] for g in gts], gt_ids=[g[1] for g in gts]))
+    with tempfile.TemporaryDirectory() as d:
+        res = TrackValidator(pred, save_dir=d)(seqs)
+        assert set(res) == {"seq0", "seq1", "COMBINED"}
+        for sid in (0, 1):
+            rows, ids = [], []
+            for r in pred(seqs[sid]["frames"]):
+                k = 0 if r.track_id is None else min(len(r.track_id), len(r.boxes))
+                rows.append(r.boxes[:k, :4]); ids.append(np.asarray(r.track_id[:k] if k else [], np.int64))
+            want = hota_of_tracks(cfg, rows, ids, seq_id=sid)
+            for key in ("HOTA", "DetA", "AssA", "LocA", "HOTA_TP", "HOTA_FN", "HOTA_FP"):
+                assert np.allclose(res[f"seq{sid}"][key], want[key], atol=1e-6), (sid, key)
+            if any(len(i) for i in ids):
+                assert os.path.getsize(os.path.join(d, f"seq{sid}.txt")) > 0
+        assert np.allclose(res["COMBINED"]["HOTA_TP"], res["seq0"]["HOTA_TP"] + res["seq1"]["HOTA_TP"])
 
 
 def test_batched_frames_equal_single_frames():

@@ -92,3 +92,49 @@ def test_sharding_two_process_gloo(tmp_path):
     d = json.loads(outs[0][0].decode().strip().splitlines()[-1])
     assert d["dt"] == 2.0 and d["fps"] == 100.0                 # MAX over ranks; whole-job aggregate
     assert d["res"][0]["seqs"] == [0, 2, 4, 6] and d["res"][1]["seqs"] == [1, 3, 5, 7]
+
+
+def _hota_case(g, case):
+    T = int(g[f"{case}.T"])
+    return {"num_timesteps": T, "num_gt_ids": int(g[f"{case}.num_gt_ids"]), "num_tracker_ids": int(g[f"{case}.num_tracker_ids"]),
+            "gt_ids": [g[f"{case}.gt_ids.{t}"] for t in range(T)], "tracker_ids": [g[f"{case}.tracker_ids.{t}"] for t in range(T)],
+            "similarity_scores": [g[f"{case}.sim.{t}"] for t in range(T)]}
+
+
+def test_product_hota_compat_vs_reference_evaluator():
+    """mo_yolo_amd.evaluate.HOTA(compat=True) against outputs of the reference's own evaluator (tests/golden/hota.npz,
+    utils/hota.py:24-164), same `eval_sequence(data)` dictionary; the caller's id arrays are left untouched."""
+    from mo_yolo_amd.evaluate import HOTA
+    g = golden("hota")
+    for case in ("easy", "hard", "sparse", "single"):
+        data = _hota_case(g, case)
+        before = [t.copy() for t in data["tracker_ids"]]
+        r = HOTA().eval_sequence(data)
+        for k in HOTA.float_array_fields + HOTA.integer_array_fields:
+            assert np.allclose(r[k], g[f"{case}.res.{k}"], atol=1e-7), (case, k)
+        for k in HOTA.float_fields:
+            assert np.isclose(r[k], float(g[f"{case}.res.{k}"]), atol=1e-7), (case, k)
+        assert all(np.array_equal(a, b) for a, b in zip(before, data["tracker_ids"]))
+
+
+def test_product_hota_standard_definition_properties():
+    """HOTA(compat=False), the published definition: perfect tracks score 1 at every alpha, relabelling tracker ids is
+    neutral, an id switch lowers AssA but not DetA, and combine_sequences weights by TP (hota.py:166-176)."""
+    from mo_yolo_amd.evaluate import HOTA, build_hota_data
+    T, n = 12, 4
+    gt = [np.arange(n) for _ in range(T)]
+    eye = [np.eye(n) for _ in range(T)]
+    h = HOTA(compat=False)
+    perfect = h.eval_sequence(build_hota_data(gt, gt, eye))
+    assert np.allclose(perfect["HOTA"], 1) and np.allclose(perfect["AssA"], 1) and np.allclose(perfect["DetA"], 1)
+    relabelled = h.eval_sequence(build_hota_data(gt, [np.array([7, 3, 11, 5])[g] for g in gt], eye))
+    assert np.allclose(relabelled["HOTA"], 1)
+    switched = [g.copy() for g in gt]
+    for t in range(T // 2, T):
+        switched[t][[0, 1]] = switched[t][[1, 0]]                   # tracks 0 and 1 swap identities half-way
+    sw = h.eval_sequence(build_hota_data(gt, switched, eye))
+    assert np.allclose(sw["DetA"], 1) and np.allclose(sw["AssA"], 2 / 3)   # half the TPs: 6 / (12 + 12 - 6)
+    comb = h.combine_sequences({"a": perfect, "b": sw})
+    assert np.allclose(comb["HOTA_TP"], 2 * T * n) and np.allclose(comb["AssA"], (1 + 2 / 3) / 2)
+    empty = h.eval_sequence(build_hota_data(gt, [np.zeros(0, np.int64)] * T, [np.zeros((n, 0))] * T))
+    assert np.allclose(empty["HOTA_FN"], T * n) and empty["HOTA(0)"] == 0

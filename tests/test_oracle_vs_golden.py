@@ -144,7 +144,7 @@ def test_hota_restatement_vs_reference_evaluator():
     validator's input layout, incl. the evaluator's in-place id shifting."""
     from oracle import hota_oracle as H
     g = golden("hota")
-    for case in ("easy", "hard"):
+    for case in ("easy", "hard", "sparse", "single"):      # sparse / single: the K == 1, K == 0 and n == 1 branches
         T = int(g[f"{case}.T"])
         r = H.eval_sequence([g[f"{case}.gt_ids.{t}"] for t in range(T)], [g[f"{case}.tracker_ids.{t}"] for t in range(T)],
                             [g[f"{case}.sim.{t}"] for t in range(T)], int(g[f"{case}.num_gt_ids"]), int(g[f"{case}.num_tracker_ids"]))
