@@ -166,6 +166,12 @@ int moy_pos2posemb(const float* pos, int M, void* out, int64_t ldo, int dtype, v
 int moy_mha_core(const void* qkv, int64_t ld_qkv, int B, int L, int nh, int E, void* out, int64_t ldo, int dtype,
                  void* stream);
 
+/* moy_mha_core with the key mask of the temporal mode: key j of sequence b takes part iff j < n_prefix[b]
+ * (live track slots) or j >= split (this frame's detect queries); n_prefix int32 [B] in device memory.  A query
+ * with no live key gets an all-zero output. */
+int moy_mha_core_masked(const void* qkv, int64_t ld_qkv, int B, int L, int nh, int E, const int32_t* n_prefix, int split,
+                        void* out, int64_t ldo, int dtype, void* stream);
+
 /* Fused deformable-attention sampling for the decoder (MSDeformAttn.forward transformer.py:267-285
  * after the three projections): softmax over the L*P attention logits, sampling locations
  * loc = ref_xy + off / P * ref_wh * 0.5, bilinear gather (zeros padding, align_corners=False),
@@ -176,6 +182,38 @@ int moy_mha_core(const void* qkv, int64_t ld_qkv, int B, int L, int nh, int E, v
  *   out T [B*Lq, ldo]. */
 int moy_msda_fused(const void* value, int64_t ldv, int B, int S, const int32_t* shapes_hw, int L, const float* offaw,
                    int64_t ld_oa, const float* ref, int Lq, void* out, int64_t ldo, int dtype, void* stream);
+
+/* ---- Temporal mode: carried track queries in a fixed-size query memory per sequence.
+ * The shipped snapshot resets its state every frame and its carried branch crashes, so these entry points
+ * follow the branch's visible intent (nn/modules/head.py:206-221, 1055-1064: decoder rows = [track queries | top-k detect
+ * queries]) and upstream MOTR (MOTR/models/motr.py:303-325, 545-577; QIM MOTR/models/qim.py:251-301); spec: DESIGN.md §7.
+ * Memory of sequence b: trk_embed / trk_qpos T [B, n_max, 256], trk_ref fp32 [B, n_max, 4] (logits), trk_id int64
+ * [B, n_max], trk_dis int32 [B, n_max], n_trk int32 [B] (live slots are the first n_trk[b]), max_obj_id int64 [B]. */
+
+/* Decoder input of a frame: rows [b*(n_max+nq) + i] = track slot i (zeros if dead) for i < n_max, detect query i - n_max
+ * otherwise.  det_* are the dense [B*nq] buffers of the per-frame path; ref_sig = sigmoid(ref_logit). */
+int moy_temporal_assemble(const void* trk_embed, const void* trk_qpos, const float* trk_ref, const int32_t* n_trk,
+                          const void* det_embed, int64_t ld_de, const void* det_qpos, int64_t ld_dq, const float* det_ref,
+                          int B, int n_max, int nq, void* embed, int64_t ld_e, void* qpos, int64_t ld_q, float* ref_logit,
+                          float* ref_sig, int dtype, void* stream);
+
+/* ID lifecycle of one frame (RuntimeTrackerBase.update loop, nn/modules/head.py:1232-1243, on carried state; thresholds
+ * head.py:1146: birth 0.4, miss below 0.5, dropped after 5 misses, counters never reset) + compaction of the surviving and
+ * newborn rows into memory slots (query order) + predictor rows (predict.py:43-94).
+ *   logits fp32 [B, Lq, nc], boxes fp32 [B, Lq, 4] with Lq = n_max + nq <= 1024; max_obj_id is read and advanced by the births.
+ *   Out: y [B, Lq, 4+nc], scores [B, Lq], obj_idxes int64 [B, Lq] (-1: no id / dead slot), dis_out int32 [B, Lq],
+ *   sel_rows int32 [B, n_max] (global decoder row feeding slot s; dead slots point at a finite dummy row), n_new [B],
+ *   n_overflow [B] (live rows that did not fit), rows [B, Lq, 6], track_id int64 [B, Lq], n_rows / n_ids [B] as moy_assign_post. */
+int moy_temporal_assign(const float* logits, const float* boxes, int B, int n_max, int nq, int nc, const int64_t* trk_id,
+                        const int32_t* trk_dis, const int32_t* n_trk, int64_t* max_obj_id, float score_thresh,
+                        float filter_thresh, int miss_tol, float conf, float img_w, float img_h, float* y, float* scores,
+                        int64_t* obj_idxes, int32_t* dis_out, int32_t* sel_rows, int32_t* n_new, int32_t* n_overflow,
+                        float* rows, int64_t* track_id, int32_t* n_rows, int32_t* n_ids, void* stream);
+
+/* Commit ids, miss counters and reference boxes (inverse_sigmoid(pred_boxes), qim.py:299) of the selected rows; n_trk = n_new. */
+int moy_temporal_commit(const int32_t* sel_rows, const int32_t* n_new, const int64_t* obj_idxes, const int32_t* dis_out,
+                        const float* boxes, int B, int n_max, int64_t* trk_id, int32_t* trk_dis, float* trk_ref,
+                        int32_t* n_trk, void* stream);
 
 /* The reference's own native operator, MultiScaleDeformableAttention.ms_deform_attn_forward
  * (MOTR/models/ops/src/vision.cpp:13-16, src/ms_deform_attn.h:21-40, CUDA kernel

@@ -43,6 +43,12 @@ SIGNATURES = {
     "moy_topk": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "moy_pos2posemb": (C.c_int, [vp, C.c_int, vp, i64, C.c_int, vp]),
     "moy_mha_core": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
+    "moy_mha_core_masked": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, i64, C.c_int, vp]),
+    "moy_temporal_assemble": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, i64, vp, C.c_int, C.c_int, C.c_int, vp, i64, vp, i64, vp, vp,
+                                        C.c_int, vp]),
+    "moy_temporal_assign": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, f32, f32, C.c_int, f32, f32, f32,
+                                      vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "moy_temporal_commit": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "moy_msda_fused": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, C.c_int, vp, i64, vp, C.c_int, vp, i64, C.c_int, vp]),
     "moy_msda_fwd_f32": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp, vp]),
     "moy_msda_fwd_bf16": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp, vp]),

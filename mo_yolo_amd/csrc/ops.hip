@@ -451,7 +451,8 @@ __device__ __forceinline__ void mma16<float>(f32x4& acc, u32x4 afrag, u32x4 bfra
 
 template <typename T, int NKT>   // NKT (even): max 16-key tiles, compile-time bound of the score registers
 __global__ __launch_bounds__(256) void mha_kernel(const T* __restrict__ qkv, int64_t ld, int L, int nh, int E,
-                                                  T* __restrict__ out, int64_t ldo, int tiles_per_block) {
+                                                  T* __restrict__ out, int64_t ldo, int tiles_per_block,
+                                                  const int32_t* __restrict__ n_prefix, int split) {
   constexpr int KPB = DT<T>::KPB;
   constexpr int NPD = 32 / (4 * KPB);             // 64-B panels per K row: bf16 1, f32 2
   constexpr int ESZ = 16 / KPB;
@@ -465,6 +466,8 @@ __global__ __launch_bounds__(256) void mha_kernel(const T* __restrict__ qkv, int
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q4 = lane >> 4;
   const T* base = qkv + (long)b * L * ld;
+  // key mask of the temporal mode: key j takes part iff j < n_prefix[b] (live track slots) or j >= split (detect queries)
+  const int npre = n_prefix ? n_prefix[b] : L;
   // ---- stage K (zero padded) and V^T
   constexpr int CPK = 4 * NPD;                    // 16-B chunks per key row
   for (int i = tid; i < Lp * CPK; i += 256) {
@@ -517,14 +520,16 @@ __global__ __launch_bounds__(256) void mha_kernel(const T* __restrict__ qkv, int
         }
         const int k0 = kt * 16 + q4 * 4;
         acc = acc * scaling;
-        acc.x = k0 + 0 < L ? acc.x : -INFINITY; acc.y = k0 + 1 < L ? acc.y : -INFINITY;
-        acc.z = k0 + 2 < L ? acc.z : -INFINITY; acc.w = k0 + 3 < L ? acc.w : -INFINITY;
+        auto live = [&](int j) { return j < L && (j < npre || j >= split); };
+        acc.x = live(k0 + 0) ? acc.x : -INFINITY; acc.y = live(k0 + 1) ? acc.y : -INFINITY;
+        acc.z = live(k0 + 2) ? acc.z : -INFINITY; acc.w = live(k0 + 3) ? acc.w : -INFINITY;
         s[kt] = acc;
         mx = fmaxf(mx, fmaxf(fmaxf(acc.x, acc.y), fmaxf(acc.z, acc.w)));
       }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (mx == -INFINITY) mx = 0.f;                  // no live key (empty track memory): all weights 0, output 0
     float sum = 0.f;
     constexpr float L2E = 1.4426950408889634f;
 #pragma unroll
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(256) void mha_kernel(const T* __restrict__ qkv, int
         }
     }
     if (query < L) {
-      const float inv = 1.0f / sum;
+      const float inv = sum > 0.f ? 1.0f / sum : 0.f;
       T* op = out + ((long)b * L + query) * ldo + h * 32 + q4 * 4;
       DT<T>::store4(op, o[0] * inv);
       DT<T>::store4(op + 16, o[1] * inv);
@@ -916,6 +921,156 @@ __global__ __launch_bounds__(1024) void assign_post_kernel(const float* __restri
   if (i == 0) { n_rows[b] = nkeep; n_ids[b] = K > 0 ? K : -1; }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Temporal mode (spec in DESIGN.md §7): every sequence b owns a fixed-size query memory of NMAX track
+// slots in HBM (content embedding, position embedding, reference box, id, miss counter; the first n_trk[b] slots are live).
+// A frame's decoder runs on Lq = NMAX + nq rows per sequence: [track slots | this frame's detect queries], the order of
+// MYDecoder._get_decoder_input's concatenations (nn/modules/head.py:1055-1064).
+template <typename T>
+__global__ __launch_bounds__(256) void temporal_assemble_kernel(const T* __restrict__ trk_embed, const T* __restrict__ trk_qpos,
+                                                                const float* __restrict__ trk_ref, const int32_t* __restrict__ n_trk,
+                                                                const T* __restrict__ det_embed, int64_t ld_de,
+                                                                const T* __restrict__ det_qpos, int64_t ld_dq,
+                                                                const float* __restrict__ det_ref, int B, int NMAX, int nq,
+                                                                T* __restrict__ embed, int64_t ld_e, T* __restrict__ qpos, int64_t ld_q,
+                                                                float* __restrict__ ref_logit, float* __restrict__ ref_sig) {
+  constexpr int KPB = DT<T>::KPB, CH = 256 / KPB;        // 16-B chunks per 256-wide row
+  const int Lq = NMAX + nq;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)B * Lq * CH) return;
+  const int c = (int)(t % CH) * KPB;
+  const long row = t / CH;
+  const int b = (int)(row / Lq), i = (int)(row % Lq);
+  u32x4 e = {0u, 0u, 0u, 0u}, qp = e;
+  f32x4 rl = {0.f, 0.f, 0.f, 0.f};
+  if (i < NMAX) {
+    if (i < n_trk[b]) {                                  // dead slots stay zero: finite keys / values for the masked rows
+      const long sr = (long)b * NMAX + i;
+      e = *reinterpret_cast<const u32x4*>(trk_embed + sr * 256 + c);
+      qp = *reinterpret_cast<const u32x4*>(trk_qpos + sr * 256 + c);
+      rl = *reinterpret_cast<const f32x4*>(trk_ref + sr * 4);
+    }
+  } else {
+    const long dr = (long)b * nq + (i - NMAX);
+    e = *reinterpret_cast<const u32x4*>(det_embed + dr * ld_de + c);
+    qp = *reinterpret_cast<const u32x4*>(det_qpos + dr * ld_dq + c);
+    rl = *reinterpret_cast<const f32x4*>(det_ref + dr * 4);
+  }
+  *reinterpret_cast<u32x4*>(embed + row * ld_e + c) = e;
+  *reinterpret_cast<u32x4*>(qpos + row * ld_q + c) = qp;
+  if (c == 0) {
+    *reinterpret_cast<f32x4*>(ref_logit + row * 4) = rl;
+    *reinterpret_cast<f32x4*>(ref_sig + row * 4) = f32x4{sigmoidf_(rl.x), sigmoidf_(rl.y), sigmoidf_(rl.z), sigmoidf_(rl.w)};
+  }
+}
+
+// ID lifecycle of one frame, one block per sequence: RuntimeTrackerBase.update's loop (nn/modules/head.py:1232-1243) on the
+// rows in query order with CARRIED ids / miss counters -- birth: id == -1 and score >= score_thresh -> next id of the
+// sequence; miss: id >= 0 and score < filter_thresh -> counter + 1, dropped at miss_tol (no reset of the counter, as
+// shipped) -- then the compaction of the surviving + newborn rows into the memory slots (stable, query order) and the
+// predictor rows of TrackPredictor.postprocess (predict.py:43-94).  The id counter only moves at births (upstream
+// MOTR/models/motr.py:303-325); the shipped re-derivation of max_obj_id from a filtered copy (head.py:1278-1281) can hand
+// out an id twice and is deliberately not reproduced.
+__global__ __launch_bounds__(1024) void temporal_assign_kernel(const float* __restrict__ logits, const float* __restrict__ boxes, int NMAX,
+                                                               int nq, int nc, const int64_t* __restrict__ trk_id,
+                                                               const int32_t* __restrict__ trk_dis, const int32_t* __restrict__ n_trk,
+                                                               int64_t* __restrict__ max_obj_id, float score_thresh, float filter_thresh,
+                                                               int miss_tol, float conf, float img_w, float img_h, float* __restrict__ y,
+                                                               float* __restrict__ scores, int64_t* __restrict__ obj_idxes,
+                                                               int32_t* __restrict__ dis_out, int32_t* __restrict__ sel_rows,
+                                                               int32_t* __restrict__ n_new, int32_t* __restrict__ n_overflow,
+                                                               float* __restrict__ rows, int64_t* __restrict__ track_id,
+                                                               int32_t* __restrict__ n_rows, int32_t* __restrict__ n_ids) {
+  __shared__ int wsum[16];
+  const int b = blockIdx.x, i = threadIdx.x;
+  const int Lq = NMAX + nq;
+  const bool in = i < Lq;
+  const int nt = n_trk[b];
+  const bool valid = in && (i < nt || i >= NMAX);
+  float score = 0.f, cx = 0.f, cy = 0.f, w = 0.f, h = 0.f;
+  int cls = 0;
+  if (in) {
+    const float* lg = logits + ((long)b * Lq + i) * nc;
+    const float* bx = boxes + ((long)b * Lq + i) * 4;
+    float* yr = y + ((long)b * Lq + i) * (4 + nc);
+    cx = bx[0]; cy = bx[1]; w = bx[2]; h = bx[3];
+    yr[0] = cx; yr[1] = cy; yr[2] = w; yr[3] = h;
+    float best_l = -INFINITY;
+    score = -INFINITY;
+    for (int c = 0; c < nc; ++c) {
+      const float pr = sigmoidf_(lg[c]);
+      yr[4 + c] = pr;
+      score = fmaxf(score, pr);
+      if (lg[c] > best_l) { best_l = lg[c]; cls = c; }
+    }
+    scores[(long)b * Lq + i] = score;
+  }
+  int64_t id = -1;
+  int dis = 0;
+  if (valid && i < NMAX) { id = trk_id[(long)b * NMAX + i]; dis = trk_dis[(long)b * NMAX + i]; }
+  const int born = valid && id == -1 && score >= score_thresh;
+  int nborn;
+  const int rank = block_excl_scan(born, wsum, i, 1024, &nborn);
+  const int64_t base_id = max_obj_id[b];
+  if (born) {
+    id = base_id + rank;
+  } else if (valid && id >= 0 && score < filter_thresh) {
+    dis += 1;
+    if (dis >= miss_tol) id = -1;
+  }
+  __syncthreads();                                        // every thread has read max_obj_id[b]
+  if (i == 0) max_obj_id[b] = base_id + nborn;
+  const int active = valid && id >= 0;
+  if (in) { obj_idxes[(long)b * Lq + i] = id; dis_out[(long)b * Lq + i] = dis; }
+  int K;
+  const int slot = block_excl_scan(active, wsum, i, 1024, &K);
+  // memory slots of the next frame: live rows in query order; empty slots point at the first detect row (always finite)
+  if (active && slot < NMAX) sel_rows[(long)b * NMAX + slot] = b * Lq + i;
+  if (i < NMAX && i >= min(K, NMAX)) sel_rows[(long)b * NMAX + i] = b * Lq + NMAX;
+  // predictor rows: active branch if K > 0 else detection fallback over the frame's rows (predict.py:43-94)
+  const bool cand = K > 0 ? active : valid;
+  const int keep = cand && score > conf;
+  int nkeep;
+  const int pos = block_excl_scan(keep, wsum, i, 1024, &nkeep);
+  if (keep) {
+    float* r = rows + ((long)b * Lq + pos) * 6;
+    r[0] = (cx - w / 2) * img_w; r[1] = (cy - h / 2) * img_h;
+    r[2] = (cx + w / 2) * img_w; r[3] = (cy + h / 2) * img_h;
+    r[4] = score; r[5] = (float)cls;
+  }
+  if (active) track_id[(long)b * Lq + slot] = id;
+  if (i == 0) {
+    n_new[b] = min(K, NMAX);
+    n_overflow[b] = max(K - NMAX, 0);
+    n_rows[b] = nkeep;
+    n_ids[b] = K > 0 ? K : -1;
+  }
+}
+
+// Commit of a frame into the query memory: ids, miss counters, reference boxes (QIM: ref_pts = inverse_sigmoid(pred_boxes),
+// MOTR/models/qim.py:299, eps 1e-5 of MOTR/util/misc.py:532-536) of the selected rows; n_trk = n_new.
+__global__ __launch_bounds__(256) void temporal_commit_kernel(const int32_t* __restrict__ sel_rows, const int32_t* __restrict__ n_new,
+                                                              const int64_t* __restrict__ obj_idxes, const int32_t* __restrict__ dis_out,
+                                                              const float* __restrict__ boxes, int B, int NMAX,
+                                                              int64_t* __restrict__ trk_id, int32_t* __restrict__ trk_dis,
+                                                              float* __restrict__ trk_ref, int32_t* __restrict__ n_trk) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= B * NMAX) return;
+  const int b = t / NMAX, s = t % NMAX;
+  const bool live = s < n_new[b];
+  const int row = sel_rows[t];
+  trk_id[t] = live ? obj_idxes[row] : (int64_t)-1;
+  trk_dis[t] = live ? dis_out[row] : 0;
+  f32x4 r = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    const f32x4 bx = *reinterpret_cast<const f32x4*>(boxes + (long)row * 4);
+    auto inv = [](float x) { x = fminf(fmaxf(x, 0.f), 1.f); return logf(fmaxf(x, 1e-5f) / fmaxf(1.f - x, 1e-5f)); };
+    r = f32x4{inv(bx.x), inv(bx.y), inv(bx.z), inv(bx.w)};
+  }
+  *reinterpret_cast<f32x4*>(trk_ref + (long)t * 4) = r;
+  if (s == 0) n_trk[b] = n_new[b];
+}
 
 // ------------------------------------------------------------------------------------------------
 // Side state of the shipped path on device: copy-filter of RuntimeTrackerBase.update + FSQM.
@@ -1336,7 +1491,8 @@ extern "C" int moy_pos2posemb(const float* pos, int M, void* out, int64_t ldo, i
 }
 
 template <typename T, int NKT>
-static int mha_launch(const void* qkv, int64_t ld_qkv, int B, int L, int nh, int E, void* out, int64_t ldo, hipStream_t st) {
+static int mha_launch(const void* qkv, int64_t ld_qkv, int B, int L, int nh, int E, void* out, int64_t ldo, const int32_t* n_prefix,
+                      int split, hipStream_t st) {
   constexpr int NPD = 32 / (4 * DT<T>::KPB), ESZ = 16 / DT<T>::KPB;
   const int Lp = (L + 31) & ~31;
   const size_t lds = (size_t)NPD * Lp * 64 + 32 * ((size_t)Lp * ESZ + 16);
@@ -1353,21 +1509,33 @@ static int mha_launch(const void* qkv, int64_t ld_qkv, int B, int L, int nh, int
   splits = splits < 1 ? 1 : (splits > (nqt + 3) / 4 ? (nqt + 3) / 4 : splits);
   const int tpb = (nqt + splits - 1) / splits;
   hipLaunchKernelGGL(kern, dim3(B * nh, (nqt + tpb - 1) / tpb), dim3(256), lds, st, static_cast<const T*>(qkv), ld_qkv, L, nh, E,
-                     static_cast<T*>(out), ldo, tpb);
+                     static_cast<T*>(out), ldo, tpb, n_prefix, split);
   return launch_status();
+}
+
+static int mha_host(const void* qkv, int64_t ld_qkv, int B, int L, int nh, int E, const int32_t* n_prefix, int split, void* out,
+                    int64_t ldo, int dtype, void* stream) {
+  if (!qkv || !out || B <= 0 || L <= 0 || nh <= 0 || E != nh * 32 || ld_qkv < 3 * E || (ld_qkv % 8) || (ldo % 4)) return MOY_EINVAL;
+  if (!aligned16(qkv) || reinterpret_cast<uintptr_t>(out) % 8) return MOY_EINVAL;
+  if (split < 0 || split > L) return MOY_EINVAL;
+  if (L > 512) return MOY_ENOSYS;    // score registers: 32 key tiles per lane
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MOY_DISPATCH_T(dtype, {
+    if (L <= 128) return mha_launch<T, 8>(qkv, ld_qkv, B, L, nh, E, out, ldo, n_prefix, split, st);
+    if (L <= 320) return mha_launch<T, 20>(qkv, ld_qkv, B, L, nh, E, out, ldo, n_prefix, split, st);
+    return mha_launch<T, 32>(qkv, ld_qkv, B, L, nh, E, out, ldo, n_prefix, split, st);
+  })
+}
+
+extern "C" int moy_mha_core_masked(const void* qkv, int64_t ld_qkv, int B, int L, int nh, int E, const int32_t* n_prefix, int split,
+                                   void* out, int64_t ldo, int dtype, void* stream) {
+  if (!n_prefix) return MOY_EINVAL;
+  return mha_host(qkv, ld_qkv, B, L, nh, E, n_prefix, split, out, ldo, dtype, stream);
 }
 
 extern "C" int moy_mha_core(const void* qkv, int64_t ld_qkv, int B, int L, int nh, int E, void* out, int64_t ldo, int dtype,
                             void* stream) {
-  if (!qkv || !out || B <= 0 || L <= 0 || nh <= 0 || E != nh * 32 || ld_qkv < 3 * E || (ld_qkv % 8) || (ldo % 4)) return MOY_EINVAL;
-  if (!aligned16(qkv) || reinterpret_cast<uintptr_t>(out) % 8) return MOY_EINVAL;
-  if (L > 512) return MOY_ENOSYS;    // score registers: 32 key tiles per lane
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  MOY_DISPATCH_T(dtype, {
-    if (L <= 128) return mha_launch<T, 8>(qkv, ld_qkv, B, L, nh, E, out, ldo, st);
-    if (L <= 320) return mha_launch<T, 20>(qkv, ld_qkv, B, L, nh, E, out, ldo, st);
-    return mha_launch<T, 32>(qkv, ld_qkv, B, L, nh, E, out, ldo, st);
-  })
+  return mha_host(qkv, ld_qkv, B, L, nh, E, nullptr, L, out, ldo, dtype, stream);
 }
 
 extern "C" int moy_msda_fused(const void* value, int64_t ldv, int B, int S, const int32_t* shapes_hw, int L, const float* offaw,
@@ -1490,6 +1658,53 @@ extern "C" int moy_assign_post(const float* logits, const float* boxes, int B, i
   return launch_status();
 }
 
+extern "C" int moy_temporal_assemble(const void* trk_embed, const void* trk_qpos, const float* trk_ref, const int32_t* n_trk,
+                                     const void* det_embed, int64_t ld_de, const void* det_qpos, int64_t ld_dq, const float* det_ref,
+                                     int B, int n_max, int nq, void* embed, int64_t ld_e, void* qpos, int64_t ld_q, float* ref_logit,
+                                     float* ref_sig, int dtype, void* stream) {
+  if (!trk_embed || !trk_qpos || !trk_ref || !n_trk || !det_embed || !det_qpos || !det_ref || !embed || !qpos || !ref_logit || !ref_sig)
+    return MOY_EINVAL;
+  if (B <= 0 || n_max <= 0 || nq <= 0 || ld_de < 256 || ld_dq < 256 || ld_e < 256 || ld_q < 256) return MOY_EINVAL;
+  if ((ld_de % 8) || (ld_dq % 8) || (ld_e % 8) || (ld_q % 8)) return MOY_EINVAL;
+  if (!aligned16(trk_embed) || !aligned16(trk_qpos) || !aligned16(trk_ref) || !aligned16(det_embed) || !aligned16(det_qpos) ||
+      !aligned16(det_ref) || !aligned16(embed) || !aligned16(qpos) || !aligned16(ref_logit) || !aligned16(ref_sig))
+    return MOY_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MOY_DISPATCH_T(dtype, {
+    const long total = (long)B * (n_max + nq) * (256 / DT<T>::KPB);
+    hipLaunchKernelGGL((temporal_assemble_kernel<T>), dim3(nblk(total)), dim3(256), 0, st, static_cast<const T*>(trk_embed),
+                       static_cast<const T*>(trk_qpos), trk_ref, n_trk, static_cast<const T*>(det_embed), ld_de,
+                       static_cast<const T*>(det_qpos), ld_dq, det_ref, B, n_max, nq, static_cast<T*>(embed), ld_e, static_cast<T*>(qpos),
+                       ld_q, ref_logit, ref_sig);
+    return launch_status();
+  })
+}
+
+extern "C" int moy_temporal_assign(const float* logits, const float* boxes, int B, int n_max, int nq, int nc, const int64_t* trk_id,
+                                   const int32_t* trk_dis, const int32_t* n_trk, int64_t* max_obj_id, float score_thresh,
+                                   float filter_thresh, int miss_tol, float conf, float img_w, float img_h, float* y, float* scores,
+                                   int64_t* obj_idxes, int32_t* dis_out, int32_t* sel_rows, int32_t* n_new, int32_t* n_overflow,
+                                   float* rows, int64_t* track_id, int32_t* n_rows, int32_t* n_ids, void* stream) {
+  if (!logits || !boxes || !trk_id || !trk_dis || !n_trk || !max_obj_id || !y || !scores || !obj_idxes || !dis_out || !sel_rows ||
+      !n_new || !n_overflow || !rows || !track_id || !n_rows || !n_ids)
+    return MOY_EINVAL;
+  if (B <= 0 || n_max <= 0 || nq <= 0 || n_max + nq > 1024 || nc <= 0 || miss_tol <= 0) return MOY_EINVAL;
+  hipLaunchKernelGGL(temporal_assign_kernel, dim3(B), dim3(1024), 0, static_cast<hipStream_t>(stream), logits, boxes, n_max, nq, nc,
+                     trk_id, trk_dis, n_trk, max_obj_id, score_thresh, filter_thresh, miss_tol, conf, img_w, img_h, y, scores, obj_idxes,
+                     dis_out, sel_rows, n_new, n_overflow, rows, track_id, n_rows, n_ids);
+  return launch_status();
+}
+
+extern "C" int moy_temporal_commit(const int32_t* sel_rows, const int32_t* n_new, const int64_t* obj_idxes, const int32_t* dis_out,
+                                   const float* boxes, int B, int n_max, int64_t* trk_id, int32_t* trk_dis, float* trk_ref,
+                                   int32_t* n_trk, void* stream) {
+  if (!sel_rows || !n_new || !obj_idxes || !dis_out || !boxes || !trk_id || !trk_dis || !trk_ref || !n_trk) return MOY_EINVAL;
+  if (B <= 0 || n_max <= 0 || !aligned16(boxes) || !aligned16(trk_ref)) return MOY_EINVAL;
+  hipLaunchKernelGGL(temporal_commit_kernel, dim3(nblk((long)B * n_max)), dim3(256), 0, static_cast<hipStream_t>(stream), sel_rows, n_new,
+                     obj_idxes, dis_out, boxes, B, n_max, trk_id, trk_dis, trk_ref, n_trk);
+  return launch_status();
+}
+
 extern "C" int moy_track_state_update(const float* scores, const float* boxes, const int64_t* obj_idxes, const void* hs, int64_t ld_hs,
                                       int B, int nq, int32_t* copy_rows, int64_t* copy_ids, int32_t* n_copy, float* mem, float* conf,
                                       int64_t* ids, float* fboxes, int32_t* low, int32_t* pool, int32_t pool_cap, int32_t* pool_hc,
@@ -1555,11 +1770,12 @@ extern "C" int moy_cast_f32_to(const float* src, int64_t lds_, int M, int N, voi
 
 extern "C" int moy_gather_rows(const void* src, int64_t lds_, const int32_t* rows, int M, int N, void* dst, int64_t ldd, int dtype,
                                void* stream) {
-  if (!src || !rows || !dst || M <= 0 || N <= 0 || (N % 8) || (lds_ % 8) || (ldd % 8) || !aligned16(src) || !aligned16(dst))
-    return MOY_EINVAL;
+  if (!src || !rows || !dst || M <= 0 || N <= 0 || !aligned16(src) || !aligned16(dst)) return MOY_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   MOY_DISPATCH_T(dtype, {
-    const int NC = N / DT<T>::KPB;
+    constexpr int KPB = DT<T>::KPB;                     // whole 16-byte chunks: 8 columns of a 16-bit type, 4 of fp32
+    if ((N % KPB) || (lds_ % KPB) || (ldd % KPB)) return MOY_EINVAL;
+    const int NC = N / KPB;
     hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(nblk((long)M * NC)), dim3(256), 0, st, static_cast<const T*>(src), lds_, rows,
                        M, NC, static_cast<T*>(dst), ldd);
     return launch_status();

@@ -59,7 +59,8 @@ class TrackEngine:
     def __init__(self, arch: TrackArch, state_dict: Dict[str, torch.Tensor], H: int, W: int, batch: int = 1,
                  dtype: torch.dtype = torch.float32, device="cuda", input_format: str = "u8", conf: float = 0.25,
                  score_thresh: float = 0.4, scale_boxes: bool = True, head_only: bool = False,
-                 level_shapes_override=None, side_state: bool = False, iou: float = 0.7, max_det: int = 300, orig_hw=None):
+                 level_shapes_override=None, side_state: bool = False, iou: float = 0.7, max_det: int = 300, orig_hw=None,
+                 temporal: int = 0, filter_score_thresh: float = 0.5, miss_tolerance: int = 5):
         if not torch.cuda.is_available():
             raise L.MoyoloError("TrackEngine needs a HIP device (no CPU path)")
         self.lib = L.lib()
@@ -73,6 +74,12 @@ class TrackEngine:
         self.head_only = head_only
         self.iou, self.max_det, self.orig_hw = iou, max_det, orig_hw      # Detect head (config C1) only
         self.side_state = side_state     # keep the output-invisible tracker copy + FSQM memory on device
+        # temporal mode: `temporal` = track slots per sequence; batch element b is then
+        # SEQUENCE b (frames of one sequence are dependent), its query memory persists across forward() calls
+        self.n_max = int(temporal)
+        self.filter_score_thresh, self.miss_tolerance = filter_score_thresh, miss_tolerance
+        if self.n_max and (side_state or head_only):
+            raise ValueError("temporal mode excludes side_state / head_only")
         self.shapes = [tuple(s) for s in level_shapes_override] if level_shapes_override else level_shapes(H, W)
         self.S = sum(h * w for h, w in self.shapes)
         self._keep: List[torch.Tensor] = []          # device tensors referenced by raw pointers
@@ -333,9 +340,14 @@ class TrackEngine:
                   self.topk_local.data_ptr(), self.topk_global.data_ptr(), self.n_masked.data_ptr())
 
         M = B * nq
-        t1, t2 = View(self._buf(M, hd)), View(self._buf(M, hd))
+        n_max = self.n_max
+        Lq = nq + n_max                  # decoder rows per batch element: [track slots | detect queries] in temporal mode
+        Md = B * Lq
+        if Lq > 512:
+            raise NotImplementedError("track slots + queries must not exceed 512 decoder rows (moy_mha_core)")
+        t1, t2 = View(self._buf(Md, hd)), View(self._buf(Md, hd))
 
-        def bbox_mlp(prefix, x: View, a_rows, mode, aux, aux_rows, out_t):
+        def bbox_mlp(prefix, x: View, a_rows, mode, aux, aux_rows, out_t, M=M):
             W0, b0 = self._linear_w(prefix + ".layers.0")
             W1, b1 = self._linear_w(prefix + ".layers.1")
             w2, b2 = self._dev(sd[prefix + ".layers.2.weight"]), self._dev(sd[prefix + ".layers.2.bias"])
@@ -347,14 +359,34 @@ class TrackEngine:
         self.refer_logit = self._buf(M, 4, torch.float32)
         bbox_mlp(d + ".enc_bbox_head", features, self.topk_global, 2, self.anchors, self.topk_local, self.refer_logit)
 
-        embed = [View(self._buf(M, hd)) for _ in range(2)]
-        self._add(lib.moy_gather_rows, features.ptr, features.ld, self.topk_global.data_ptr(), M, hd, embed[0].ptr,
-                  embed[0].ld, code)
-        qpos = View(self._buf(M, hd))
-        self._add(lib.moy_pos2posemb, self.refer_logit.data_ptr(), M, qpos.ptr, qpos.ld, code)
+        embed = [View(self._buf(Md, hd)) for _ in range(2)]
+        qpos = View(self._buf(Md, hd))
+        refs = [self._buf(Md, 4, torch.float32) for _ in range(2)]
+        if not n_max:
+            self._add(lib.moy_gather_rows, features.ptr, features.ld, self.topk_global.data_ptr(), M, hd, embed[0].ptr,
+                      embed[0].ld, code)
+            self._add(lib.moy_pos2posemb, self.refer_logit.data_ptr(), M, qpos.ptr, qpos.ld, code)
+            self._add(lib.moy_sigmoid_f32, self.refer_logit.data_ptr(), M * 4, refs[0].data_ptr())
+            self.refer_all = self.refer_logit
+        else:
+            # per-sequence query memory (static shapes: the whole temporal step stays graph-capturable)
+            i32, i64 = torch.int32, torch.int64
+            self.trk = dict(embed=self._buf(B * n_max, hd), qpos=self._buf(B * n_max, hd),
+                            ref=self._buf(B * n_max, 4, torch.float32),
+                            id=torch.full((B, n_max), -1, device=self.dev, dtype=i64),
+                            dis=torch.zeros(B, n_max, device=self.dev, dtype=i32),
+                            n=torch.zeros(B, device=self.dev, dtype=i32),
+                            max_obj_id=torch.zeros(B, device=self.dev, dtype=i64))
+            det_embed, det_qpos = View(self._buf(M, hd)), View(self._buf(M, hd))
+            self._add(lib.moy_gather_rows, features.ptr, features.ld, self.topk_global.data_ptr(), M, hd, det_embed.ptr,
+                      det_embed.ld, code)
+            self._add(lib.moy_pos2posemb, self.refer_logit.data_ptr(), M, det_qpos.ptr, det_qpos.ld, code)
+            self.refer_all = self._buf(Md, 4, torch.float32)
+            t = self.trk
+            self._add(lib.moy_temporal_assemble, t["embed"].data_ptr(), t["qpos"].data_ptr(), t["ref"].data_ptr(), t["n"].data_ptr(),
+                      det_embed.ptr, det_embed.ld, det_qpos.ptr, det_qpos.ld, self.refer_logit.data_ptr(), B, n_max, nq,
+                      embed[0].ptr, embed[0].ld, qpos.ptr, qpos.ld, self.refer_all.data_ptr(), refs[0].data_ptr(), code)
         self.query_pos = qpos
-        refs = [self._buf(M, 4, torch.float32) for _ in range(2)]
-        self._add(lib.moy_sigmoid_f32, self.refer_logit.data_ptr(), M * 4, refs[0].data_ptr())
 
         # value projections of all decoder layers in ONE GEMM over the S tokens: feats is layer
         # invariant (transformer.py:700-706 passes the same `feats` to every layer)
@@ -365,6 +397,7 @@ class TrackEngine:
         self._gemm(feats, self._weight(Wv), ndl * hd, hd, value, B * S, shift=self._dev(bv))
         self.value = value
 
+        M = Md                           # from here on: decoder rows
         qkv = View(self._buf(M, 3 * hd))
         attn = View(self._buf(M, hd))
         e1, e2 = View(self._buf(M, hd)), View(self._buf(M, hd))
@@ -382,7 +415,11 @@ class TrackEngine:
             x = embed[cur]
             self._gemm(x, Wqk, 2 * hd, hd, qkv.slice(0, 2 * hd), M, shift=bqk, A2=qpos)
             self._gemm(x, Wvv, hd, hd, qkv.slice(2 * hd, hd), M, shift=bvv)
-            self._add(lib.moy_mha_core, qkv.ptr, qkv.ld, B, nq, arch.nh, hd, attn.ptr, attn.ld, code)
+            if n_max:   # keys: live track slots + this frame's detect queries
+                self._add(lib.moy_mha_core_masked, qkv.ptr, qkv.ld, B, Lq, arch.nh, hd, self.trk["n"].data_ptr(), n_max, attn.ptr,
+                          attn.ld, code)
+            else:
+                self._add(lib.moy_mha_core, qkv.ptr, qkv.ld, B, nq, arch.nh, hd, attn.ptr, attn.ld, code)
             Wo, bo = self._linear_w(q + ".self_attn.out_proj")
             self._gemm(attn, Wo, hd, hd, e1, M, shift=bo, R=x, ln=self._ln(q + ".norm1"))
             Woa = torch.cat([sd[q + ".cross_attn.sampling_offsets.weight"], sd[q + ".cross_attn.attention_weights.weight"]], 0)
@@ -391,14 +428,14 @@ class TrackEngine:
             self._gemm(e1, Woa_d, Woa.shape[0], hd, View(offaw), M, shift=boa_d, A2=qpos, out_f32=True)
             vslice = value.slice(i * hd, hd)
             self._add(lib.moy_msda_fused, vslice.ptr, vslice.ld, B, S, shapes_c, nl, offaw.data_ptr(), offaw.shape[1],
-                      refs[cur].data_ptr(), nq, samp.ptr, samp.ld, code)
+                      refs[cur].data_ptr(), Lq, samp.ptr, samp.ld, code)
             Wp, bp = self._linear_w(q + ".cross_attn.output_proj")
             self._gemm(samp, Wp, hd, hd, e2, M, shift=bp, R=e1, ln=self._ln(q + ".norm2"))
             W1, b1 = self._linear_w(q + ".linear1")
             W2, b2 = self._linear_w(q + ".linear2")
             self._gemm(e2, W1, arch.d_ffn, hd, ffn, M, shift=b1, act=L.ACT_RELU)
             self._gemm(ffn, W2, hd, arch.d_ffn, embed[nxt], M, shift=b2, R=e2, ln=self._ln(q + ".norm3"))
-            bbox_mlp(f"{d}.dec_bbox_head.{i}", embed[nxt], None, 1, refs[cur], None, refs[nxt])
+            bbox_mlp(f"{d}.dec_bbox_head.{i}", embed[nxt], None, 1, refs[cur], None, refs[nxt], M=M)
             self.layer_out.append((embed[nxt], refs[nxt]))
             cur, nxt = nxt, cur
         self.hs = embed[cur]
@@ -409,17 +446,20 @@ class TrackEngine:
         self._add(lib.moy_rowdot, self.hs.ptr, self.hs.ld, None, M, hd, wd.data_ptr(), bd.data_ptr(), nc, 0, None, None,
                   self.logits.data_ptr(), code)
 
-        self.y = torch.zeros(B, nq, 4 + nc, device=self.dev)
-        self.scores = torch.zeros(B, nq, device=self.dev)
-        self.obj_idxes = torch.zeros(B, nq, device=self.dev, dtype=torch.int64)
-        self.rows = torch.zeros(B, nq, 6, device=self.dev)
-        self.track_id = torch.zeros(B, nq, device=self.dev, dtype=torch.int64)
+        self.y = torch.zeros(B, Lq, 4 + nc, device=self.dev)
+        self.scores = torch.zeros(B, Lq, device=self.dev)
+        self.obj_idxes = torch.zeros(B, Lq, device=self.dev, dtype=torch.int64)
+        self.rows = torch.zeros(B, Lq, 6, device=self.dev)
+        self.track_id = torch.zeros(B, Lq, device=self.dev, dtype=torch.int64)
         self.n_rows = torch.zeros(B, device=self.dev, dtype=torch.int32)
         self.n_ids = torch.zeros(B, device=self.dev, dtype=torch.int32)
-        self._add(lib.moy_assign_post, self.logits.data_ptr(), self.boxes.data_ptr(), B, nq, nc,
-                  C.c_float(self.score_thresh), C.c_float(self.conf), C.c_float(self.img_wh[0]), C.c_float(self.img_wh[1]),
-                  self.y.data_ptr(), self.scores.data_ptr(), self.obj_idxes.data_ptr(), self.rows.data_ptr(),
-                  self.track_id.data_ptr(), self.n_rows.data_ptr(), self.n_ids.data_ptr())
+        if not n_max:
+            self._add(lib.moy_assign_post, self.logits.data_ptr(), self.boxes.data_ptr(), B, nq, nc,
+                      C.c_float(self.score_thresh), C.c_float(self.conf), C.c_float(self.img_wh[0]), C.c_float(self.img_wh[1]),
+                      self.y.data_ptr(), self.scores.data_ptr(), self.obj_idxes.data_ptr(), self.rows.data_ptr(),
+                      self.track_id.data_ptr(), self.n_rows.data_ptr(), self.n_ids.data_ptr())
+        else:
+            self._build_temporal_update(qpos)
 
         if self.side_state:
             i32, i64, f32 = torch.int32, torch.int64, torch.float32
@@ -433,6 +473,62 @@ class TrackEngine:
                       self.hs.ptr, self.hs.ld, B, nq, self.copy_rows.data_ptr(), self.copy_ids.data_ptr(), self.n_copy.data_ptr(),
                       f["mem"].data_ptr(), f["conf"].data_ptr(), f["ids"].data_ptr(), f["boxes"].data_ptr(), f["low"].data_ptr(),
                       f["pool"].data_ptr(), f["pool"].numel(), f["pool_hc"].data_ptr(), code)
+
+    def _build_temporal_update(self, qpos: View):
+        """After the decoder of a frame (temporal mode): ID lifecycle + compaction (`moy_temporal_assign`), the learned
+        query update of the surviving / newborn tracks (`QueryInteractionModule._update_track_embedding`,
+        MOTR/models/qim.py:251-301, update_query_pos=False) on the compacted slots, commit into the query memory."""
+        arch, B, sd, lib, code = self.arch, self.B, self.sd, self.lib, self.code
+        hd, nq, nc, n_max = arch.hd, arch.nq, arch.nc, self.n_max
+        Lq, Mq = nq + n_max, B * n_max
+        i32, i64 = torch.int32, torch.int64
+        t = self.trk
+        self.dis_out = torch.zeros(B, Lq, device=self.dev, dtype=i32)
+        self.sel_rows = torch.zeros(B, n_max, device=self.dev, dtype=i32)
+        self.n_new = torch.zeros(B, device=self.dev, dtype=i32)
+        self.n_overflow = torch.zeros(B, device=self.dev, dtype=i32)
+        self._add(lib.moy_temporal_assign, self.logits.data_ptr(), self.boxes.data_ptr(), B, n_max, nq, nc, t["id"].data_ptr(),
+                  t["dis"].data_ptr(), t["n"].data_ptr(), t["max_obj_id"].data_ptr(), C.c_float(self.score_thresh),
+                  C.c_float(self.filter_score_thresh), self.miss_tolerance, C.c_float(self.conf), C.c_float(self.img_wh[0]),
+                  C.c_float(self.img_wh[1]), self.y.data_ptr(), self.scores.data_ptr(), self.obj_idxes.data_ptr(),
+                  self.dis_out.data_ptr(), self.sel_rows.data_ptr(), self.n_new.data_ptr(), self.n_overflow.data_ptr(),
+                  self.rows.data_ptr(), self.track_id.data_ptr(), self.n_rows.data_ptr(), self.n_ids.data_ptr())
+        # the selected rows' decoder output (content embedding of the track from now on), the position embedding and the
+        # reference box they were decoded with
+        sel = self.sel_rows.data_ptr()
+        out_embed = View(t["embed"])
+        qp_prev = View(self._buf(Mq, hd))
+        ref_in = self._buf(Mq, 4, torch.float32)
+        self._add(lib.moy_gather_rows, self.hs.ptr, self.hs.ld, sel, Mq, hd, out_embed.ptr, out_embed.ld, code)
+        self._add(lib.moy_gather_rows, qpos.ptr, qpos.ld, sel, Mq, hd, qp_prev.ptr, qp_prev.ld, code)
+        self._add(lib.moy_gather_rows, self.refer_all.data_ptr(), 4, sel, Mq, 4, ref_in.data_ptr(), 4, L.F32)
+        pos = View(self._buf(Mq, hd))
+        self._add(lib.moy_pos2posemb, ref_in.data_ptr(), Mq, pos.ptr, pos.ld, code)
+        q = f"model.{len(arch.layers)}.track_embed"
+        Wqk, bqk = self._linear_w_raw(sd[q + ".self_attn.in_proj_weight"][:2 * hd], sd[q + ".self_attn.in_proj_bias"][:2 * hd])
+        Wvv, bvv = self._linear_w_raw(sd[q + ".self_attn.in_proj_weight"][2 * hd:], sd[q + ".self_attn.in_proj_bias"][2 * hd:])
+        qkv = View(self._buf(Mq, 3 * hd))
+        self._gemm(out_embed, Wqk, 2 * hd, hd, qkv.slice(0, 2 * hd), Mq, shift=bqk, A2=pos)
+        self._gemm(out_embed, Wvv, hd, hd, qkv.slice(2 * hd, hd), Mq, shift=bvv)
+        attn = View(self._buf(Mq, hd))
+        self._add(lib.moy_mha_core_masked, qkv.ptr, qkv.ld, B, n_max, arch.nh, hd, self.n_new.data_ptr(), n_max, attn.ptr, attn.ld,
+                  code)
+        tgt1, tgt2 = View(self._buf(Mq, hd)), View(self._buf(Mq, hd))
+        Wo, bo = self._linear_w(q + ".self_attn.out_proj")
+        self._gemm(attn, Wo, hd, hd, tgt1, Mq, shift=bo, R=out_embed, ln=self._ln(q + ".norm1"))
+        W1, b1 = self._linear_w(q + ".linear1")
+        W2, b2 = self._linear_w(q + ".linear2")
+        dff = sd[q + ".linear1.weight"].shape[0]
+        f1 = View(self._buf(Mq, dff))
+        self._gemm(tgt1, W1, dff, hd, f1, Mq, shift=b1, act=L.ACT_RELU)
+        self._gemm(f1, W2, hd, dff, tgt2, Mq, shift=b2, R=tgt1, ln=self._ln(q + ".norm2"))
+        Wf1, bf1 = self._linear_w(q + ".linear_feat1")
+        Wf2, bf2 = self._linear_w(q + ".linear_feat2")
+        g1 = View(self._buf(Mq, dff))
+        self._gemm(tgt2, Wf1, dff, hd, g1, Mq, shift=bf1, act=L.ACT_RELU)
+        self._gemm(g1, Wf2, hd, dff, View(t["qpos"]), Mq, shift=bf2, R=qp_prev, ln=self._ln(q + ".norm_feat"))
+        self._add(lib.moy_temporal_commit, sel, self.n_new.data_ptr(), self.obj_idxes.data_ptr(), self.dis_out.data_ptr(),
+                  self.boxes.data_ptr(), B, n_max, t["id"].data_ptr(), t["dis"].data_ptr(), t["ref"].data_ptr(), t["n"].data_ptr())
 
     def _build_detect_head(self, head_src):
         """Detect head of config C1 (nn/modules/head.py:27-78) + NMS / scale_boxes
@@ -472,8 +568,17 @@ class TrackEngine:
                   C.c_float(7680.0), C.c_float(gain), C.c_float(padx), C.c_float(pady), C.c_float(cw), C.c_float(ch_),
                   self.rows.data_ptr(), self.n_rows.data_ptr())
 
-    def reset_sequence(self):
-        """FSQM.reset (fsqm.py:182-190): call at the start of a new video sequence."""
+    def reset_sequence(self, which=None):
+        """Start of a new video sequence.  Temporal mode: empties the query memory and restarts the id counter of the
+        sequences `which` (indices into the batch; default all) -- `is_first` of MOTRTrack.forward (head.py:199-205).
+        side_state: FSQM.reset (fsqm.py:182-190)."""
+        if self.n_max:
+            t = self.trk
+            idx = slice(None) if which is None else torch.as_tensor(which, device=self.dev, dtype=torch.long)
+            t["n"][idx] = 0
+            t["max_obj_id"][idx] = 0
+            t["id"][idx] = -1
+            t["dis"][idx] = 0
         if self.side_state:
             f = self.fsqm
             L.check(self.lib.moy_fsqm_reset(f["mem"].data_ptr(), f["conf"].data_ptr(), f["ids"].data_ptr(), f["boxes"].data_ptr(),
@@ -543,10 +648,17 @@ class TrackEngine:
         if self.arch.head_kind == "detect":
             return dict(y=self.y, rows=self.rows, n_rows=self.n_rows)
         B, nq = self.B, self.arch.nq
-        return dict(y=self.y, scores=self.scores, obj_idxes=self.obj_idxes, rows=self.rows, track_id=self.track_id,
-                    n_rows=self.n_rows, n_ids=self.n_ids, logits=self.logits.view(B, nq, -1),
-                    boxes=self.boxes.view(B, nq, 4), hs=self.hs.tensor().view(B, nq, -1),
-                    topk_ind=self.topk_local, n_masked=self.n_masked, refer_bbox_logit=self.refer_logit.view(B, nq, 4))
+        Lq = nq + self.n_max             # temporal mode: rows = [track slots | detect queries] per sequence
+        out = dict(y=self.y, scores=self.scores, obj_idxes=self.obj_idxes, rows=self.rows, track_id=self.track_id,
+                   n_rows=self.n_rows, n_ids=self.n_ids, logits=self.logits.view(B, Lq, -1),
+                   boxes=self.boxes.view(B, Lq, 4), hs=self.hs.tensor().view(B, Lq, -1),
+                   topk_ind=self.topk_local, n_masked=self.n_masked, refer_bbox_logit=self.refer_logit.view(B, nq, 4))
+        if self.n_max:
+            t = self.trk
+            out.update(n_tracks=t["n"], n_overflow=self.n_overflow, trk_id=t["id"], trk_dis=t["dis"],
+                       trk_ref=t["ref"].view(B, self.n_max, 4), trk_qpos=t["qpos"].view(B, self.n_max, -1),
+                       trk_embed=t["embed"].view(B, self.n_max, -1), max_obj_id=t["max_obj_id"])
+        return out
 
     @property
     def num_launches(self):

@@ -50,20 +50,28 @@ class TrackResults:
 
 class TrackPredictor:
     def __init__(self, arch, state_dict, imgsz=(608, 1088), conf=0.25, dtype=torch.float32, device="cuda", batch=1,
-                 graph=False):
+                 graph=False, temporal=0):
+        """`temporal` = track slots per sequence (0: the shipped per-frame-reset semantics).  In temporal mode the `batch`
+        frames of a chunk are ONE time step of `batch` sequences running in lockstep (source order t0s0, t0s1, ..., t1s0, ...);
+        call `reset_sequences()` at the start of new videos (`is_first`, head.py:199-205)."""
         self.arch, self.sd, self.imgsz, self.conf, self.dtype, self.device = arch, state_dict, tuple(imgsz), conf, dtype, device
-        self.batch, self.graph = batch, graph
+        self.batch, self.graph, self.temporal = batch, graph, int(temporal)
         self._engines = {}
+
+    def reset_sequences(self, which=None):
+        for eng in self._engines.values():
+            eng.reset_sequence(which)
 
     def _engine(self, fmt, orig_hw=None):
         key = (fmt, tuple(orig_hw or self.imgsz))
         if key not in self._engines:
             H, W = self.imgsz
             eng = TrackEngine(self.arch, self.sd, H, W, batch=self.batch, dtype=self.dtype, device=self.device,
-                              input_format=fmt, conf=self.conf, scale_boxes=(fmt == "u8"), orig_hw=key[1])
+                              input_format=fmt, conf=self.conf, scale_boxes=(fmt == "u8"), orig_hw=key[1], temporal=self.temporal)
             if self.graph:
                 eng.forward(torch.zeros_like(eng.input))
                 eng.capture()
+                eng.reset_sequence()                      # the warm-up frames must not leave tracks behind
             self._engines[key] = eng
         return self._engines[key]
 

@@ -1,0 +1,198 @@
+"""Temporal mode: carried track queries in a fixed-size GPU query memory.
+The reference's carried branch cannot run, so parity here is against oracle/temporal_oracle.py, the spec
+assembled from reference-pinned pieces."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mo_yolo_amd import _lib as L
+from mo_yolo_amd import ops
+from mo_yolo_amd.engine import TrackEngine
+from mo_yolo_amd.synth import SyntheticSequence, to_network_input
+from oracle import track_oracle as O
+from oracle.temporal_oracle import TemporalOracle
+from tests._util import fixture
+
+DEV = "cuda"
+
+
+def _st():
+    import ctypes
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def test_mha_key_mask_vs_torch():
+    """moy_mha_core_masked: keys = live prefix + tail; a sequence with nothing live in a prefix-only call returns zeros."""
+    B, Lq, nh, E, split = 3, 40, 8, 256, 24
+    g = torch.Generator().manual_seed(0)
+    qkv = torch.randn(B, Lq, 3 * E, generator=g) * 0.5
+    npre = torch.tensor([0, 7, 24], dtype=torch.int32)
+    for sp in (split, Lq):                                            # decoder form / QIM form (no tail)
+        out = torch.empty(B, Lq, E, device=DEV)
+        x = qkv.to(DEV).contiguous()
+        L.check(L.lib().moy_mha_core_masked(x.data_ptr(), 3 * E, B, Lq, nh, E, npre.to(DEV).data_ptr(), sp, out.data_ptr(), E, L.F32,
+                                            _st()), "mha")
+        q, k, v = (t.view(B, Lq, nh, 32).transpose(1, 2) for t in qkv.split(E, -1))
+        live = torch.arange(Lq)[None, :] < npre[:, None].long()
+        live = live | (torch.arange(Lq)[None, :] >= sp)
+        s = (q * 32 ** -0.5) @ k.transpose(-1, -2)
+        s = s.masked_fill(~live[:, None, None, :], float("-inf"))
+        a = torch.softmax(s, -1).nan_to_num(0.0)
+        want = (a @ v).transpose(1, 2).reshape(B, Lq, E)
+        assert torch.allclose(out.cpu(), want, atol=2e-5), sp
+
+
+def test_temporal_assign_vs_reference_loop():
+    """moy_temporal_assign vs the literal loop of RuntimeTrackerBase.update (head.py:1232-1243) on carried state, plus the
+    compaction, overflow and the detection-style fallback."""
+    import ctypes as C
+    B, n_max, nq, nc = 4, 6, 10, 2
+    Lq = n_max + nq
+    g = torch.Generator().manual_seed(1)
+    logits = torch.randn(B, Lq, nc, generator=g) * 2
+    logits[2] = -9.0                                                   # nothing is born, the one carried track decays
+    logits[3, n_max:] = 9.0                                            # ten births on top of 3 live tracks -> overflow
+    boxes = torch.rand(B, Lq, 4, generator=g)
+    n_trk = torch.tensor([0, 4, 1, 3], dtype=torch.int32)
+    trk_id = torch.full((B, n_max), -1, dtype=torch.int64)
+    trk_dis = torch.zeros(B, n_max, dtype=torch.int32)
+    trk_id[1, :4] = torch.tensor([5, 2, 9, 0]); trk_dis[1, :4] = torch.tensor([0, 4, 4, 1])
+    trk_id[2, :1] = 3; trk_dis[2, :1] = 4
+    trk_id[3, :3] = torch.tensor([0, 1, 2])
+    max_id = torch.tensor([0, 10, 4, 3], dtype=torch.int64)
+    d = lambda t: t.to(DEV).contiguous()
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, device=DEV, dtype=dt)
+    i32, i64 = torch.int32, torch.int64
+    out = dict(y=z(B, Lq, 4 + nc), scores=z(B, Lq), obj=z(B, Lq, dt=i64), dis=z(B, Lq, dt=i32), sel=z(B, n_max, dt=i32),
+               n_new=z(B, dt=i32), n_over=z(B, dt=i32), rows=z(B, Lq, 6), tid=z(B, Lq, dt=i64), n_rows=z(B, dt=i32), n_ids=z(B, dt=i32))
+    lg, bx, ti, td, nt, mi = d(logits), d(boxes), d(trk_id), d(trk_dis), d(n_trk), d(max_id)
+    L.check(L.lib().moy_temporal_assign(lg.data_ptr(), bx.data_ptr(), B, n_max, nq, nc, ti.data_ptr(), td.data_ptr(), nt.data_ptr(),
+                                        mi.data_ptr(), 0.4, 0.5, 5, 0.25, 100.0, 50.0, *(out[k].data_ptr() for k in
+                                        ("y", "scores", "obj", "dis", "sel", "n_new", "n_over", "rows", "tid", "n_rows", "n_ids")),
+                                        _st()), "assign")
+    torch.cuda.synchronize()
+    o = {k: v.cpu() for k, v in out.items()}
+    for b in range(B):
+        n = int(n_trk[b])
+        idx = list(range(n)) + list(range(n_max, Lq))                  # the rows the reference would see, in its order
+        sc = logits[b, idx].sigmoid().max(-1).values
+        ids, dis, mx = O.assign_ids_loop(sc, trk_id[b, :n].tolist() + [-1] * nq, trk_dis[b, :n].tolist() + [0] * nq, int(max_id[b]))
+        assert o["obj"][b, idx].tolist() == ids and o["dis"][b, idx].tolist() == dis and int(mi[b]) == mx
+        assert (o["obj"][b, n:n_max] == -1).all()                      # dead slots never carry an id
+        act = [idx[j] for j, v in enumerate(ids) if v >= 0]
+        assert int(o["n_new"][b]) == min(len(act), n_max) and int(o["n_over"][b]) == max(len(act) - n_max, 0)
+        assert o["sel"][b, :min(len(act), n_max)].tolist() == [b * Lq + r for r in act[:n_max]]
+        assert (o["sel"][b, min(len(act), n_max):] == b * Lq + n_max).all()
+        y = torch.cat((boxes[b, idx], logits[b, idx].sigmoid()), -1)
+        rows, tid = O.postprocess(y, logits[b, idx], torch.tensor(ids), 0.25, orig_hw=(50, 100))
+        k = int(o["n_rows"][b])
+        assert k == rows.shape[0] and torch.allclose(o["rows"][b, :k], rows, atol=1e-4)
+        if tid is None:
+            assert int(o["n_ids"][b]) == -1
+        else:
+            assert o["tid"][b, :int(o["n_ids"][b])].tolist() == tid.tolist()
+
+
+def _run_oracle(cfg, arch, sd, seq_id, T, n_max):
+    orc = TemporalOracle(sd, arch, n_max)
+    seq = SyntheticSequence(seq_id, cfg["H"], cfg["W"], cfg["style"])
+    return [orc.step(to_network_input(seq.frames(t, 1)), orig_hw=(cfg["H"], cfg["W"])) for t in range(T)], orc
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_temporal_engine_vs_oracle_stream(graph):
+    """Two sequences in lockstep (batch element = sequence), 7 frames, fp32: per-frame ids, miss counters, boxes, rows and
+    the carried memory against the oracle; with hipGraph replay the state lives in the captured buffers."""
+    cfg, arch, sd = fixture("tiny")
+    n_max, T, B = 24, 7, 2
+    eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=torch.float32, temporal=n_max)
+    seqs = [SyntheticSequence(s, cfg["H"], cfg["W"], cfg["style"]) for s in range(B)]
+    want = [_run_oracle(cfg, arch, sd, s, T, n_max)[0] for s in range(B)]
+    nq = arch.nq
+    born_total = 0
+    for t in range(T):
+        fr = torch.from_numpy(np.concatenate([s.frames(t, 1) for s in seqs])).to(DEV)
+        if graph and t == 1:
+            # capture warms up by running the plan: do it on scratch state, then restore the memory of frame 0
+            keep = {k: v.clone() for k, v in eng.trk.items()}
+            eng.capture()
+            for k, v in keep.items():
+                eng.trk[k].copy_(v)
+        out = {k: v.clone() for k, v in eng.forward(fr).items()}
+        torch.cuda.synchronize()
+        for b in range(B):
+            w = want[b][t]
+            n = w["n_in"]
+            idx = list(range(n)) + list(range(n_max, n_max + nq))
+            margin = min((w["scores"] - 0.4).abs().min(), (w["scores"] - 0.5).abs().min())
+            assert margin > 1e-4, "fixture too close to a threshold for an exact id comparison"
+            assert torch.allclose(out["scores"][b, idx].cpu(), w["scores"], atol=2e-4), (t, b)
+            assert torch.allclose(out["boxes"][b, idx].cpu(), w["boxes"], atol=2e-4), (t, b)
+            assert out["obj_idxes"][b, idx].cpu().tolist() == w["ids"].tolist(), (t, b)
+            k = int(out["n_rows"][b])
+            assert k == w["rows"].shape[0] and torch.allclose(out["rows"][b, :k].cpu(), w["rows"], atol=5e-2, rtol=1e-5)
+            if w["track_id"] is not None:
+                assert out["track_id"][b, :int(out["n_ids"][b])].cpu().tolist() == w["track_id"].tolist()
+            born_total += sum(1 for v in w["ids"][n:].tolist() if v >= 0)
+            assert int(out["n_overflow"][b]) == w["n_overflow"]
+    assert born_total > 0 and int(out["n_tracks"].max()) > 0            # the stream exercises births and carried tracks
+    # the memory after the last frame
+    for b in range(B):
+        orc = _run_oracle(cfg, arch, sd, b, T, n_max)[1]
+        n = len(orc.ids)
+        assert int(out["n_tracks"][b]) == n
+        assert out["trk_id"][b, :n].cpu().tolist() == orc.ids and out["trk_dis"][b, :n].cpu().tolist() == orc.dis
+        assert torch.allclose(out["trk_ref"][b, :n].cpu(), orc.ref, atol=2e-3)
+        assert torch.allclose(out["trk_qpos"][b, :n].cpu(), orc.qpos, atol=2e-3)
+        assert torch.allclose(out["trk_embed"][b, :n].cpu(), orc.embed, atol=2e-3)
+        assert int(out["max_obj_id"][b]) == orc.max_obj_id
+
+
+def test_temporal_reset_and_independence():
+    """reset_sequence(which) restarts one sequence only; sequences in a batch do not influence each other."""
+    cfg, arch, sd = fixture("tiny")
+    n_max = 24
+    eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=2, dtype=torch.float32, temporal=n_max)
+    s0 = SyntheticSequence(0, cfg["H"], cfg["W"], cfg["style"])
+    f = lambda t: torch.from_numpy(np.concatenate([s0.frames(t, 1), s0.frames(t, 1)])).to(DEV)
+    for t in range(3):
+        o = {k: v.clone() for k, v in eng.forward(f(t)).items()}
+    assert torch.equal(o["obj_idxes"][0], o["obj_idxes"][1])            # same frames, same history -> same result
+    eng.reset_sequence([1])
+    o3 = {k: v.clone() for k, v in eng.forward(f(3)).items()}
+    torch.cuda.synchronize()
+    single = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=1, dtype=torch.float32, temporal=n_max)
+    fresh = {k: v.clone() for k, v in single.forward(f(3)[:1]).items()}
+    assert torch.equal(o3["obj_idxes"][1], fresh["obj_idxes"][0])       # sequence 1 restarted: ids from 0 again
+    assert int(o3["n_tracks"][0]) >= 0 and not torch.equal(o3["obj_idxes"][0], o3["obj_idxes"][1]) or int(o["n_tracks"][0]) == 0
+
+
+def test_temporal_predictor_and_bf16_smoke():
+    """TrackPredictor(temporal=...) streams one sequence frame by frame (ids persist across frames, restart after
+    reset_sequences); the bf16 engine stays finite and tracks a similar number of objects as fp32."""
+    from mo_yolo_amd.predictor import TrackPredictor
+    cfg, arch, sd = fixture("tiny")
+    seq = SyntheticSequence(0, cfg["H"], cfg["W"], cfg["style"])
+    T, n_max = 6, 24
+    want, _ = _run_oracle(cfg, arch, sd, 0, T, n_max)
+    pred = TrackPredictor(arch, sd, imgsz=(cfg["H"], cfg["W"]), conf=0.25, batch=1, graph=True, temporal=n_max)
+    res = pred(list(seq.frames(0, T)))
+    for t, r in enumerate(res):
+        w = want[t]
+        assert np.allclose(r.boxes, w["rows"].numpy(), atol=5e-2, rtol=1e-5)
+        if w["track_id"] is not None:
+            assert r.track_id.tolist() == w["track_id"].tolist()
+    pred.reset_sequences()
+    again = pred(list(seq.frames(0, 2)))
+    assert again[0].track_id is None or again[0].track_id.tolist() == res[0].track_id.tolist()
+    counts = {}
+    for dt in (torch.float32, torch.bfloat16):
+        eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=1, dtype=dt, temporal=n_max)
+        for t in range(T):
+            out = eng.forward(torch.from_numpy(seq.frames(t, 1)).to(DEV))
+        torch.cuda.synchronize()
+        assert torch.isfinite(out["y"]).all() and torch.isfinite(out["trk_qpos"].float()).all()
+        counts[dt] = (int(out["n_tracks"][0]), int(out["max_obj_id"][0]))
+    assert abs(counts[torch.float32][0] - counts[torch.bfloat16][0]) <= max(3, counts[torch.float32][0] // 3)
