@@ -608,6 +608,273 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
   return launch_inst<T, BM, BN, WGM, WGN, LN, KS, 1>(p, st);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Direct 3x3 stride-1 convolution for 16-bit types (the bottleneck convs of the C2f blocks: Cin = Cout in {32, 64, 128}).
+// The implicit GEMM above re-reads every activation row once per tap: 9 x (BM x Cin) bytes through buffer loads and
+// ds_write_b128 (the ~80 B/clk VGPR->LDS path) per output tile.  Here the (TH+2) x 18 pixel halo patch of a TH x 16 output
+// tile goes to LDS ONCE and the nine taps are nine shifted views of it; only the (small, L2-resident) weight tap tiles stream
+// through a two-stage LDS ring.  Staged bytes per 256 output pixels at C = 64: 41 KB patch + 9 x 8 KB weights vs 440 KB.
+//   * patch / weight rows are [row][C] with the 16-B chunk index XORed by a function of the row, chosen by exhaustive search
+//     so that every ds_read_b128 lane group is conflict-free for ANY starting pixel (hence any tap shift):
+//     C = 32: (row >> 1) & 3;  C = 64: row & 7;  C = 128: (row & 7) << 1;
+//   * pixels outside the image are out-of-range buffer offsets -> zeros (= the conv's zero padding), no predicates;
+//   * MFMA operands swapped as above (weights as A): a lane owns 4 consecutive output channels of one pixel.
+template <int C>
+__device__ __forceinline__ int conv_swz(int row) {
+  return C == 32 ? ((row >> 1) & 3) : (C == 64 ? (row & 7) : ((row & 7) << 1));
+}
+
+template <int C, int BN, int TH>
+constexpr int conv_stage_bytes() { return (TH + 2) * 18 * C * 2 + (C == 32 ? 9 : 2) * BN * C * 2; }
+
+template <typename T, int C, int BN, int TH, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_direct_kernel(const GemmParams p) {
+  static_assert(sizeof(T) == 2, "16-bit types only");
+  constexpr int TW = 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW;
+  constexpr int CPP = C / 8;                      // 16-B chunks per pixel / weight row
+  constexpr int NW = WGM * WGN, NTHR = 64 * NW;
+  constexpr int MT = TH / WGM, NT = BN / 16 / WGN, TM = MT * 16, TN = NT * 16;
+  constexpr int BM = TH * TW;
+  constexpr int PATCH_BYTES = NPIX * C * 2, WTAP_BYTES = BN * C * 2;
+  constexpr int NPL = (NPIX * CPP + NTHR - 1) / NTHR;     // patch chunks per thread
+  constexpr int NWL = (BN * CPP + NTHR - 1) / NTHR;       // weight-tap chunks per thread
+  constexpr uint32_t OOB = 0x80000000u;
+  constexpr bool WRES = C == 32;                  // all nine weight taps resident (18 KB): no ring, no barrier per tap
+  static_assert(TH % WGM == 0 && (BN / 16) % WGN == 0, "tile vs waves");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* patch = smem;
+  unsigned char* wbuf = smem + PATCH_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  int bid = blockIdx.x;
+  {
+    const int nb = p.nblocks, qd = nb >> 3, rm = nb & 7, x = bid & 7;
+    bid = (x < rm ? x * (qd + 1) : rm * (qd + 1) + (x - rm) * qd) + (bid >> 3);
+  }
+  // logical id -> (image b, tile row, tile column, channel tile), channel tile fastest (they share the patch in L2)
+  const int tiles_x = (p.Wout + TW - 1) / TW, tiles_y = (p.Hout + TH - 1) / TH;
+  int t = bid;
+  const int tn = t % p.tiles_n; t /= p.tiles_n;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int b = t / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = tn * BN;
+
+  const T* __restrict__ Ag = static_cast<const T*>(p.A);
+  const T* __restrict__ Wg = static_cast<const T*>(p.W);
+  const int64_t img_elems = (int64_t)p.Hin * p.Win * p.lda;
+  const int64_t a_left = p.a_bytes - (int64_t)b * img_elems * 2;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Ag + (int64_t)b * img_elems), 0,
+                                                     (uint32_t)(a_left < 0x7fffffffLL ? a_left : 0x7fffffffLL), 0x00020000);
+  const int64_t w_left = ((int64_t)p.N - n0) * p.Kpad * 2;
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Wg + (int64_t)n0 * p.Kpad), 0,
+                                                     (uint32_t)(w_left < 0x7fffffffLL ? w_left : 0x7fffffffLL), 0x00020000);
+
+  // ---- the halo patch: all loads first, then the LDS stores
+  u32x4 preg[NPL];
+#pragma unroll
+  for (int k = 0; k < NPL; ++k) {
+    const int i = tid + k * NTHR;
+    const int pix = i / CPP, ch = i - pix * CPP;
+    const int py = pix / PW, px = pix - py * PW;
+    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+    const bool ok = i < NPIX * CPP && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+    const uint32_t vo = ok ? (uint32_t)((((int64_t)iy * p.Win + ix) * p.lda + ch * 8) * 2) : OOB;
+    preg[k] = __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0);
+  }
+  uint32_t w_voff[NWL];
+  int w_lds[NWL];
+#pragma unroll
+  for (int k = 0; k < NWL; ++k) {
+    const int i = tid + k * NTHR;
+    const int row = i / CPP, ch = i - row * CPP;
+    const bool ok = i < BN * CPP && n0 + row < p.N;
+    w_voff[k] = ok ? (uint32_t)(((int64_t)row * p.Kpad + ch * 8) * 2) : OOB;
+    w_lds[k] = i < BN * CPP ? row * C * 2 + ((ch ^ conv_swz<C>(row)) * 16) : -1;
+  }
+  // Weight taps travel global -> registers -> LDS ring; the registers of tap t + PFD are requested while tap t is computed
+  // (one tap is only (C/32)*MT*NT MFMAs per wave, shorter than an L2 round trip: with distance 1 every tap stalled on it).
+  // The tap loop is fully unrolled so the register sets rotate statically.  C = 32: all nine taps resident, no ring.
+  constexpr int PFD = WRES ? 9 : (C == 64 ? 4 : 3);
+  u32x4 wreg[9][NWL];
+  auto load_w = [&](auto tap_c) {
+    constexpr int tap = decltype(tap_c)::value;
+#pragma unroll
+    for (int k = 0; k < NWL; ++k) wreg[tap][k] = __builtin_amdgcn_raw_buffer_load_b128(rsW, w_voff[k], tap * C * 2, 0);
+  };
+  auto store_w = [&](auto tap_c) {
+    constexpr int tap = decltype(tap_c)::value;
+    constexpr int buf = WRES ? tap : (tap & 1);
+#pragma unroll
+    for (int k = 0; k < NWL; ++k)
+      if (w_lds[k] >= 0) *reinterpret_cast<u32x4*>(wbuf + buf * WTAP_BYTES + w_lds[k]) = wreg[tap][k];
+  };
+  auto for_taps = [&](auto&& f, auto lo_c, auto hi_c) {       // static loop over taps [lo, hi)
+    constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
+    [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, lo + I>{}), ...); }
+    (std::make_integer_sequence<int, (hi > lo ? hi - lo : 0)>{});
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I9 = std::integral_constant<int, 9>;
+  using IP = std::integral_constant<int, (PFD < 9 ? PFD : 9)>;
+  for_taps(load_w, I0{}, IP{});
+#pragma unroll
+  for (int k = 0; k < NPL; ++k) {
+    const int i = tid + k * NTHR;
+    if (i < NPIX * CPP) {
+      const int pix = i / CPP, ch = i - pix * CPP;
+      *reinterpret_cast<u32x4*>(patch + pix * C * 2 + ((ch ^ conv_swz<C>(pix)) * 16)) = preg[k];
+    }
+  }
+  store_w(I0{});
+  if constexpr (WRES) for_taps(store_w, I1{}, I9{});
+  __syncthreads();
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto tap_body = [&](auto tap_c) {
+    constexpr int tap = decltype(tap_c)::value;
+    if constexpr (!WRES && tap + PFD < 9) load_w(std::integral_constant<int, tap + PFD>{});
+    constexpr int ky = tap / 3, kx = tap % 3;
+    const unsigned char* wb = wbuf + (WRES ? tap : (tap & 1)) * WTAP_BYTES;
+#pragma unroll
+    for (int cc = 0; cc < C / 32; ++cc) {
+      u32x4 af[MT], wf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int pix = (wm * MT + i + ky) * PW + kx + r;
+        af[i] = *reinterpret_cast<const u32x4*>(patch + pix * C * 2 + (((cc * 4 + q) ^ conv_swz<C>(pix)) * 16));
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int row = wn * TN + j * 16 + r;
+        wf[j] = *reinterpret_cast<const u32x4*>(wb + row * C * 2 + (((cc * 4 + q) ^ conv_swz<C>(row)) * 16));
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) mma_panel<T>(acc[i][j], wf[j], af[i]);
+    }
+    if constexpr (!WRES) {
+      if constexpr (tap + 1 < 9) store_w(std::integral_constant<int, tap + 1>{});
+      __syncthreads();
+    }
+  };
+  for_taps(tap_body, I0{}, I9{});
+  if constexpr (WRES) __syncthreads();
+
+  // ---- epilogue: BN/bias + activation in registers, tile through LDS (output type, or fp32 when a residual is added),
+  // rows of the tile are the TH x 16 pixels in raster order
+  float* Cs = reinterpret_cast<float*>(smem);
+  const T* __restrict__ Rg = static_cast<const T*>(p.R);
+  constexpr int CPR = BN / 8, RSTEP = NTHR / CPR, NPASS = BM / RSTEP;
+  static_assert(BM % RSTEP == 0, "tile vs threads");
+  const int cc8 = tid % CPR, rr0 = tid / CPR;
+  const int n = n0 + cc8 * 8;
+  T* cbase = static_cast<T*>(p.C) + n;
+  auto out_row = [&](int rr, int64_t& m) {          // tile row -> output row index; false outside the image
+    const int oy = y0 + rr / TW, ox = x0 + (rr % TW);
+    m = ((int64_t)b * p.Hout + oy) * p.Wout + ox;
+    return oy < p.Hout && ox < p.Wout && n < p.N;
+  };
+  if (!Rg) {
+    stage_acc<T, true, BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q);
+    __syncthreads();
+    const unsigned char* ch = reinterpret_cast<const unsigned char*>(Cs);
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {
+      const int rr = rr0 + k * RSTEP;
+      const u32x2 lo = *reinterpret_cast<const u32x2*>(ch + ((size_t)rr * (BN + 4) + cc8 * 8) * 2);
+      const u32x2 hi = *reinterpret_cast<const u32x2*>(ch + ((size_t)rr * (BN + 4) + cc8 * 8 + 4) * 2);
+      int64_t m;
+      if (out_row(rr, m)) *reinterpret_cast<u32x4*>(cbase + m * p.ldc) = u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+  } else {
+    constexpr int LDC = BN + 4;
+    stage_acc<T, false, BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q);
+    u32x4 res[NPASS];
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {               // clamped, branch-free: all residual loads in flight together
+      const int rr = rr0 + k * RSTEP;
+      const int oy = min(y0 + rr / TW, p.Hout - 1), ox = min(x0 + (rr % TW), p.Wout - 1);
+      const int64_t m = ((int64_t)b * p.Hout + oy) * p.Wout + ox;
+      res[k] = *reinterpret_cast<const u32x4*>(Rg + m * p.ldr + (n < p.N ? n : 0));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {
+      const int rr = rr0 + k * RSTEP;
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + cc8 * 8);
+      f32x4 v1 = *reinterpret_cast<const f32x4*>(Cs + rr * LDC + cc8 * 8 + 4);
+      v0 += f32x4{DT<T>::lo(res[k].x), DT<T>::hi(res[k].x), DT<T>::lo(res[k].y), DT<T>::hi(res[k].y)};
+      v1 += f32x4{DT<T>::lo(res[k].z), DT<T>::hi(res[k].z), DT<T>::lo(res[k].w), DT<T>::hi(res[k].w)};
+      int64_t m;
+      if (out_row(rr, m))
+        *reinterpret_cast<u32x4*>(cbase + m * p.ldc) =
+            u32x4{DT<T>::pack2(v0.x, v0.y), DT<T>::pack2(v0.z, v0.w), DT<T>::pack2(v1.x, v1.y), DT<T>::pack2(v1.z, v1.w)};
+    }
+  }
+}
+
+template <typename T, int C, int BN, int TH, int WGM, int WGN>
+static int launch_conv_direct(GemmParams& p, int B, hipStream_t st) {
+  constexpr int BM = TH * 16;
+  constexpr int stage = conv_stage_bytes<C, BN, TH>();
+  constexpr int epi_h = BM * (BN + 4) * 2, epi_f = BM * (BN + 4) * 4;
+  const int epi = p.R ? epi_f : epi_h;
+  const int lds = stage > epi ? stage : epi;
+  auto kern = conv3x3_direct_kernel<T, C, BN, TH, WGM, WGN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    constexpr int mx = stage > epi_f ? stage : epi_f;
+    if (mx > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
+      return MOY_ELAUNCH;
+    attr_set = true;
+  }
+  p.tiles_n = (p.N + BN - 1) / BN;
+  p.nblocks = B * ((p.Hout + TH - 1) / TH) * ((p.Wout + 15) / 16) * p.tiles_n;
+  hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(64 * WGM * WGN), lds, st, p);
+  return launch_status();
+}
+
+// Direct path for the shapes it wins on; MOY_ENOSYS = not eligible (the caller falls back to the implicit GEMM).
+template <typename T>
+static int try_conv_direct(GemmParams& p, int B, bool ln, hipStream_t st) {
+  if constexpr (sizeof(T) != 2) {
+    return MOY_ENOSYS;
+  } else {
+    static int mode = -1;                   // MOY_CONV_DIRECT=0 switches the path off (A/B runs)
+    if (mode < 0) { const char* e = getenv("MOY_CONV_DIRECT"); mode = e ? atoi(e) : 1; }
+    if (!mode || ln || p.ksize != 3 || p.stride != 1 || !p.wide_store || p.c_rpb || p.out_f32) return MOY_ENOSYS;
+    if (p.Cin != p.K / 9 || (p.lda % 8) || (p.N % 32)) return MOY_ENOSYS;
+    if ((int64_t)p.Hin * p.Win * p.lda * 2 > 0x7fffffffLL) return MOY_ENOSYS;
+    // tile utilisation: partial tiles at the image border compute (and stage) for nothing
+    auto util = [&](int th) {
+      const long tiles = (long)((p.Hout + th - 1) / th) * ((p.Wout + 15) / 16);
+      return (double)p.Hout * p.Wout / (double)(tiles * th * 16);
+    };
+    const bool big = util(16) >= 0.85;
+    if (!big && util(8) < 0.75) return MOY_ENOSYS;
+    // every wave covers all BN channels of its pixel rows (NT = BN/16) and 4 (TH 16) or 2 (TH 8) rows of 16 pixels: the
+    // larger register tile halves the LDS fragment reads per MFMA, which bound the first version (1 ds_read_b128 per MFMA)
+    if (p.Cin == 32 && p.N == 32) return big ? launch_conv_direct<T, 32, 32, 16, 4, 1>(p, B, st) : launch_conv_direct<T, 32, 32, 8, 4, 1>(p, B, st);
+    static int th64 = -1;
+    if (th64 < 0) { const char* e = getenv("MOY_TH64"); th64 = e ? atoi(e) : 16; }
+    if (p.Cin == 64 && p.N % 64 == 0) return (big && th64 == 16) ? launch_conv_direct<T, 64, 64, 16, 4, 1>(p, B, st) : launch_conv_direct<T, 64, 64, 8, 4, 1>(p, B, st);
+    if (p.Cin == 128 && p.N % 64 == 0) return big ? launch_conv_direct<T, 128, 64, 16, 4, 1>(p, B, st) : launch_conv_direct<T, 128, 64, 8, 4, 1>(p, B, st);
+    return MOY_ENOSYS;
+  }
+}
+
 template <typename T, int KS>
 static int dispatch_tile(GemmParams& p, bool ln, hipStream_t st) {
   if (ln) return launch_cfg<T, 64, 256, 2, 4, true, KS>(p, st);
@@ -697,6 +964,10 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
   // section 4): an LDS-DMA ring (global_load_lds, 1-2 blocks/CU), weights-resident-in-LDS with
   // activations straight to registers (16 rows x 64 B request shape), prefetch distance 2, a persistent
   // tile loop, a direct-from-register epilogue.  They are not kept in the tree.
+  if (a->ksize == 3 && a->dtype != MOY_F32) {
+    const int rc = a->dtype == MOY_BF16 ? try_conv_direct<bf16_t>(p, a->B, ln, st) : try_conv_direct<f16_t>(p, a->B, ln, st);
+    if (rc != MOY_ENOSYS) return rc;
+  }
   if (a->dtype == MOY_BF16)
     return a->ksize == 1 ? dispatch_tile<bf16_t, 1>(p, ln, st) : dispatch_tile<bf16_t, 3>(p, ln, st);
   if (a->dtype == MOY_F16)

@@ -122,11 +122,17 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const uint8_t* __restric
   const int r = lane & 15, q = lane >> 4;
   u32x4 wf[NTC];
   f32x4 sc[NTC], sh[NTC];
+  // Channel -> MFMA row assignment: tiles are taken in pairs and row rho of tile j is channel
+  // (j/2)*32 + (rho/4)*8 + (j%2)*4 + rho%4, so a lane ends up with 8 CONSECUTIVE channels of its pixel in the accumulators
+  // of a tile pair -> one 16-byte store; a wave instruction then writes 16 pixels x 64 B = 1 KiB contiguous (the plain
+  // assignment gave 8-byte stores in 32-B pieces).  A single tile (COUT 16) keeps the plain assignment.
+  constexpr bool PAIR = (NTC % 2) == 0;
+  auto chan = [&](int j, int rho) { return PAIR ? (j / 2) * 32 + (rho / 4) * 8 + (j % 2) * 4 + (rho % 4) : j * 16 + rho; };
 #pragma unroll
   for (int j = 0; j < NTC; ++j) {
-    wf[j] = *reinterpret_cast<const u32x4*>(wpad + (j * 16 + r) * 32 + q * 8);   // lane: channel r of tile j, k-slice q
-    sc[j] = *reinterpret_cast<const f32x4*>(scale + j * 16 + q * 4);
-    sh[j] = *reinterpret_cast<const f32x4*>(shift + j * 16 + q * 4);
+    wf[j] = *reinterpret_cast<const u32x4*>(wpad + chan(j, r) * 32 + q * 8);      // lane: MFMA row r of tile j, k-slice q
+    sc[j] = *reinterpret_cast<const f32x4*>(scale + chan(j, q * 4));
+    sh[j] = *reinterpret_cast<const f32x4*>(shift + chan(j, q * 4));
   }
   // this lane's k-slice: k = 8q+e -> tap (ky, kx), channel c_rgb; the stored byte is BGR (2 - c_rgb)
   int kky[8], kcol[8];
@@ -160,9 +166,16 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const uint8_t* __restric
     }
     const int oy = oy0 + orow, ox = ox0 + ocol;
     if (oy < Ho && ox < Wo) {
-      bf16_t* o = out + (((long)b * Ho + oy) * Wo + ox) * ldc + q * 4;
+      bf16_t* o = out + (((long)b * Ho + oy) * Wo + ox) * ldc;
+      if constexpr (PAIR) {
 #pragma unroll
-      for (int j = 0; j < NTC; ++j) DT<bf16_t>::store4(o + j * 16, y[j]);
+        for (int j = 0; j < NTC; j += 2)
+          *reinterpret_cast<u32x4*>(o + chan(j, q * 4)) = u32x4{pack_bf2(y[j].x, y[j].y), pack_bf2(y[j].z, y[j].w),
+                                                               pack_bf2(y[j + 1].x, y[j + 1].y), pack_bf2(y[j + 1].z, y[j + 1].w)};
+      } else {
+#pragma unroll
+        for (int j = 0; j < NTC; ++j) DT<bf16_t>::store4(o + j * 16 + q * 4, y[j]);
+      }
     }
   }
 }
@@ -1408,6 +1421,7 @@ extern "C" int moy_stem_conv_mfma(const void* in_u8, int B, int H, int W, const 
       reinterpret_cast<uintptr_t>(in_u8) % 4)
     return MOY_EINVAL;
   if ((long)B * H * W * 3 > 0x7fffffffffffL) return MOY_EINVAL;
+  if (Cout >= 32 && ((ldc % 8) || !aligned16(out))) return MOY_EINVAL;     // 16-byte pixel stores
   const int Ho = H / 2, Wo = W / 2;
   const unsigned blocks = (unsigned)B * ((Ho + STEM_TH - 1) / STEM_TH) * ((Wo + STEM_TW - 1) / STEM_TW);
   hipStream_t st = static_cast<hipStream_t>(stream);
