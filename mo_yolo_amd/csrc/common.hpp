@@ -56,7 +56,13 @@ template <>
 struct DT<f16_t> {
   static constexpr int KPB = 8;
   static constexpr int code = MOY_F16;
-  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)f2h(lo) | ((uint32_t)f2h(hi) << 16); }
+  // The empty asm pins the fp32 value: without it hipcc may fold a preceding fp32 multiply into v_fma_mixlo_f16 (ONE rounding
+  // to fp16) in one kernel and keep mul + cvt (two roundings) in another -- the same epilogue then differs by an ulp between
+  // kernels (seen: SiLU epilogue, tiled vs weight-stationary GEMM).
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return (uint32_t)f2h(lo) | ((uint32_t)f2h(hi) << 16);
+  }
   static __device__ __forceinline__ float lo(uint32_t w) { return h2f((uint16_t)(w & 0xffffu)); }
   static __device__ __forceinline__ float hi(uint32_t w) { return h2f((uint16_t)(w >> 16)); }
   static __device__ __forceinline__ f32x4 load4(const f16_t* p) {
@@ -139,5 +145,8 @@ inline int launch_status() {
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// gemm_wreg.hip: weight-stationary kernel for K == 256 (MOY_ENOSYS when the shape is not its own)
+int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st);
 
 }  // namespace moy

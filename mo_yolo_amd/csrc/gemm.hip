@@ -964,6 +964,10 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
   // section 4): an LDS-DMA ring (global_load_lds, 1-2 blocks/CU), weights-resident-in-LDS with
   // activations straight to registers (16 rows x 64 B request shape), prefetch distance 2, a persistent
   // tile loop, a direct-from-register epilogue.  They are not kept in the tree.
+  if (a->ksize == 1 && a->dtype != MOY_F32) {
+    const int rc = gemm_wreg_try(a, st);
+    if (rc != MOY_ENOSYS) return rc;
+  }
   if (a->ksize == 3 && a->dtype != MOY_F32) {
     const int rc = a->dtype == MOY_BF16 ? try_conv_direct<bf16_t>(p, a->B, ln, st) : try_conv_direct<f16_t>(p, a->B, ln, st);
     if (rc != MOY_ENOSYS) return rc;

@@ -1,0 +1,282 @@
+// Weight-stationary GEMM for the token-major linears of the path whose K is 256 (value_proj of all decoder layers in one
+// launch, transformer.py:255-257; enc_output, head.py:1036-1040): C[M, N] = act(A[M, 256] . W[N, 256]^T * scale + shift),
+// 16-bit types, M in the millions, N a multiple of 256.
+//
+// Why a second GEMM kernel: in the tiled kernel (gemm.hip) a 128x128x256 tile stages 128 KB through the VGPR->LDS store path
+// (~79 B/clk/CU) and re-reads 384 KB of fragments for only 512 MFMAs; with K this short the tile prologue, the LDS traffic and
+// the epilogue are not amortised and the value projection ran at 2.2 TB/s / 490 TFLOP/s.  Here
+//   * a block owns 256 output columns for its whole life: each of its 4 waves keeps W[64 columns][256 k] in REGISTERS
+//     (128 VGPRs as MFMA A-operand fragments) -- weights never touch LDS again;
+//   * the block walks row tiles of BM rows; an activation tile is BM x 512 B, brought in by LDS-DMA
+//     (global_load_lds_dwordx4: no VGPRs, no ds_write) into a ring of NBUF buffers, DIST = NBUF-1 tiles ahead of the MFMAs,
+//     retired by a counted vmcnt that leaves the younger tiles and the output stores in flight; ONE barrier per tile;
+//   * the LDS image of a tile row is its 32 16-B chunks with the chunk index XORed by (row & 15): the DMA destination is
+//     lane-linear, so the swizzle is applied to the per-lane SOURCE address; every ds_read_b128 fragment read is
+//     conflict-free (lanes of a 16-lane group hit 16 distinct chunk slots mod 16);
+//   * MFMA operands swapped (weights = A): a lane owns 4 consecutive output channels of one row, as in gemm.hip, and the k
+//     order per accumulator is the same 8 panels of 32 -> results are bit-identical to the tiled kernel;
+//   * epilogue per WAVE (its 64 columns = one 128-B line per row): accumulators -> wave-private LDS strip in the output
+//     type -> 16-byte stores of whole lines; no block barrier, so one wave's epilogue overlaps the other waves' MFMAs;
+//   * grid = 8 XCDs x slots; the N/256 column groups of one row-tile sequence sit on the SAME XCD and advance in lock step,
+//     so an activation tile is fetched from HBM once and hits that XCD's L2 for the other groups.
+#include "common.hpp"
+
+#include <type_traits>
+
+namespace moy {
+
+struct WregParams {
+  const void* A;
+  int64_t lda;
+  const void* W;
+  const float* scale;
+  const float* shift;
+  int act;
+  void* C;
+  int64_t ldc;
+  int M, N;
+  int ngroups;   // N / 256
+  int lanes;     // row-tile sequences per XCD
+  int ntiles;    // ceil(M / BM)
+};
+
+// LDS-DMA of 16 bytes per lane: LDS[m0 + lane*16 ..] <- *gsrc.  M0 is compiler-reserved: saved and restored in the statement.
+// Source = wave-uniform base (SGPR pair) + 32-bit per-lane byte offset.
+__device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(lds_dst), "s"(sbase)
+               : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T>
+__device__ __forceinline__ f32x4 mfma16(f32x4 acc, u32x4 w, u32x4 a);
+template <>
+__device__ __forceinline__ f32x4 mfma16<bf16_t>(f32x4 acc, u32x4 w, u32x4 a) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4 mfma16<f16_t>(f32x4 acc, u32x4 w, u32x4 a) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
+}
+
+template <int BM, int NBUF>
+constexpr int wreg_lds_bytes() { return NBUF * BM * 512 + 4 * BM * 136 + 2048; }
+
+template <typename T, int BM, int NBUF, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_wreg_kernel(const WregParams p) {
+  constexpr int MT = BM / 16;              // row sub-tiles per wave (every wave covers all BM rows)
+  constexpr int NT = 4;                    // 64 columns per wave
+  constexpr int TILE_BYTES = BM * 512;
+  constexpr int IPW = TILE_BYTES / 1024 / 4;   // DMA instructions per wave and tile
+  constexpr int DIST = NBUF - 1;           // tiles in flight ahead of the one being computed
+  constexpr int EP_PITCH = 136;            // bytes per row of the wave's epilogue strip (64 x 2 B + 8)
+  constexpr int NST = BM / 8;              // 16-byte store instructions per wave and tile
+  static_assert(BM % 16 == 0 && IPW >= 1, "tile");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases and descriptors live in SGPRs
+  const int r = lane & 15, q = lane >> 4;
+
+  // block -> (XCD, column group, row-tile lane)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int grp = slot % p.ngroups, ln = slot / p.ngroups;
+  if (ln >= p.lanes) return;
+  const int t0 = xcd + 8 * ln, tstep = 8 * p.lanes;
+  if (t0 >= p.ntiles) return;
+  const int n_mine = (p.ntiles - t0 + tstep - 1) / tstep;
+
+  unsigned char* ep = smem + NBUF * TILE_BYTES + wave * (BM * EP_PITCH);
+  float* ssc = reinterpret_cast<float*>(smem + NBUF * TILE_BYTES + 4 * BM * EP_PITCH);
+  float* ssh = ssc + 256;
+  const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+  const int nb = grp * 256;                // first output column of the block
+  {
+    ssc[tid] = p.scale ? p.scale[nb + tid] : 1.0f;
+    ssh[tid] = p.shift ? p.shift[nb + tid] : 0.0f;
+  }
+
+  // ---- DMA geometry (loop invariant): instruction I = wave*IPW + jj fills LDS bytes [I*1024, +1024) = tile rows 2I, 2I+1.
+  // Source address = scalar tile base + per-lane 32-bit offset; rows past M (last tile only) re-read row M-1, never stored.
+  const unsigned char* Ab = static_cast<const unsigned char*>(p.A);
+  const int drow0 = wave * IPW * 2 + (lane >> 5);                  // + 2*jj
+  const uint32_t lds_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_base + wave * IPW * 1024));
+  uint32_t dcol[IPW];                                              // byte offset of the source chunk inside its row
+#pragma unroll
+  for (int jj = 0; jj < IPW; ++jj) dcol[jj] = (uint32_t)(((lane & 31) ^ ((drow0 + 2 * jj) & 15)) * 16);
+  const uint32_t row_bytes = (uint32_t)(p.lda * 2);
+  auto issue_tile = [&](int tile, int buf) {
+    const int m0 = min(tile, p.ntiles - 1) * BM;                   // over-fetch tiles past the end re-read the last one
+    const unsigned char* tb = Ab + (int64_t)m0 * p.lda * 2;
+    const int last = p.M - 1 - m0;                                 // last valid row of this tile (>= BM-1 except in the tail)
+#pragma unroll
+    for (int jj = 0; jj < IPW; ++jj) {
+      const int row = min(drow0 + 2 * jj, last);
+      glds16(tb, (uint32_t)row * row_bytes + dcol[jj], lds_w + buf * TILE_BYTES + jj * 1024);
+    }
+  };
+
+  // ---- weights of this wave's 64 columns -> registers (MFMA A operand: lane (r,q) holds W[n = j*16 + r][k = pn*32 + q*8 ..+7])
+  u32x4 wf[NT][8];
+  {
+    const T* Wg = static_cast<const T*>(p.W) + (int64_t)(nb + wave * 64) * 256;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int pn = 0; pn < 8; ++pn) wf[j][pn] = *reinterpret_cast<const u32x4*>(Wg + (j * 16 + r) * 256 + pn * 32 + q * 8);
+  }
+
+  // prologue: DIST tiles in flight (tiles past the end are clamped re-reads that nobody consumes: the counts stay uniform)
+#pragma unroll
+  for (int d = 0; d < DIST; ++d) issue_tile(t0 + d * tstep, d);
+  wait_vmcnt<(DIST - 1) * IPW>();
+  __syncthreads();
+
+  const int lbase = r * 512 + ((q ^ r) << 4);      // fragment read: row i*16 + r, chunk (pn*4 + q) ^ r  ==  lbase ^ (pn*64) + i*8192
+  int buf = 0;
+  for (int it = 0; it < n_mine; ++it) {
+    const int tile = t0 + it * tstep;
+    {
+      int nbuf = buf + DIST; if (nbuf >= NBUF) nbuf -= NBUF;
+      issue_tile(tile + DIST * tstep, nbuf);
+    }
+    const unsigned char* As = smem + buf * TILE_BYTES;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragments of panel pn+1 are requested before the MFMAs of panel pn (counted lgkmcnt): with one wave per SIMD nothing
+    // else hides the LDS latency
+    u32x4 af[2][MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[0][i] = *reinterpret_cast<const u32x4*>(As + (lbase + i * 8192));
+#pragma unroll
+    for (int pn = 0; pn < 8; ++pn) {
+      if (pn + 1 < 8) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          af[(pn + 1) & 1][i] = *reinterpret_cast<const u32x4*>(As + ((lbase ^ ((pn + 1) * 64)) + i * 8192));
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs (the scheduler otherwise sinks them back)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<T>(acc[i][j], wf[j][pn], af[pn & 1][i]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue of this wave's BM x 64 strip
+    const int m0 = tile * BM;
+    auto stage = [&](auto act_c) {
+      constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(ssc + wave * 64 + j * 16 + q * 4);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(ssh + wave * 64 + j * 16 + q * 4);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          f32x4 v = acc[i][j] * sc + sh;
+          if constexpr (ACT == MOY_ACT_SILU) { v.x = siluf_(v.x); v.y = siluf_(v.y); v.z = siluf_(v.z); v.w = siluf_(v.w); }
+          else if constexpr (ACT == MOY_ACT_RELU) { v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f}); }
+          else if constexpr (ACT == MOY_ACT_SIGMOID) { v.x = fast_sigmoid(v.x); v.y = fast_sigmoid(v.y); v.z = fast_sigmoid(v.z); v.w = fast_sigmoid(v.w); }
+          *reinterpret_cast<u32x2*>(ep + (i * 16 + r) * EP_PITCH + (j * 16 + q * 4) * 2) =
+              u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+        }
+      }
+    };
+    switch (p.act) {   // wave-uniform
+      case MOY_ACT_SILU: stage(std::integral_constant<int, MOY_ACT_SILU>{}); break;
+      case MOY_ACT_RELU: stage(std::integral_constant<int, MOY_ACT_RELU>{}); break;
+      case MOY_ACT_SIGMOID: stage(std::integral_constant<int, MOY_ACT_SIGMOID>{}); break;
+      default: stage(std::integral_constant<int, MOY_ACT_NONE>{}); break;
+    }
+    {
+      // rows past M fall outside the descriptor and are dropped by the range check: the NST stores are unconditional
+      // (all strip reads first, then the stores back to back; the vmcnt bookkeeping below counts exactly NST)
+      const int cc = lane & 7, rr0 = lane >> 3;
+      T* cb = static_cast<T*>(p.C) + (int64_t)m0 * p.ldc + nb + wave * 64;
+      const int64_t left = ((int64_t)(p.M - 1 - m0) * p.ldc + 64) * 2;
+      const auto rsC = __builtin_amdgcn_make_buffer_rsrc(cb, 0, (uint32_t)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
+      u32x2 lo[NST], hi[NST];
+#pragma unroll
+      for (int k = 0; k < NST; ++k) {
+        const int rr = rr0 + k * 8;
+        lo[k] = *reinterpret_cast<const u32x2*>(ep + rr * EP_PITCH + cc * 16);
+        hi[k] = *reinterpret_cast<const u32x2*>(ep + rr * EP_PITCH + cc * 16 + 8);
+      }
+      const uint32_t voff0 = (uint32_t)(rr0 * (int)p.ldc + cc * 8) * 2, vstep = (uint32_t)p.ldc * 16;
+#pragma unroll
+      for (int k = 0; k < NST; ++k)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[k].x, lo[k].y, hi[k].x, hi[k].y}, rsC, voff0 + k * vstep, 0, 0);
+    }
+    // tile it+1 must have landed; the younger DMA tiles and the stores issued since stay in flight
+    wait_vmcnt<(DIST - 1) * (IPW + NST) + NST>();
+    __syncthreads();
+    if (++buf == NBUF) buf = 0;
+  }
+  wait_vmcnt<0>();   // clamped over-fetch tiles still target this block's LDS
+}
+
+static int wreg_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+template <typename T, int BM, int NBUF, int OCC>
+static int launch_wreg(WregParams& p, hipStream_t st) {
+  constexpr int lds = wreg_lds_bytes<BM, NBUF>();
+  auto kern = gemm_wreg_kernel<T, BM, NBUF, OCC>;
+  static bool attr_set = false;
+  if (lds > 65536 && !attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return MOY_ELAUNCH;
+    attr_set = true;
+  }
+  const int slots = wreg_num_cus() / 8 * OCC;          // resident blocks per XCD
+  p.ntiles = (p.M + BM - 1) / BM;
+  p.lanes = slots / p.ngroups;
+  if (p.lanes < 1) return MOY_ENOSYS;
+  hipLaunchKernelGGL(kern, dim3(8 * p.lanes * p.ngroups), dim3(256), lds, st, p);
+  return launch_status();
+}
+
+// Eligibility + dispatch; MOY_ENOSYS = not this kernel's shape (moy_gemm falls through to the tiled kernel).
+int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
+  static int mode = -1;                    // MOY_GEMM_WREG=0 switches the kernel off (A/B runs, bit-identity test)
+  if (mode < 0) { const char* e = getenv("MOY_GEMM_WREG"); mode = e ? atoi(e) : 1; }
+  if (!mode) return MOY_ENOSYS;
+  if (a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_ENOSYS;
+  if (a->ksize != 1 || a->K != 256 || a->N % 256 || a->N / 256 > 16) return MOY_ENOSYS;
+  if (a->A2 || a->a_rows || a->a_mask || a->R || a->ln_g || a->out_f32 || a->c_rows_per_batch || a->dot_n) return MOY_ENOSYS;
+  if (a->M < 65536) return MOY_ENOSYS;     // persistent row-tile walk: needs many tiles per block
+  if ((a->lda % 8) || (a->ldc % 8) || !aligned16(a->A) || !aligned16(a->C) || !aligned16(a->W)) return MOY_ENOSYS;
+  WregParams p{};
+  p.A = a->A; p.lda = a->lda; p.W = a->W; p.scale = a->scale; p.shift = a->shift; p.act = a->act;
+  p.C = a->C; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.ngroups = a->N / 256;
+  static int variant = -1;
+  if (variant < 0) { const char* e = getenv("MOY_WREG_VARIANT"); variant = e ? atoi(e) : 0; }
+  // measured on the value projection (M = 1.3 M, N = 1536, bf16): BM 32 / 3 buffers / 2 blocks per CU 1168 us,
+  // BM 64 / 3 buffers / 1 block per CU 1254 us, BM 64 / 2 buffers 1274 us (tiled kernel: 1951 us)
+  if (a->dtype == MOY_BF16) {
+    if (variant == 1) return launch_wreg<bf16_t, 64, 3, 1>(p, st);
+    if (variant == 2) return launch_wreg<bf16_t, 32, 4, 2>(p, st);
+    return launch_wreg<bf16_t, 32, 3, 2>(p, st);
+  }
+  return launch_wreg<f16_t, 32, 3, 2>(p, st);
+}
+
+}  // namespace moy

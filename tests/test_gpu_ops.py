@@ -55,6 +55,37 @@ def test_gemm_linear_variants(dt, M, N, K):
     assert torch.allclose(y.cpu(), ref, atol=tol(dt, 2e-5, 2e-2), rtol=1e-5)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,act", [(70000, 256, "none"), (65537, 512, "silu"), (66000 + 63, 1536, "none")])
+def test_gemm_weight_stationary_kernel_bit_identical_to_tiled(dt, M, N, act):
+    """K == 256, M >= 65536, 16-bit: moy_gemm runs the weight-stationary kernel (gemm_wreg.hip).  It must agree with the
+    torch fp32 reference and be BIT-identical to the tiled kernel (same MFMA, same k order), which is what runs when the
+    same rows are submitted as two launches of fewer than 65536 rows; ragged last tile, partial last row tile, channel-slice
+    output (ldc > N) and a padded input pitch (lda > K) included."""
+    K = 256
+    x, w = q(rnd(M, K, seed=11), dt), q(rnd(N, K, seed=12, scale=1 / math.sqrt(K)), dt)
+    b = rnd(N, seed=13, scale=0.1)
+    sc = (rnd(N, seed=14) * 0.2 + 1.0) if act == "silu" else None
+    xbuf = torch.zeros(M, K + 64, device=DEV, dtype=dt)
+    xbuf[:, :K] = x.to(DEV, dt)
+    xd = xbuf[:, :K]
+    wd = ops.pad_weight(w.to(DEV), dt)
+    code = L.ACT_SILU if act == "silu" else L.ACT_NONE
+    kw = dict(shift=b.to(DEV), scale=sc.to(DEV) if sc is not None else None, act=code)
+    out = torch.full((M + 1, N + 32), 7.0, device=DEV, dtype=dt)       # guard row / guard columns
+    ops.gemm(xd, wd, N, K, out=out[:M, :N], **kw)
+    h = M // 2
+    two = torch.empty(M, N, device=DEV, dtype=dt)
+    ops.gemm(xd[:h], wd, N, K, out=two[:h], **kw)
+    ops.gemm(xd[h:], wd, N, K, out=two[h:], **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:M, :N], two), "weight-stationary kernel differs from the tiled kernel"
+    assert bool((out[M] == 7.0).all()) and bool((out[:, N:] == 7.0).all()), "wrote outside its rows / columns"
+    ref = x @ w.T
+    ref = F.silu(ref * sc + b) if act == "silu" else ref + b
+    assert torch.allclose(out[:M, :N].float().cpu(), ref, atol=tol(dt), rtol=tol(dt, 1e-5, 1e-2))
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_layernorm_residual_prologue_add_gather_mask(dt):
     M, N, K = 333, 256, 256
