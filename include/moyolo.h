@@ -59,8 +59,8 @@ const char* moy_strerror(int code);
  *               A[((b*Hin + oy*stride+ky-1)*Win + ox*stride+kx-1) * lda + c], 0 outside the image
  *               (pad = 1).  Cin % 8 == 0 (16-bit types) / % 4 (f32).
  *   A2 (optional, ksize 1 only): added element-wise to A before the product (q = k = x + pos).
- *   a_mask (optional, ksize 1 only): rows with a_mask[m % mask_period] == 0 read as zero
- *               (valid_mask * feats, head.py:1039).
+ *   a_mask (optional, ksize 1 only): rows with a_mask[arow(m) % mask_period] == 0 read as zero
+ *               (valid_mask * feats, head.py:1039; the mask belongs to the token, gathered or not).
  * W: [N, Kpad] dtype T, K contiguous, Kpad = K rounded up to 64 (bf16) / 32 (f32), zero padded.
  * Epilogue, in this order (all optional, fp32 math):
  *   v = acc * scale[n] + shift[n]   (BN folded to scale/shift, or bias with scale == NULL)
@@ -68,6 +68,11 @@ const char* moy_strerror(int code);
  *   v += R[m * ldr + n]             (residual, dtype T)
  *   v = LayerNorm_n(v) * ln_g[n] + ln_b[n]   (eps 1e-5; requires N == 256)  [+ optional fused narrow head, see dot_*]
  *   C[m * ldc + n] = v              (dtype T, or fp32 when out_f32 != 0)
+ *   C == NULL is allowed when the fused narrow head (dot_*) is given: only dot_out is produced (enc_score_head over all
+ *   S tokens without materialising enc_output for them, head.py:1036-1042; the selected rows are recomputed afterwards).
+ * 16-bit launches with K == 256, N % 256 == 0 and M >= 65536 run a weight-stationary kernel (csrc/gemm_wreg.hip), with
+ * results bit-identical to the tiled kernel in store mode; its score mode evaluates the LayerNorm statistics in one pass
+ * (E[v^2] - mean^2), i.e. equal up to fp32 rounding.
  * -------------------------------------------------------------------------------------------- */
 typedef struct moy_gemm_args {
   const void* A;

@@ -139,6 +139,24 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
+// Division by a launch-time constant: q = (n * M) >> (32 + s) with M = ceil(2^(32+s) / d), s = ceil(log2 d), exact for
+// every 32-bit n (Granlund & Montgomery); M = 2^32 + magic.  A 32-bit divide by a runtime value costs ~35 VALU ops and
+// the tile set-up (pixel coordinates of every staged row) did five of them before the first load could issue.
+struct FastDiv {
+  uint32_t magic, shift, d;
+};
+static FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f{0u, 0u, d ? d : 1u};
+  d = f.d;
+  while ((1ull << f.shift) < d) ++f.shift;
+  f.magic = (uint32_t)((((1ull << f.shift) - d) << 32) / d + 1);   // ceil(2^(32+s)/d) - 2^32
+  if (d == 1) f.magic = 0;
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+  return (uint32_t)(((uint64_t)__umulhi(n, f.magic) + n) >> f.shift);
+}
+
 inline int launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MOY_OK : MOY_ELAUNCH;

@@ -22,24 +22,6 @@ namespace moy {
 
 constexpr int PANELS = 2;
 
-// Division by a launch-time constant: q = (n * M) >> (32 + s) with M = ceil(2^(32+s) / d), s = ceil(log2 d), exact for
-// every 32-bit n (Granlund & Montgomery); M = 2^32 + magic.  A 32-bit divide by a runtime value costs ~35 VALU ops and
-// the tile set-up (pixel coordinates of every staged row) did five of them before the first load could issue.
-struct FastDiv {
-  uint32_t magic, shift, d;
-};
-static FastDiv make_fastdiv(uint32_t d) {
-  FastDiv f{0u, 0u, d ? d : 1u};
-  d = f.d;
-  while ((1ull << f.shift) < d) ++f.shift;
-  f.magic = (uint32_t)((((1ull << f.shift) - d) << 32) / d + 1);   // ceil(2^(32+s)/d) - 2^32
-  if (d == 1) f.magic = 0;
-  return f;
-}
-__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
-  return (uint32_t)(((uint64_t)__umulhi(n, f.magic) + n) >> f.shift);
-}
-
 struct GemmParams {
   const void* A;
   const void* A2;
@@ -247,7 +229,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const float* 
           }
       }
     }
-    if (col_ok && m < p.M) {
+    if (col_ok && m < p.M && p.C) {   // C == NULL: score-only launch (LayerNorm + narrow head, rows not stored)
       int64_t mo = m;
       if (p.c_rpb) { const int bq = (int)fdiv(m, p.fd_rpb); mo = (int64_t)bq * p.c_bstride + (m - bq * p.c_rpb); }   // wave-uniform rare path
       unsigned char* cp = cbase + mo * p.ldc * out_esz;
@@ -410,8 +392,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
     a_taps[j] = 0;
     if (m < p.M) {
       if (KS == 1) {
-        const bool masked = p.a_mask && p.a_mask[m - (int)fdiv(m, p.fd_mask) * p.mask_period] == 0;
-        const int64_t row = p.a_rows ? (int64_t)p.a_rows[m] : (int64_t)(m - m0);
+        const int arow = p.a_rows ? p.a_rows[m] : m;     // the mask belongs to the A rows (tokens), gathered or not
+        const bool masked = p.a_mask && p.a_mask[arow - (int)fdiv(arow, p.fd_mask) * p.mask_period] == 0;
+        const int64_t row = p.a_rows ? (int64_t)arow : (int64_t)(m - m0);
         if (!masked) a_voff[j] = (uint32_t)((row * p.lda + kc0) * ESZ);
       } else {
         const int hw = p.Hout * p.Wout;
@@ -896,7 +879,8 @@ static int dispatch_tile(GemmParams& p, bool ln, hipStream_t st) {
 using namespace moy;
 
 extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
-  if (!a || !a->A || !a->W || !a->C) return MOY_EINVAL;
+  if (!a || !a->A || !a->W) return MOY_EINVAL;
+  if (!a->C && !(a->ln_g && a->dot_n > 0 && a->dot_out)) return MOY_EINVAL;   // rows may be dropped only when the fused head is the output
   if (a->dtype != MOY_F32 && a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_EINVAL;
   const int kpb = a->dtype == MOY_F32 ? 4 : 8;
   const int esz = a->dtype == MOY_F32 ? 4 : 2;

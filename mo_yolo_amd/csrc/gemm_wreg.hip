@@ -38,6 +38,16 @@ struct WregParams {
   int ngroups;   // N / 256
   int lanes;     // row-tile sequences per XCD
   int ntiles;    // ceil(M / BM)
+  // score mode (LN = true): LayerNorm statistics + the narrow head of the normalised row, nothing else is written
+  const float* ln_g;
+  const float* ln_b;
+  const float* dot_w;
+  const float* dot_b;
+  float* dot_out;
+  int dot_n;
+  const uint8_t* a_mask;
+  int mask_period;
+  FastDiv fd_mask;
 };
 
 // LDS-DMA of 16 bytes per lane: LDS[m0 + lane*16 ..] <- *gsrc.  M0 is compiler-reserved: saved and restored in the statement.
@@ -66,10 +76,14 @@ __device__ __forceinline__ f32x4 mfma16<f16_t>(f32x4 acc, u32x4 w, u32x4 a) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
 }
 
-template <int BM, int NBUF>
-constexpr int wreg_lds_bytes() { return NBUF * BM * 512 + 4 * BM * 136 + 2048; }
+constexpr int WREG_MAXDOT = 4;           // classes of the fused narrow head in score mode
+template <int BM, int NBUF, bool LN>
+constexpr int wreg_lds_bytes() {
+  // A ring | (store mode) 4 epilogue strips | scale, shift | (score mode) g*w per class, G/B constants, row partials [BM][6][16]
+  return NBUF * BM * 512 + (LN ? 0 : 4 * BM * 136) + 2048 + (LN ? WREG_MAXDOT * 1024 + 64 + BM * ((2 + WREG_MAXDOT) * 64 + 16) : 0);
+}
 
-template <typename T, int BM, int NBUF, int OCC>
+template <typename T, int BM, int NBUF, int OCC, bool LN>
 __global__ __launch_bounds__(256, OCC) void gemm_wreg_kernel(const WregParams p) {
   constexpr int MT = BM / 16;              // row sub-tiles per wave (every wave covers all BM rows)
   constexpr int NT = 4;                    // 64 columns per wave
@@ -77,7 +91,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_wreg_kernel(const WregParams p)
   constexpr int IPW = TILE_BYTES / 1024 / 4;   // DMA instructions per wave and tile
   constexpr int DIST = NBUF - 1;           // tiles in flight ahead of the one being computed
   constexpr int EP_PITCH = 136;            // bytes per row of the wave's epilogue strip (64 x 2 B + 8)
-  constexpr int NST = BM / 8;              // 16-byte store instructions per wave and tile
+  constexpr int NST = LN ? 0 : BM / 8;     // 16-byte store instructions per wave and tile (score mode: see below)
+  constexpr int EP_BYTES = LN ? 0 : 4 * BM * EP_PITCH;
   static_assert(BM % 16 == 0 && IPW >= 1, "tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -94,13 +109,48 @@ __global__ __launch_bounds__(256, OCC) void gemm_wreg_kernel(const WregParams p)
   const int n_mine = (p.ntiles - t0 + tstep - 1) / tstep;
 
   unsigned char* ep = smem + NBUF * TILE_BYTES + wave * (BM * EP_PITCH);
-  float* ssc = reinterpret_cast<float*>(smem + NBUF * TILE_BYTES + 4 * BM * EP_PITCH);
+  float* ssc = reinterpret_cast<float*>(smem + NBUF * TILE_BYTES + EP_BYTES);
   float* ssh = ssc + 256;
+  float* gw = ssh + 256;                   // score mode: ln_g[n] * dot_w[c][n]
+  float* GB = gw + WREG_MAXDOT * 256;      // [0..3] sum_n gw[c][n]; [4..7] sum_n ln_b[n] * dot_w[c][n] + dot_b[c]
+  constexpr int PROW = (2 + WREG_MAXDOT) * 16 + 4;   // floats per row of P: [quantity][wave * 4 + lane group]; +4: rows 4 banks apart
+  float* P = GB + 16;                      // row partials, reduced by wave 0 after one barrier
+  uint32_t* mbits = reinterpret_cast<uint32_t*>(P + BM * PROW);   // valid-token bitmask (mask_period bits), dynamic tail of the LDS
   const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);
   const int nb = grp * 256;                // first output column of the block
   {
     ssc[tid] = p.scale ? p.scale[nb + tid] : 1.0f;
     ssh[tid] = p.shift ? p.shift[nb + tid] : 0.0f;
+  }
+  if constexpr (LN) {
+    // score_c = sum_n LN(v)_n w_cn + b_c = rstd * (sum_n v_n g_n w_cn - mean * G_c) + B_c: every row quantity is a plain sum over
+    // the row, so ONE reduction round (sum v, sum v^2, sum v gw_c) replaces the normalise-then-dot passes
+#pragma unroll
+    for (int c = 0; c < WREG_MAXDOT; ++c) {
+      const float wv = c < p.dot_n ? p.dot_w[c * 256 + tid] : 0.0f;
+      const float g = p.ln_g[tid] * wv, bb = p.ln_b[tid] * wv;
+      gw[c * 256 + tid] = g;
+      const float gs = wave_sum(g), bs = wave_sum(bb);
+      if (lane == 0) { P[(c * 2 + 0) * 4 + wave] = gs; P[(c * 2 + 1) * 4 + wave] = bs; }
+    }
+    if (p.a_mask) {
+      const int nwords = (p.mask_period + 31) >> 5;
+      for (int w = tid; w < nwords; w += 256) {
+        uint32_t bits = 0;
+        for (int k = 0; k < 32; ++k) {
+          const int idx = w * 32 + k;
+          if (idx < p.mask_period && p.a_mask[idx]) bits |= 1u << k;
+        }
+        mbits[w] = bits;
+      }
+    }
+    __syncthreads();
+    if (tid < WREG_MAXDOT) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(P + (tid * 2 + 0) * 4), b = *reinterpret_cast<const f32x4*>(P + (tid * 2 + 1) * 4);
+      GB[tid] = a.x + a.y + a.z + a.w;
+      GB[4 + tid] = b.x + b.y + b.z + b.w + (tid < p.dot_n ? p.dot_b[tid] : 0.0f);
+    }
+    // (ordered before the first use by the barrier that ends the prologue)
   }
 
   // ---- DMA geometry (loop invariant): instruction I = wave*IPW + jj fills LDS bytes [I*1024, +1024) = tile rows 2I, 2I+1.
@@ -173,6 +223,87 @@ __global__ __launch_bounds__(256, OCC) void gemm_wreg_kernel(const WregParams p)
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    if constexpr (LN) {
+      // ---- score mode: row statistics of v = acc * scale + shift (masked token rows: v = shift, i.e. a zero A row) and the
+      // narrow head: every lane leaves its partial sums in LDS, wave 0 adds the 16 partials of each row after ONE barrier
+      const int m0 = tile * BM;
+      bool mk[MT];
+      {
+        const int mrem = p.a_mask ? m0 - (int)fdiv((uint32_t)m0, p.fd_mask) * p.mask_period : 0;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          mk[i] = false;
+          if (p.a_mask) {
+            int idx = mrem + i * 16 + r;
+            if (idx >= p.mask_period) idx -= p.mask_period;
+            mk[i] = ((mbits[idx >> 5] >> (idx & 31)) & 1u) == 0;
+          }
+        }
+      }
+      {
+        float s1[MT], s2[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int col = wave * 64 + j * 16 + q * 4;
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(ssc + col), sh = *reinterpret_cast<const f32x4*>(ssh + col);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const f32x4 v = mk[i] ? sh : acc[i][j] * sc + sh;
+            acc[i][j] = v;
+            s1[i] += (v.x + v.y) + (v.z + v.w);
+            s2[i] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          float* pr = P + (i * 16 + r) * PROW + wave * 4 + q;
+          pr[0] = s1[i];
+          pr[16] = s2[i];
+        }
+      }
+      for (int c = 0; c < p.dot_n; ++c) {     // one class at a time (rolled): the class count does not cost registers
+        float dd[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) dd[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const f32x4 gv = *reinterpret_cast<const f32x4*>(gw + c * 256 + wave * 64 + j * 16 + q * 4);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const f32x4 v = acc[i][j];
+            dd[i] += (v.x * gv.x + v.y * gv.y) + (v.z * gv.z + v.w * gv.w);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) P[(i * 16 + r) * PROW + 32 + c * 16 + wave * 4 + q] = dd[i];
+      }
+      __syncthreads();
+      if (wave == 0) {
+        const int row = lane < BM ? lane : 0;
+        const float* pr = P + row * PROW;
+        auto sum16 = [](const float* x) {   // the 16 partials of a row quantity: 4 waves x 4 lane groups
+          const f32x4 a = *reinterpret_cast<const f32x4*>(x), b = *reinterpret_cast<const f32x4*>(x + 4);
+          const f32x4 c = *reinterpret_cast<const f32x4*>(x + 8), d = *reinterpret_cast<const f32x4*>(x + 12);
+          const f32x4 t = (a + b) + (c + d);
+          return (t.x + t.y) + (t.z + t.w);
+        };
+        const float mean = sum16(pr) * (1.0f / 256.0f);
+        const float var = fmaxf(sum16(pr + 16) * (1.0f / 256.0f) - mean * mean, 0.0f);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        const int64_t nbytes = (int64_t)p.M * p.dot_n * 4;
+        const auto rsD = __builtin_amdgcn_make_buffer_rsrc(p.dot_out, 0, (uint32_t)(nbytes < 0x7fffffffLL ? nbytes : 0x7fffffffLL), 0x00020000);
+        const uint32_t off = lane < BM ? (uint32_t)((m0 + row) * p.dot_n) * 4u : 0x80000000u;   // rows >= M: out of range, dropped
+#pragma unroll
+        for (int c = 0; c < WREG_MAXDOT; ++c)
+          if (c < p.dot_n) {
+            const float sdot = rstd * (sum16(pr + 32 + c * 16) - mean * GB[c]) + GB[4 + c];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sdot), rsD, off + c * 4, 0, 0);
+          }
+      }
+      // Wave 0's few score stores are not counted below: its wait then also retires that many of the youngest DMA pieces.
+    } else {
     // ---- epilogue of this wave's BM x 64 strip
     const int m0 = tile * BM;
     auto stage = [&](auto act_c) {
@@ -217,6 +348,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_wreg_kernel(const WregParams p)
       for (int k = 0; k < NST; ++k)
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[k].x, lo[k].y, hi[k].x, hi[k].y}, rsC, voff0 + k * vstep, 0, 0);
     }
+    }
     // tile it+1 must have landed; the younger DMA tiles and the stores issued since stay in flight
     wait_vmcnt<(DIST - 1) * (IPW + NST) + NST>();
     __syncthreads();
@@ -236,15 +368,15 @@ static int wreg_num_cus() {
   return n;
 }
 
-template <typename T, int BM, int NBUF, int OCC>
+template <typename T, int BM, int NBUF, int OCC, bool LN = false>
 static int launch_wreg(WregParams& p, hipStream_t st) {
-  constexpr int lds = wreg_lds_bytes<BM, NBUF>();
-  auto kern = gemm_wreg_kernel<T, BM, NBUF, OCC>;
-  static bool attr_set = false;
-  if (lds > 65536 && !attr_set) {
+  const int lds = wreg_lds_bytes<BM, NBUF, LN>() + (LN && p.a_mask ? ((p.mask_period + 31) / 32) * 4 : 0);
+  auto kern = gemm_wreg_kernel<T, BM, NBUF, OCC, LN>;
+  static int attr_lds = 0;
+  if (lds > 65536 && lds > attr_lds) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return MOY_ELAUNCH;
-    attr_set = true;
+    attr_lds = lds;
   }
   const int slots = wreg_num_cus() / 8 * OCC;          // resident blocks per XCD
   p.ntiles = (p.M + BM - 1) / BM;
@@ -261,12 +393,27 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   if (!mode) return MOY_ENOSYS;
   if (a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_ENOSYS;
   if (a->ksize != 1 || a->K != 256 || a->N % 256 || a->N / 256 > 16) return MOY_ENOSYS;
-  if (a->A2 || a->a_rows || a->a_mask || a->R || a->ln_g || a->out_f32 || a->c_rows_per_batch || a->dot_n) return MOY_ENOSYS;
+  if (a->A2 || a->a_rows || a->R || a->out_f32 || a->c_rows_per_batch) return MOY_ENOSYS;
+  // score mode: LayerNorm + narrow head with NO feature output (C == NULL; moy_gemm documents it); the normalised rows
+  // themselves are the tiled kernel's job
+  const bool score = a->ln_g && !a->C;
+  if (score) {
+    if (a->N != 256 || a->dot_n < 1 || a->dot_n > WREG_MAXDOT || a->act != MOY_ACT_NONE) return MOY_ENOSYS;
+    if (a->a_mask && (a->mask_period < 64 || a->mask_period > 262144)) return MOY_ENOSYS;
+  } else if (a->ln_g || a->a_mask || a->dot_n || !a->C) {
+    return MOY_ENOSYS;
+  }
   if (a->M < 65536) return MOY_ENOSYS;     // persistent row-tile walk: needs many tiles per block
-  if ((a->lda % 8) || (a->ldc % 8) || !aligned16(a->A) || !aligned16(a->C) || !aligned16(a->W)) return MOY_ENOSYS;
+  if ((a->lda % 8) || !aligned16(a->A) || !aligned16(a->W)) return MOY_ENOSYS;
+  if (!score && ((a->ldc % 8) || !aligned16(a->C))) return MOY_ENOSYS;
   WregParams p{};
   p.A = a->A; p.lda = a->lda; p.W = a->W; p.scale = a->scale; p.shift = a->shift; p.act = a->act;
   p.C = a->C; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.ngroups = a->N / 256;
+  if (score) {
+    p.ln_g = a->ln_g; p.ln_b = a->ln_b; p.dot_w = a->dot_w; p.dot_b = a->dot_b; p.dot_out = a->dot_out; p.dot_n = a->dot_n;
+    p.a_mask = a->a_mask; p.mask_period = a->mask_period; p.fd_mask = make_fastdiv(a->mask_period > 0 ? a->mask_period : 1);
+    return a->dtype == MOY_BF16 ? launch_wreg<bf16_t, 32, 3, 2, true>(p, st) : launch_wreg<f16_t, 32, 3, 2, true>(p, st);
+  }
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("MOY_WREG_VARIANT"); variant = e ? atoi(e) : 0; }
   // measured on the value projection (M = 1.3 M, N = 1536, bf16): BM 32 / 3 buffers / 2 blocks per CU 1168 us,

@@ -148,7 +148,9 @@ class TrackEngine:
             a.R, a.ldr = R.ptr, R.ld
         if ln is not None:
             a.ln_g, a.ln_b = ln[0].data_ptr(), ln[1].data_ptr()
-        a.C, a.ldc, a.out_f32, a.dtype = C_.ptr, C_.ld, int(out_f32), self.code
+        if C_ is not None:
+            a.C, a.ldc = C_.ptr, C_.ld
+        a.out_f32, a.dtype = int(out_f32), self.code
         a.c_rows_per_batch, a.c_batch_stride = c_rpb, c_bstride
         if dot is not None:
             a.dot_w, a.dot_b, a.dot_out, a.dot_n = dot[0].data_ptr(), dot[1].data_ptr(), dot[2].data_ptr(), dot[0].shape[0]
@@ -158,7 +160,7 @@ class TrackEngine:
             a_elems = geom[0] * geom[1] * geom[2] * geom[5]      # every input pixel read once
         else:
             a_elems = M * K * (2 if A2 is not None else 1)
-        alg = (a_elems + N * K) * esz + M * N * (4 if out_f32 else esz) + (M * N * esz if R is not None else 0)
+        alg = (a_elems + N * K) * esz + (M * N * (4 if out_f32 else esz) if C_ is not None else 0) + (M * N * esz if R is not None else 0)
         tag = f"gemm{ksize}x{ksize}" + ("s2" if stride == 2 else "") + ("+ln" if ln is not None else "")
         self._add(self.lib.moy_gemm, C.byref(a), meta=dict(name=f"{tag} M{M} N{N} K{K}", bytes=alg, flops=2 * M * N * K))
 
@@ -319,17 +321,21 @@ class TrackEngine:
         self.anchors = self._dev(anchors[0])                        # [S, 4] (+inf at masked tokens)
         self.valid = self._dev(valid[0, :, 0].to(torch.uint8))     # [S]
 
-        features = View(self._buf(B * S, hd))
-        Wt, bias = self._linear_w(d + ".enc_output.0")
-        ln = (self._dev(sd[d + ".enc_output.1.weight"]), self._dev(sd[d + ".enc_output.1.bias"]))
+        # enc_output (Linear + LayerNorm, head.py:1036-1040) is row-wise and only the nq selected rows are ever read again
+        # (head.py:1048-1113), so the pass over all S tokens produces the enc_score_head logits ONLY (C = NULL): no [B*S, 256]
+        # write.  The selected rows are recomputed below by the same GEMM on gathered rows.
+        Wt_enc, bias_enc = self._linear_w(d + ".enc_output.0")
+        ln_enc = (self._dev(sd[d + ".enc_output.1.weight"]), self._dev(sd[d + ".enc_output.1.bias"]))
         self.scores_all = self._buf(B * S, nc, torch.float32)
         wsc, bsc = self._dev(sd[d + ".enc_score_head.weight"]), self._dev(sd[d + ".enc_score_head.bias"])
-        fuse_score = nc <= 8     # enc_score_head rides on the LayerNorm epilogue (no second pass over the features)
-        self._gemm(feats, Wt, hd, hd, features, B * S, shift=bias, a_mask=self.valid, mask_period=S, ln=ln,
-                   dot=(wsc, bsc, self.scores_all) if fuse_score else None)
-        self.features = features
-        if not fuse_score:
-            self._add(lib.moy_rowdot, features.ptr, features.ld, None, B * S, hd, wsc.data_ptr(), bsc.data_ptr(), nc, 0,
+        fuse_score = nc <= 8     # enc_score_head rides on the LayerNorm epilogue
+        if fuse_score:
+            self._gemm(feats, Wt_enc, hd, hd, None, B * S, shift=bias_enc, a_mask=self.valid, mask_period=S, ln=ln_enc,
+                       dot=(wsc, bsc, self.scores_all))
+        else:
+            allf = View(self._buf(B * S, hd))
+            self._gemm(feats, Wt_enc, hd, hd, allf, B * S, shift=bias_enc, a_mask=self.valid, mask_period=S, ln=ln_enc)
+            self._add(lib.moy_rowdot, allf.ptr, allf.ld, None, B * S, hd, wsc.data_ptr(), bsc.data_ptr(), nc, 0,
                       None, None, self.scores_all.data_ptr(), code)
 
         self.topk_local = torch.zeros(B, nq, device=self.dev, dtype=torch.int32)
@@ -356,15 +362,19 @@ class TrackEngine:
             self._add(lib.moy_rowdot, t2.ptr, t2.ld, None, M, hd, w2.data_ptr(), b2.data_ptr(), 4, mode,
                       aux.data_ptr(), aux_rows.data_ptr() if aux_rows is not None else None, out_t.data_ptr(), code)
 
-        self.refer_logit = self._buf(M, 4, torch.float32)
-        bbox_mlp(d + ".enc_bbox_head", features, self.topk_global, 2, self.anchors, self.topk_local, self.refer_logit)
-
-        embed = [View(self._buf(Md, hd)) for _ in range(2)]
+        # embed[0] = decoder input (never overwritten by the step), embed[1], embed[2] = layer outputs (ping-pong)
+        embed = [View(self._buf(Md, hd)) for _ in range(3)]
         qpos = View(self._buf(Md, hd))
         refs = [self._buf(Md, 4, torch.float32) for _ in range(2)]
+        # enc_output of the selected tokens = the decoder's content queries (head.py:1104-1113)
+        sel = embed[0] if not n_max else View(self._buf(M, hd))
+        self._gemm(feats, Wt_enc, hd, hd, sel, M, shift=bias_enc, a_rows=self.topk_global, a_mask=self.valid, mask_period=S,
+                   ln=ln_enc)
+        self.features = sel              # [B*nq, 256]: rows of enc_output at the selected tokens, in query order
+        self.refer_logit = self._buf(M, 4, torch.float32)
+        bbox_mlp(d + ".enc_bbox_head", sel, None, 2, self.anchors, self.topk_local, self.refer_logit)
+
         if not n_max:
-            self._add(lib.moy_gather_rows, features.ptr, features.ld, self.topk_global.data_ptr(), M, hd, embed[0].ptr,
-                      embed[0].ld, code)
             self._add(lib.moy_pos2posemb, self.refer_logit.data_ptr(), M, qpos.ptr, qpos.ld, code)
             self._add(lib.moy_sigmoid_f32, self.refer_logit.data_ptr(), M * 4, refs[0].data_ptr())
             self.refer_all = self.refer_logit
@@ -377,9 +387,7 @@ class TrackEngine:
                             dis=torch.zeros(B, n_max, device=self.dev, dtype=i32),
                             n=torch.zeros(B, device=self.dev, dtype=i32),
                             max_obj_id=torch.zeros(B, device=self.dev, dtype=i64))
-            det_embed, det_qpos = View(self._buf(M, hd)), View(self._buf(M, hd))
-            self._add(lib.moy_gather_rows, features.ptr, features.ld, self.topk_global.data_ptr(), M, hd, det_embed.ptr,
-                      det_embed.ld, code)
+            det_embed, det_qpos = sel, View(self._buf(M, hd))
             self._add(lib.moy_pos2posemb, self.refer_logit.data_ptr(), M, det_qpos.ptr, det_qpos.ld, code)
             self.refer_all = self._buf(Md, 4, torch.float32)
             t = self.trk
@@ -408,11 +416,12 @@ class TrackEngine:
         self._keep.append(shapes_c)
         self.layer_out = []
         cur, nxt = 0, 1
+        ecur, enxt = 0, 1
         for i in range(ndl):
             q = f"{d}.decoder.layers.{i}"
             Wqk, bqk = self._linear_w_raw(sd[q + ".self_attn.in_proj_weight"][:2 * hd], sd[q + ".self_attn.in_proj_bias"][:2 * hd])
             Wvv, bvv = self._linear_w_raw(sd[q + ".self_attn.in_proj_weight"][2 * hd:], sd[q + ".self_attn.in_proj_bias"][2 * hd:])
-            x = embed[cur]
+            x = embed[ecur]
             self._gemm(x, Wqk, 2 * hd, hd, qkv.slice(0, 2 * hd), M, shift=bqk, A2=qpos)
             self._gemm(x, Wvv, hd, hd, qkv.slice(2 * hd, hd), M, shift=bvv)
             if n_max:   # keys: live track slots + this frame's detect queries
@@ -434,11 +443,12 @@ class TrackEngine:
             W1, b1 = self._linear_w(q + ".linear1")
             W2, b2 = self._linear_w(q + ".linear2")
             self._gemm(e2, W1, arch.d_ffn, hd, ffn, M, shift=b1, act=L.ACT_RELU)
-            self._gemm(ffn, W2, hd, arch.d_ffn, embed[nxt], M, shift=b2, R=e2, ln=self._ln(q + ".norm3"))
-            bbox_mlp(f"{d}.dec_bbox_head.{i}", embed[nxt], None, 1, refs[cur], None, refs[nxt], M=M)
-            self.layer_out.append((embed[nxt], refs[nxt]))
+            self._gemm(ffn, W2, hd, arch.d_ffn, embed[enxt], M, shift=b2, R=e2, ln=self._ln(q + ".norm3"))
+            bbox_mlp(f"{d}.dec_bbox_head.{i}", embed[enxt], None, 1, refs[cur], None, refs[nxt], M=M)
+            self.layer_out.append((embed[enxt], refs[nxt]))
             cur, nxt = nxt, cur
-        self.hs = embed[cur]
+            ecur, enxt = enxt, (2 if enxt == 1 else 1)
+        self.hs = embed[ecur]
         self.boxes = refs[cur]
         self.logits = self._buf(M, nc, torch.float32)
         wd = self._dev(sd[f"{d}.dec_score_head.{ndl - 1}.weight"])

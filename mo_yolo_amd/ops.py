@@ -47,8 +47,9 @@ def pad_weight(w2d: torch.Tensor, dtype) -> torch.Tensor:
 
 def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shift=None, act=L.ACT_NONE, A2=None,
          a_rows=None, a_mask=None, mask_period=0, R=None, ln=None, out_f32=False, M=None, c_rpb=0, c_bstride=0,
-         dot=None):
-    """See moy_gemm.  A: 2-D row-major view [rows, >=Cin] (channels-last pixels or tokens)."""
+         dot=None, store=True):
+    """See moy_gemm.  store=False (with dot): C = NULL, only the fused head's output is produced (returned as (None, dot_out)).
+    A: 2-D row-major view [rows, >=Cin] (channels-last pixels or tokens)."""
     _need_gpu(A, Wp)
     a = L.GemmArgs()
     a.A, a.lda = A.data_ptr(), _ld(A)
@@ -77,10 +78,14 @@ def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shi
         a.R, a.ldr = R.data_ptr(), _ld(R)
     if ln is not None:
         a.ln_g, a.ln_b = ln[0].data_ptr(), ln[1].data_ptr()
-    if out is None:
-        rows = M if not c_rpb else (M // c_rpb) * c_bstride
-        out = torch.empty(rows, N, device=A.device, dtype=torch.float32 if out_f32 else A.dtype)
-    a.C, a.ldc, a.out_f32, a.dtype = out.data_ptr(), _ld(out), int(out_f32), _code(A)
+    if not store:
+        assert dot is not None and out is None
+        a.out_f32, a.dtype = int(out_f32), _code(A)
+    else:
+        if out is None:
+            rows = M if not c_rpb else (M // c_rpb) * c_bstride
+            out = torch.empty(rows, N, device=A.device, dtype=torch.float32 if out_f32 else A.dtype)
+        a.C, a.ldc, a.out_f32, a.dtype = out.data_ptr(), _ld(out), int(out_f32), _code(A)
     a.c_rows_per_batch, a.c_batch_stride = c_rpb, c_bstride
     dot_out = None
     if dot is not None:     # (w fp32 [n, 256], b fp32 [n]) fused behind the LayerNorm

@@ -47,10 +47,12 @@ def test_engine_fp32_seams_vs_oracle(name, B):
         chk(f"L{L_.i}({L_.kind})", nhwc_to_nchw(eng.layer_views[L_.i], B, eng.layer_hw[L_.i]), outs[L_.i], 1e-4)
     S = eng.S
     chk("feats", eng.feats.tensor().float().cpu().view(B, S, -1), r["feats"], 1e-4)
-    chk("features", eng.features.tensor().float().cpu().view(B, S, -1), r["features"], 2e-4)
     chk("enc_scores_all", eng.scores_all.cpu().view(B, S, -1), r["enc_scores_all"], 2e-4)
     assert np.array_equal(eng.valid.cpu().numpy().astype(bool), r["valid"][0, :, 0].numpy())
     tk = out["topk_ind"].cpu().long()
+    # enc_output is materialised for the selected tokens only (the pass over all S tokens yields the score logits)
+    chk("features[selected]", eng.features.tensor().float().cpu().view(B, arch.nq, -1),
+        r["features"][torch.arange(B)[:, None], tk], 2e-4)
     if not torch.equal(tk, r["topk_ind"]):
         errs.append(f"topk order differs at {(tk != r['topk_ind']).sum().item()} positions")
         outs, r, trace = run_oracle(cfg, arch, sd, 0, B, topk=tk)      # same query order for the rest

@@ -86,6 +86,33 @@ def test_gemm_weight_stationary_kernel_bit_identical_to_tiled(dt, M, N, act):
     assert torch.allclose(out[:M, :N].float().cpu(), ref, atol=tol(dt), rtol=tol(dt, 1e-5, 1e-2))
 
 
+@pytest.mark.parametrize("dt,M,nc", [(torch.bfloat16, 70001, 1), (torch.float16, 66000, 3), (torch.float32, 700, 2),
+                                     (torch.bfloat16, 1000, 5)])
+def test_gemm_score_only_layernorm_head(dt, M, nc):
+    """C == NULL: LayerNorm + narrow head over all rows, rows not stored (enc_score_head over the S tokens, head.py:1036-1042).
+    16-bit, M >= 65536, nc <= 4 runs the weight-stationary kernel's one-pass statistics; otherwise the tiled kernel.  Masked
+    rows (period mask, wrapping inside tiles) read as zero rows."""
+    N = K = 256
+    x, w = q(rnd(M, K, seed=21), dt), q(rnd(N, K, seed=22, scale=1 / math.sqrt(K)), dt)
+    b, g, be = rnd(N, seed=23, scale=0.1), rnd(N, seed=24) * 0.2 + 1.0, rnd(N, seed=25, scale=0.1)
+    dw, db = rnd(nc, N, seed=26, scale=0.1), rnd(nc, seed=27)
+    period = 997
+    mask = (torch.arange(period) % 5 != 0).to(torch.uint8)
+    xd, wd = x.to(DEV, dt), ops.pad_weight(w.to(DEV), dt)
+    _, sc = ops.gemm(xd, wd, N, K, shift=b.to(DEV), a_mask=mask.to(DEV), mask_period=period, ln=(g.to(DEV), be.to(DEV)),
+                     dot=(dw.to(DEV), db.to(DEV)), store=False)
+    mrow = mask[torch.arange(M) % period].float()[:, None]
+    ref = F.layer_norm((x * mrow) @ w.T + b, (N,), g, be, 1e-5) @ dw.T + db
+    assert sc.shape == (M, nc)
+    assert torch.allclose(sc.cpu(), ref, atol=tol(dt, 5e-5, 5e-2))
+    # gathered rows carry their token's mask (the recompute of the selected enc_output rows)
+    rows = torch.randperm(M, generator=torch.Generator().manual_seed(9))[:300].int()
+    y = ops.gemm(xd, wd, N, K, shift=b.to(DEV), a_rows=rows.to(DEV), a_mask=mask.to(DEV), mask_period=period,
+                 ln=(g.to(DEV), be.to(DEV)))
+    ref = F.layer_norm((x * mrow)[rows.long()] @ w.T + b, (N,), g, be, 1e-5)
+    assert torch.allclose(y.float().cpu(), ref, atol=tol(dt, 3e-5, 4e-2))
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_layernorm_residual_prologue_add_gather_mask(dt):
     M, N, K = 333, 256, 256
