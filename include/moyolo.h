@@ -109,6 +109,14 @@ typedef struct moy_gemm_args {
   const float* dot_b;
   float* dot_out;
   int32_t dot_n;
+  /* optional accumulator seed (NULL = zeros), ksize 1 only: the row m = (b, y, x) of a [B, pre_h, pre_w] raster starts from
+   *   pre[((b * (pre_h/2) + y/2) * (pre_w/2) + x/2) * ld_pre + n]            (fp32, pre_h and pre_w even)
+   * i.e. from the nearest-2x upsampled rows of a half-resolution product.  A 1x1 conv commutes with nn.Upsample(nearest), so
+   * Conv1x1(Concat[Upsample(u), s]) = W_u.u (at HALF resolution, seeded here) + W_s.s: the neck's Upsample + Concat
+   * (yolo_track.yaml:28-33, conv.py:295-297) need no kernel and no full-resolution copy of u. */
+  const float* pre;
+  int64_t ld_pre;
+  int32_t pre_h, pre_w;
 } moy_gemm_args;
 
 int moy_gemm(const moy_gemm_args* args, void* stream);

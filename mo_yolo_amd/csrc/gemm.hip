@@ -53,6 +53,10 @@ struct GemmParams {
   int wide_store;   // bf16 output, N % 8 == 0, 16-byte aligned rows: 8 columns per store
   int tiles_n, nblocks;
   FastDiv fd_tiles_n, fd_hw, fd_wout, fd_mask, fd_rpb;
+  const float* pre;    // accumulator seed: nearest-2x upsampled rows of a half-resolution product (moy_gemm_args.pre)
+  int64_t ld_pre;
+  int pre_w, pre_hw, pre_loww, pre_lowhw;
+  FastDiv fd_pre_hw, fd_pre_w;
 };
 
 // 16-B column swizzle: lanes of one ds_read_b128 lane group hit distinct bank quartets.
@@ -471,6 +475,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (p.pre) {   // wave-uniform; the loads are in flight under the first staging loads
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * TM + i * 16 + r;
+      if (m < p.M) {
+        const int b = (int)fdiv(m, p.fd_pre_hw), rem = m - b * p.pre_hw;
+        const int y = (int)fdiv(rem, p.fd_pre_w), x = rem - y * p.pre_w;
+        const float* pr = p.pre + ((int64_t)b * p.pre_lowhw + (y >> 1) * p.pre_loww + (x >> 1)) * p.ld_pre;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = n0 + wn * TN + j * 16 + q * 4;
+          if (n < p.N) acc[i][j] = *reinterpret_cast<const f32x4*>(pr + n);
+        }
+      }
+    }
+  }
 
   auto compute_stage = [&](int buf) {
     const unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
@@ -927,6 +948,13 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
   if (a->dot_n < 0 || a->dot_n > 8) return MOY_EINVAL;
   if (a->dot_n && (!ln || !a->dot_w || !a->dot_b || !a->dot_out || !aligned16(a->dot_w))) return MOY_EINVAL;
   p.dot_w = a->dot_w; p.dot_b = a->dot_b; p.dot_out = a->dot_out; p.dot_n = a->dot_n;
+  if (a->pre) {
+    if (a->ksize != 1 || a->pre_h <= 0 || a->pre_w <= 0 || (a->pre_h & 1) || (a->pre_w & 1) || a->M % (a->pre_h * a->pre_w)) return MOY_EINVAL;
+    if (!aligned16(a->pre) || (a->ld_pre % 4) || a->ld_pre < a->N) return MOY_EINVAL;
+    p.pre = a->pre; p.ld_pre = a->ld_pre; p.pre_w = a->pre_w; p.pre_hw = a->pre_h * a->pre_w;
+    p.pre_loww = a->pre_w / 2; p.pre_lowhw = (a->pre_h / 2) * (a->pre_w / 2);
+    p.fd_pre_hw = make_fastdiv((uint32_t)p.pre_hw); p.fd_pre_w = make_fastdiv((uint32_t)p.pre_w);
+  }
   p.wide_store = a->dtype != MOY_F32 && !a->out_f32 && !ln && a->N % 8 == 0 && (a->ldc % 8) == 0 && aligned16(a->C) &&
                  (!a->R || ((a->ldr % 8) == 0 && aligned16(a->R)));
   if (a->ksize == 1) {

@@ -393,7 +393,7 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   if (!mode) return MOY_ENOSYS;
   if (a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_ENOSYS;
   if (a->ksize != 1 || a->K != 256 || a->N % 256 || a->N / 256 > 16) return MOY_ENOSYS;
-  if (a->A2 || a->a_rows || a->R || a->out_f32 || a->c_rows_per_batch) return MOY_ENOSYS;
+  if (a->A2 || a->a_rows || a->R || a->out_f32 || a->c_rows_per_batch || a->pre) return MOY_ENOSYS;
   // score mode: LayerNorm + narrow head with NO feature output (C == NULL; moy_gemm documents it); the normalised rows
   // themselves are the tiled kernel's job
   const bool score = a->ln_g && !a->C;

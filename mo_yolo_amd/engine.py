@@ -12,6 +12,8 @@ PyTorch is used for device memory and streams only.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Dict, List
 
@@ -127,7 +129,7 @@ class TrackEngine:
 
     def _gemm(self, A: View, Wt, N, K, C_: View, M, *, ksize=1, stride=1, geom=None, scale=None, shift=None, act=0,
               A2: View | None = None, a_rows=None, a_mask=None, mask_period=0, R: View | None = None, ln=None,
-              out_f32=False, c_rpb=0, c_bstride=0, dot=None):
+              out_f32=False, c_rpb=0, c_bstride=0, dot=None, pre=None):
         a = L.GemmArgs()
         a.A, a.lda = A.ptr, A.ld
         a.A2 = A2.ptr if A2 is not None else None
@@ -154,6 +156,9 @@ class TrackEngine:
         a.c_rows_per_batch, a.c_batch_stride = c_rpb, c_bstride
         if dot is not None:
             a.dot_w, a.dot_b, a.dot_out, a.dot_n = dot[0].data_ptr(), dot[1].data_ptr(), dot[2].data_ptr(), dot[0].shape[0]
+        if pre is not None:
+            pt, ph, pw = pre
+            a.pre, a.ld_pre, a.pre_h, a.pre_w = pt.data_ptr(), pt.stride(0), ph, pw
         self._keep.append(a)
         esz = 4 if self.dtype == torch.float32 else 2
         if geom is not None:
@@ -165,11 +170,23 @@ class TrackEngine:
         self._add(self.lib.moy_gemm, C.byref(a), meta=dict(name=f"{tag} M{M} N{N} K{K}", bytes=alg, flops=2 * M * N * K))
 
     # conv + BN + SiLU on channels-last views
-    def _conv(self, p, x: View, hw_in, cin, cout, k, s, out: View, R: View | None = None, act=L.ACT_SILU):
+    def _conv(self, p, x: View, hw_in, cin, cout, k, s, out: View, R: View | None = None, act=L.ACT_SILU, up_src=None):
+        """up_src = (u view, (h, w), cu): the conv's input is Concat[Upsample2x(u), x] (u at half resolution, cu channels first)."""
         sd = self.sd
         w = sd[p + ".conv.weight"]
         scale, shift = self._bn(p + ".bn")
         Hin, Win = hw_in
+        if k == 1 and up_src is not None:
+            # Conv1x1(Concat[Upsample(u), x]) = Upsample(W_u . u) + W_x . x: the u half of the product is formed at HALF
+            # resolution (fp32, no rounding) and seeds the accumulators of the full-resolution GEMM over x alone
+            u, (hu, wu), cu = up_src
+            assert (2 * hu, 2 * wu) == (Hin, Win) and w.shape[1] == cu + cin
+            w2 = w.reshape(cout, cu + cin)
+            t = self._buf(self.B * hu * wu, cout, torch.float32)
+            self._gemm(u, self._weight(w2[:, :cu]), cout, cu, View(t), self.B * hu * wu, out_f32=True)
+            self._gemm(x, self._weight(w2[:, cu:]), cout, cin, out, self.B * Hin * Win, scale=scale, shift=shift, act=act, R=R,
+                       pre=(t, Hin, Win))
+            return hw_in
         if k == 1:
             Wt = self._weight(w.reshape(cout, cin))
             self._gemm(x, Wt, cout, cin, out, self.B * Hin * Win, scale=scale, shift=shift, act=act, R=R)
@@ -239,6 +256,21 @@ class TrackEngine:
                 h_, w_ = hw[i]
                 return View(self._buf(B * h_ * w_, c))
 
+            # Upsample -> Concat -> C2f (yolo_track.yaml:28-33): when the concat's only consumer is that C2f, neither the
+            # upsampled tensor nor its copy into the concat buffer is ever formed (see _conv up_src)
+            consumers: Dict[int, list] = {}
+            for Ls in arch.layers:
+                for j in Ls.src:
+                    consumers.setdefault(j if j >= 0 else Ls.i - 1, []).append(Ls.i)
+            virt_up: Dict[int, tuple] = {}       # Upsample layer -> (source view, source hw, channels)
+            virt_cat: Dict[int, tuple] = {}      # Concat layer -> (u view, u hw, cu, x view, cx)
+            def fusable(cat):
+                if cat.kind != "Concat" or len(cat.src) != 2:
+                    return False
+                up = arch.layers[cat.src[0]]
+                cons = [arch.layers[c] for c in consumers.get(cat.i, [])]
+                return (up.kind == "Upsample" and consumers.get(up.i, []) == [cat.i] and len(cons) == 1 and cons[0].kind == "C2f"
+                        and os.environ.get("MOY_FUSE_UPSAMPLE", "1") != "0")
             for Ls in arch.layers:
                 p = f"model.{Ls.i}"
                 x = outv[Ls.src[0]] if Ls.src[0] >= 0 else None
@@ -266,7 +298,11 @@ class TrackEngine:
                     h_, w_ = hin
                     cat = View(self._buf(B * h_ * w_, (2 + Ls.n) * c))
                     tmp = View(self._buf(B * h_ * w_, c))
-                    self._conv(p + ".cv1", x, hin, Ls.c1, 2 * c, 1, 1, cat.slice(0, 2 * c))
+                    if Ls.src[0] in virt_cat:
+                        u, uhw, cu, xs, cx = virt_cat[Ls.src[0]]
+                        self._conv(p + ".cv1", xs, hin, cx, 2 * c, 1, 1, cat.slice(0, 2 * c), up_src=(u, uhw, cu))
+                    else:
+                        self._conv(p + ".cv1", x, hin, Ls.c1, 2 * c, 1, 1, cat.slice(0, 2 * c))
                     for j in range(Ls.n):
                         src = cat.slice((1 + j) * c, c)
                         self._conv(f"{p}.m.{j}.cv1", src, hin, c, c, 3, 1, tmp)
@@ -286,14 +322,23 @@ class TrackEngine:
                     self._conv(p + ".cv2", cat, hin, 4 * c_, Ls.c2, 1, 1, o)
                     outv[Ls.i] = o
                 elif Ls.kind == "Upsample":
-                    o = out_view(Ls.i, Ls.c2)
-                    self._add(lib.moy_upsample2x, x.ptr, x.ld, B, hin[0], hin[1], Ls.c1, o.ptr, o.ld, code)
-                    outv[Ls.i] = o
+                    cat = arch.layers[consumers[Ls.i][0]] if len(consumers.get(Ls.i, [])) == 1 else None
+                    if cat is not None and fusable(cat):
+                        virt_up[Ls.i] = (x, hin, Ls.c1)
+                        outv[Ls.i] = None
+                    else:
+                        o = out_view(Ls.i, Ls.c2)
+                        self._add(lib.moy_upsample2x, x.ptr, x.ld, B, hin[0], hin[1], Ls.c1, o.ptr, o.ld, code)
+                        outv[Ls.i] = o
                 elif Ls.kind == "Concat":
                     outv[Ls.i] = home[Ls.i]
+                    if Ls.src[0] in virt_up:
+                        u, uhw, cu = virt_up[Ls.src[0]]
+                        virt_cat[Ls.i] = (u, uhw, cu, home[Ls.src[1]], arch.layers[Ls.src[1]].c2)
                 else:
                     raise ValueError(Ls.kind)
             self.layer_views, self.layer_hw = outv, hw
+            self.virtual_layers = set(virt_up) | set(virt_cat)     # never materialised (Upsample + Concat folded into the C2f)
 
             head_src = [(outv[j], hw[j]) for j in (15, 18, 21)]
         self._head_start = len(self._steps)

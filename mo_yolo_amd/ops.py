@@ -47,7 +47,7 @@ def pad_weight(w2d: torch.Tensor, dtype) -> torch.Tensor:
 
 def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shift=None, act=L.ACT_NONE, A2=None,
          a_rows=None, a_mask=None, mask_period=0, R=None, ln=None, out_f32=False, M=None, c_rpb=0, c_bstride=0,
-         dot=None, store=True):
+         dot=None, store=True, pre=None):
     """See moy_gemm.  store=False (with dot): C = NULL, only the fused head's output is produced (returned as (None, dot_out)).
     A: 2-D row-major view [rows, >=Cin] (channels-last pixels or tokens)."""
     _need_gpu(A, Wp)
@@ -87,6 +87,10 @@ def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shi
             out = torch.empty(rows, N, device=A.device, dtype=torch.float32 if out_f32 else A.dtype)
         a.C, a.ldc, a.out_f32, a.dtype = out.data_ptr(), _ld(out), int(out_f32), _code(A)
     a.c_rows_per_batch, a.c_batch_stride = c_rpb, c_bstride
+    if pre is not None:     # (fp32 [B*(H/2)*(W/2), >=N], H, W): accumulator seed = nearest-2x upsampled half-resolution product
+        pt, ph, pw = pre
+        assert pt.dtype == torch.float32
+        a.pre, a.ld_pre, a.pre_h, a.pre_w = pt.data_ptr(), _ld(pt), ph, pw
     dot_out = None
     if dot is not None:     # (w fp32 [n, 256], b fp32 [n]) fused behind the LayerNorm
         dw, db = dot

@@ -114,6 +114,26 @@ def test_gemm_score_only_layernorm_head(dt, M, nc):
 
 
 @pytest.mark.parametrize("dt", DT)
+def test_gemm_upsampled_accumulator_seed(dt):
+    """Conv1x1(Concat[Upsample2x(u), s]) == GEMM over s seeded with the nearest-2x rows of the half-resolution product W_u.u
+    (yolo_track.yaml:28-33 without the upsample / concat copies); ragged tile tails on both GEMMs."""
+    B, h, w, cu, cs, N = 2, 7, 9, 64, 32, 96
+    H, W = 2 * h, 2 * w
+    u, s_ = q(rnd(B, cu, h, w, seed=31), dt), q(rnd(B, cs, H, W, seed=32), dt)
+    wt = q(rnd(N, cu + cs, seed=33, scale=1 / math.sqrt(cu + cs)), dt)
+    sc, sh = rnd(N, seed=34) * 0.2 + 1, rnd(N, seed=35, scale=0.1)
+    cat = torch.cat([F.interpolate(u, scale_factor=2, mode="nearest"), s_], 1)
+    ref = F.silu(F.conv2d(cat, wt[:, :, None, None]) * sc[None, :, None, None] + sh[None, :, None, None])
+    ud = u.permute(0, 2, 3, 1).reshape(B * h * w, cu).contiguous().to(DEV, dt)
+    sd_ = s_.permute(0, 2, 3, 1).reshape(B * H * W, cs).contiguous().to(DEV, dt)
+    t = ops.gemm(ud, ops.pad_weight(wt[:, :cu].to(DEV), dt), N, cu, out_f32=True)
+    y = ops.gemm(sd_, ops.pad_weight(wt[:, cu:].to(DEV), dt), N, cs, scale=sc.to(DEV), shift=sh.to(DEV), act=L.ACT_SILU,
+                 pre=(t, H, W))
+    got = y.float().cpu().view(B, H, W, N).permute(0, 3, 1, 2)
+    assert torch.allclose(got, ref, atol=tol(dt, 2e-5, 3e-2), rtol=tol(dt, 1e-5, 1e-2))
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_gemm_layernorm_residual_prologue_add_gather_mask(dt):
     M, N, K = 333, 256, 256
     x, p = q(rnd(M, K, seed=1), dt), q(rnd(M, K, seed=6), dt)
