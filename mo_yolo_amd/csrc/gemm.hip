@@ -874,6 +874,10 @@ static int try_conv_direct(GemmParams& p, int B, bool ln, hipStream_t st) {
     static int th64 = -1;
     if (th64 < 0) { const char* e = getenv("MOY_TH64"); th64 = e ? atoi(e) : 16; }
     if (p.Cin == 64 && p.N % 64 == 0) return (big && th64 == 16) ? launch_conv_direct<T, 64, 64, 16, 4, 1>(p, B, st) : launch_conv_direct<T, 64, 64, 8, 4, 1>(p, B, st);
+    static int bn128 = -1;
+    if (bn128 < 0) { const char* e = getenv("MOY_BN128"); bn128 = e ? atoi(e) : 0; }
+    if (bn128 && p.Cin == 128 && p.N % 128 == 0 && big) return launch_conv_direct<T, 128, 128, 16, 4, 2>(p, B, st);
+    if (bn128 == 2 && p.Cin == 128 && p.N % 128 == 0) return launch_conv_direct<T, 128, 128, 8, 4, 2>(p, B, st);
     if (p.Cin == 128 && p.N % 64 == 0) return big ? launch_conv_direct<T, 128, 64, 16, 4, 1>(p, B, st) : launch_conv_direct<T, 128, 64, 8, 4, 1>(p, B, st);
     return MOY_ENOSYS;
   }
@@ -882,6 +886,12 @@ static int try_conv_direct(GemmParams& p, int B, bool ln, hipStream_t st) {
 template <typename T, int KS>
 static int dispatch_tile(GemmParams& p, bool ln, hipStream_t st) {
   if (ln) return launch_cfg<T, 64, 256, 2, 4, true, KS>(p, st);
+  static int force = -1;   // MOY_TILE: tuning knob (tools/bench_gemm.py); 0 = the measured heuristic below
+  if (force < 0) { const char* e = getenv("MOY_TILE"); force = e ? atoi(e) : 0; }
+  if (force == 1) return launch_cfg<T, 128, 128, 2, 4, false, KS>(p, st);
+  if (force == 2) return launch_cfg<T, 64, 128, 2, 2, false, KS>(p, st);
+  if (force == 3) return launch_cfg<T, 128, 64, 4, 2, false, KS>(p, st);
+  if (force == 4) return launch_cfg<T, 64, 64, 2, 2, false, KS>(p, st);
   // Tile choice (measured, tools/bench_gemm.py): 8-wave blocks for the large tiles; fill >= ~2 blocks
   // per CU when the problem allows it, keep tiles large otherwise.
   const long big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);

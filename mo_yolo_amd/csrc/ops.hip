@@ -462,7 +462,12 @@ __device__ __forceinline__ void mma16<float>(f32x4& acc, u32x4 afrag, u32x4 bfra
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
 }
 
-template <typename T, int NKT>   // NKT (even): max 16-key tiles, compile-time bound of the score registers
+// Latency structure (the first version took 58 us per layer for ~3 us of MFMA work: a rolled staging loop with one
+// load -> wait -> LDS-write round trip per iteration, a wave-uniform branch with a full s_waitcnt around every key tile,
+// Q loaded inside the tile loop): every loop below has a compile-time trip count -- the LDS image always holds NKT*16
+// keys (zero rows past L, masked to -inf), so the key loops are branch-free and the compiler keeps the fragment reads in
+// flight under the MFMAs; all K/V staging loads and the wave's Q fragments are issued before anything is waited for.
+template <typename T, int NKT, bool MASKED>   // NKT (even): 16-key tiles held in LDS and in the score registers
 __global__ __launch_bounds__(256) void mha_kernel(const T* __restrict__ qkv, int64_t ld, int L, int nh, int E,
                                                   T* __restrict__ out, int64_t ldo, int tiles_per_block,
                                                   const int32_t* __restrict__ n_prefix, int split) {
@@ -470,88 +475,104 @@ __global__ __launch_bounds__(256) void mha_kernel(const T* __restrict__ qkv, int
   constexpr int NPD = 32 / (4 * KPB);             // 64-B panels per K row: bf16 1, f32 2
   constexpr int ESZ = 16 / KPB;
   constexpr bool BF = KPB == 8;
+  constexpr int Lp = NKT * 16;                    // keys in the LDS image
+  constexpr int vstride = Lp * ESZ + 16;          // bytes per V^T row (pad breaks the power-of-two stride)
+  constexpr int CPK = 4 * NPD;                    // 16-B chunks per key row
+  constexpr int NST = (Lp * CPK + 255) / 256;     // staging chunks per thread
+  constexpr int MAXQT = (NKT + 3) / 4;            // 16-query tiles per wave (tiles_per_block <= NKT)
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-  const int Lp = (L + 31) & ~31;                  // keys padded to a whole PV k-step
-  const int vstride = Lp * ESZ + 16;              // bytes per V^T row (pad breaks the power-of-two stride)
   unsigned char* Ks = dyn;                         // [NPD][Lp][64 B]
   unsigned char* Vt = dyn + NPD * Lp * 64;         // [32][vstride]
+  float* kbias = reinterpret_cast<float*>(Vt + 32 * vstride);   // [Lp]: 0 for a live key, -inf otherwise
   const int b = blockIdx.x / nh, h = blockIdx.x % nh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q4 = lane >> 4;
   const T* base = qkv + (long)b * L * ld;
-  // key mask of the temporal mode: key j takes part iff j < n_prefix[b] (live track slots) or j >= split (detect queries)
-  const int npre = n_prefix ? n_prefix[b] : L;
-  // ---- stage K (zero padded) and V^T
-  constexpr int CPK = 4 * NPD;                    // 16-B chunks per key row
-  for (int i = tid; i < Lp * CPK; i += 256) {
+  // key mask of the temporal mode: key j takes part iff j < n_prefix[b] (live track slots) or j >= split (detect queries).
+  // The mask enters as the MFMA's C operand (score = -inf + q.k for a dead key or a zero row past L): no VALU in the loops.
+  const int npre = MASKED ? n_prefix[b] : L;
+  for (int j = tid; j < Lp; j += 256) {
+    const bool lv = MASKED ? (j < L && (j < npre || j >= split)) : j < L;
+    kbias[j] = lv ? 0.0f : -INFINITY;
+  }
+  const int t_begin = blockIdx.y * tiles_per_block;
+  const int nqt = (L + 15) >> 4;
+  const int t_end = min(nqt, t_begin + tiles_per_block);
+
+  // ---- all global loads first: K / V chunks of this thread, Q fragments of this wave's tiles
+  u32x4 kreg[NST], vreg[NST];
+#pragma unroll
+  for (int k = 0; k < NST; ++k) {
+    const int i = tid + k * 256;
+    const int key = min(i / CPK, L - 1), ch = i % CPK;       // clamped: always a valid address; rows >= L are zeroed below
+    kreg[k] = *reinterpret_cast<const u32x4*>(base + (long)key * ld + E + h * 32 + ch * KPB);
+    vreg[k] = *reinterpret_cast<const u32x4*>(base + (long)key * ld + 2 * E + h * 32 + ch * KPB);
+  }
+  u32x4 qf[MAXQT][NPD];
+#pragma unroll
+  for (int t = 0; t < MAXQT; ++t) {
+    const int qld = min((t_begin + wave + 4 * t) * 16 + r, L - 1);
+#pragma unroll
+    for (int pd = 0; pd < NPD; ++pd) qf[t][pd] = *reinterpret_cast<const u32x4*>(base + (long)qld * ld + h * 32 + (pd * 4 + q4) * KPB);
+  }
+#pragma unroll
+  for (int k = 0; k < NST; ++k) {
+    const int i = tid + k * 256;
     const int key = i / CPK, ch = i % CPK;
-    u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-    if (key < L) {
-      kv = *reinterpret_cast<const u32x4*>(base + (long)key * ld + E + h * 32 + ch * KPB);
-      vv = *reinterpret_cast<const u32x4*>(base + (long)key * ld + 2 * E + h * 32 + ch * KPB);
-    }
-    const int pd = ch >> 2, c4 = ch & 3;
-    *reinterpret_cast<u32x4*>(Ks + (pd * Lp + key) * 64 + swz16(key, c4) * 16) = kv;
-    if constexpr (BF) {
+    if (i < Lp * CPK) {
+      u32x4 kv = kreg[k], vv = vreg[k];
+      if (key >= L) { kv = u32x4{0u, 0u, 0u, 0u}; vv = kv; }
+      const int pd = ch >> 2, c4 = ch & 3;
+      *reinterpret_cast<u32x4*>(Ks + (pd * Lp + key) * 64 + swz16(key, c4) * 16) = kv;
       const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+      if constexpr (BF) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const uint16_t hv = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
-        *reinterpret_cast<uint16_t*>(Vt + (ch * 8 + e) * vstride + key * 2) = hv;
+        for (int e = 0; e < 8; ++e) {
+          const uint16_t hv = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+          *reinterpret_cast<uint16_t*>(Vt + (ch * 8 + e) * vstride + key * 2) = hv;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<uint32_t*>(Vt + (ch * 4 + e) * vstride + key * 4) = w[e];
       }
-    } else {
-      const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) *reinterpret_cast<uint32_t*>(Vt + (ch * 4 + e) * vstride + key * 4) = w[e];
     }
   }
   __syncthreads();
-  const int nkt = (L + 15) >> 4;
-  const int nqt = (L + 15) >> 4;
   const float scaling = 0.17677669529663687f;     // 32^-0.5 (torch MHA scales q before QK^T)
-  const int t_begin = blockIdx.y * tiles_per_block;
-  const int t_end = min(nqt, t_begin + tiles_per_block);
-  for (int qt = t_begin + wave; qt < t_end; qt += 4) {
-    const int query = qt * 16 + r;
-    const int qld = min(query, L - 1);
-    u32x4 qf[NPD];
+  constexpr float L2E = 1.4426950408889634f;
+  const float cexp = scaling * L2E;               // softmax(x * scaling) = exp2((x - max) * cexp) / sum
 #pragma unroll
-    for (int pd = 0; pd < NPD; ++pd)
-      qf[pd] = *reinterpret_cast<const u32x4*>(base + (long)qld * ld + h * 32 + (pd * 4 + q4) * KPB);
+  for (int t = 0; t < MAXQT; ++t) {
+    const int qt = t_begin + wave + 4 * t;
+    if (qt >= t_end) break;                        // wave-uniform
+    const int query = qt * 16 + r;
     f32x4 s[NKT];
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      s[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      if (kt < nkt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const int krow = kt * 16 + r;
+      f32x4 acc = *reinterpret_cast<const f32x4*>(kbias + kt * 16 + q4 * 4);
+      const int krow = kt * 16 + r;
 #pragma unroll
-        for (int pd = 0; pd < NPD; ++pd) {
-          const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + (pd * Lp + krow) * 64 + swz16(krow, q4) * 16);
-          mma16<T>(acc, kf, qf[pd]);             // D[key = q4*4+reg][query = r]
-        }
-        const int k0 = kt * 16 + q4 * 4;
-        acc = acc * scaling;
-        auto live = [&](int j) { return j < L && (j < npre || j >= split); };
-        acc.x = live(k0 + 0) ? acc.x : -INFINITY; acc.y = live(k0 + 1) ? acc.y : -INFINITY;
-        acc.z = live(k0 + 2) ? acc.z : -INFINITY; acc.w = live(k0 + 3) ? acc.w : -INFINITY;
-        s[kt] = acc;
-        mx = fmaxf(mx, fmaxf(fmaxf(acc.x, acc.y), fmaxf(acc.z, acc.w)));
+      for (int pd = 0; pd < NPD; ++pd) {
+        const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + (pd * Lp + krow) * 64 + swz16(krow, q4) * 16);
+        mma16<T>(acc, kf, qf[t][pd]);              // D[key = q4*4+reg][query = r]
       }
+      s[kt] = acc;                                 // raw q.k (the 32^-0.5 scaling is folded into the exponent below)
+      mx = fmaxf(fmaxf(mx, acc.x), acc.y);         // v_max3_f32
+      mx = fmaxf(fmaxf(mx, acc.z), acc.w);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     if (mx == -INFINITY) mx = 0.f;                  // no live key (empty track memory): all weights 0, output 0
     float sum = 0.f;
-    constexpr float L2E = 1.4426950408889634f;
+    const float nmx = -mx * cexp;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       f32x4 e;
-      // v_exp_f32 (1 ulp): libm expf cost ~40 VALU ops per score and dominated the kernel
-      e.x = __builtin_amdgcn_exp2f((s[kt].x - mx) * L2E); e.y = __builtin_amdgcn_exp2f((s[kt].y - mx) * L2E);
-      e.z = __builtin_amdgcn_exp2f((s[kt].z - mx) * L2E); e.w = __builtin_amdgcn_exp2f((s[kt].w - mx) * L2E);
-      s[kt] = e;                                  // exp(-inf) = 0 for masked / unused tiles
+      // one fma + v_exp_f32 (1 ulp) per score: libm expf cost ~40 VALU ops per score and dominated the first version
+      e.x = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt].x, cexp, nmx)); e.y = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt].y, cexp, nmx));
+      e.z = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt].z, cexp, nmx)); e.w = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt].w, cexp, nmx));
+      s[kt] = e;                                  // exp(-inf) = 0 for masked keys and the zero rows past L
       sum += (e.x + e.y) + (e.z + e.w);
     }
     sum += __shfl_xor(sum, 16, 64);
@@ -559,28 +580,26 @@ __global__ __launch_bounds__(256) void mha_kernel(const T* __restrict__ qkv, int
     f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     if constexpr (BF) {
 #pragma unroll
-      for (int kb = 0; kb < (NKT + 1) / 2; ++kb)
-        if (kb * 2 < nkt) {
-          const f32x4 p0 = s[2 * kb], p1 = s[2 * kb + 1];
-          const u32x4 pf = {DT<T>::pack2(p0.x, p0.y), DT<T>::pack2(p0.z, p0.w), DT<T>::pack2(p1.x, p1.y), DT<T>::pack2(p1.z, p1.w)};
+      for (int kb = 0; kb < NKT / 2; ++kb) {
+        const f32x4 p0 = s[2 * kb], p1 = s[2 * kb + 1];
+        const u32x4 pf = {DT<T>::pack2(p0.x, p0.y), DT<T>::pack2(p0.z, p0.w), DT<T>::pack2(p1.x, p1.y), DT<T>::pack2(p1.z, p1.w)};
 #pragma unroll
-          for (int dh = 0; dh < 2; ++dh) {
-            const unsigned char* vr = Vt + (dh * 16 + r) * vstride + (kb * 32 + q4 * 4) * 2;
-            const u32x2 v0 = *reinterpret_cast<const u32x2*>(vr), v1 = *reinterpret_cast<const u32x2*>(vr + 32);
-            mma16<T>(o[dh], u32x4{v0.x, v0.y, v1.x, v1.y}, pf);   // D[d = q4*4+reg][query = r]
-          }
+        for (int dh = 0; dh < 2; ++dh) {
+          const unsigned char* vr = Vt + (dh * 16 + r) * vstride + (kb * 32 + q4 * 4) * 2;
+          const u32x2 v0 = *reinterpret_cast<const u32x2*>(vr), v1 = *reinterpret_cast<const u32x2*>(vr + 32);
+          mma16<T>(o[dh], u32x4{v0.x, v0.y, v1.x, v1.y}, pf);   // D[d = q4*4+reg][query = r]
         }
+      }
     } else {
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
-        if (kt < nkt) {
-          const u32x4 pf = __builtin_bit_cast(u32x4, s[kt]);
+      for (int kt = 0; kt < NKT; ++kt) {
+        const u32x4 pf = __builtin_bit_cast(u32x4, s[kt]);
 #pragma unroll
-          for (int dh = 0; dh < 2; ++dh) {
-            const u32x4 vf = *reinterpret_cast<const u32x4*>(Vt + (dh * 16 + r) * vstride + (kt * 16 + q4 * 4) * 4);
-            mma16<T>(o[dh], vf, pf);
-          }
+        for (int dh = 0; dh < 2; ++dh) {
+          const u32x4 vf = *reinterpret_cast<const u32x4*>(Vt + (dh * 16 + r) * vstride + (kt * 16 + q4 * 4) * 4);
+          mma16<T>(o[dh], vf, pf);
         }
+      }
     }
     if (query < L) {
       const float inv = sum > 0.f ? 1.0f / sum : 0.f;
@@ -1504,13 +1523,13 @@ extern "C" int moy_pos2posemb(const float* pos, int M, void* out, int64_t ldo, i
   })
 }
 
-template <typename T, int NKT>
+template <typename T, int NKT, bool MASKED>
 static int mha_launch(const void* qkv, int64_t ld_qkv, int B, int L, int nh, int E, void* out, int64_t ldo, const int32_t* n_prefix,
                       int split, hipStream_t st) {
   constexpr int NPD = 32 / (4 * DT<T>::KPB), ESZ = 16 / DT<T>::KPB;
-  const int Lp = (L + 31) & ~31;
-  const size_t lds = (size_t)NPD * Lp * 64 + 32 * ((size_t)Lp * ESZ + 16);
-  auto kern = mha_kernel<T, NKT>;
+  constexpr int Lp = NKT * 16;
+  const size_t lds = (size_t)NPD * Lp * 64 + 32 * ((size_t)Lp * ESZ + 16) + (size_t)Lp * 4;
+  auto kern = mha_kernel<T, NKT, MASKED>;
   static bool attr_set = false;   // opt in to > 64 KiB of LDS once per kernel symbol
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -1527,6 +1546,13 @@ static int mha_launch(const void* qkv, int64_t ld_qkv, int B, int L, int nh, int
   return launch_status();
 }
 
+template <typename T, int NKT>
+static int mha_launch_m(const void* qkv, int64_t ld_qkv, int B, int L, int nh, int E, void* out, int64_t ldo, const int32_t* n_prefix,
+                        int split, hipStream_t st) {
+  return n_prefix ? mha_launch<T, NKT, true>(qkv, ld_qkv, B, L, nh, E, out, ldo, n_prefix, split, st)
+                  : mha_launch<T, NKT, false>(qkv, ld_qkv, B, L, nh, E, out, ldo, n_prefix, split, st);
+}
+
 static int mha_host(const void* qkv, int64_t ld_qkv, int B, int L, int nh, int E, const int32_t* n_prefix, int split, void* out,
                     int64_t ldo, int dtype, void* stream) {
   if (!qkv || !out || B <= 0 || L <= 0 || nh <= 0 || E != nh * 32 || ld_qkv < 3 * E || (ld_qkv % 8) || (ldo % 4)) return MOY_EINVAL;
@@ -1535,9 +1561,9 @@ static int mha_host(const void* qkv, int64_t ld_qkv, int B, int L, int nh, int E
   if (L > 512) return MOY_ENOSYS;    // score registers: 32 key tiles per lane
   hipStream_t st = static_cast<hipStream_t>(stream);
   MOY_DISPATCH_T(dtype, {
-    if (L <= 128) return mha_launch<T, 8>(qkv, ld_qkv, B, L, nh, E, out, ldo, n_prefix, split, st);
-    if (L <= 320) return mha_launch<T, 20>(qkv, ld_qkv, B, L, nh, E, out, ldo, n_prefix, split, st);
-    return mha_launch<T, 32>(qkv, ld_qkv, B, L, nh, E, out, ldo, n_prefix, split, st);
+    if (L <= 128) return mha_launch_m<T, 8>(qkv, ld_qkv, B, L, nh, E, out, ldo, n_prefix, split, st);
+    if (L <= 320) return mha_launch_m<T, 20>(qkv, ld_qkv, B, L, nh, E, out, ldo, n_prefix, split, st);
+    return mha_launch_m<T, 32>(qkv, ld_qkv, B, L, nh, E, out, ldo, n_prefix, split, st);
   })
 }
 

@@ -29,6 +29,9 @@ SHAPES = [
     ("dec ffn1 256->1024", 1, 1, 1, 300, 256, 1024, False),
     ("dec ffn2+ln 1024->256", 1, 1, 1, 300, 1024, 256, True),
     ("dec qk 256->512", 1, 1, 1, 300, 256, 512, False),
+    ("dec lin 256->256", 1, 1, 1, 300, 256, 256, False),
+    ("dec lin+ln 256->256", 1, 1, 1, 300, 256, 256, True),
+    ("dec offaw 256->288", 1, 1, 1, 300, 256, 288, False),
 ]
 
 
