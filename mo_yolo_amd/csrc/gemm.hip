@@ -850,6 +850,10 @@ static int launch_conv_direct(GemmParams& p, int B, hipStream_t st) {
   return launch_status();
 }
 
+// Measured negative (round 1): a persistent tile loop that requests the next tile's halo patch into registers under the last four
+// taps.  The 44-84 extra live VGPRs (and the hoisted LDS addresses of the unrolled taps) cost the second resident block per CU:
+// C = 32 149 -> 200 us, C = 64 114 -> 150 us (TH 8: 131 us), C = 128 unchanged.  Occupancy hides the prologue better than the
+// prefetch does; a BN = 128 tile for C = 128 (patch staged once for all channels) measured equal.
 // Direct path for the shapes it wins on; MOY_ENOSYS = not eligible (the caller falls back to the implicit GEMM).
 template <typename T>
 static int try_conv_direct(GemmParams& p, int B, bool ln, hipStream_t st) {
