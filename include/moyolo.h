@@ -117,6 +117,9 @@ typedef struct moy_gemm_args {
   const float* pre;
   int64_t ld_pre;
   int32_t pre_h, pre_w;
+  /* with A2: only output columns n < a2_cols see A + A2, the others see A (0 = all columns; a multiple of 256).  One launch
+   * then makes q | k | v of nn.MultiheadAttention: q = k = x + pos, v = x (transformer.py:637-640). */
+  int32_t a2_cols;
 } moy_gemm_args;
 
 int moy_gemm(const moy_gemm_args* args, void* stream);

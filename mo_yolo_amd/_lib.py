@@ -27,7 +27,7 @@ class GemmArgs(C.Structure):
         ("C", vp), ("ldc", i64), ("out_f32", i32), ("dtype", i32),
         ("c_rows_per_batch", i32), ("c_batch_stride", i32),
         ("dot_w", vp), ("dot_b", vp), ("dot_out", vp), ("dot_n", i32),
-        ("pre", vp), ("ld_pre", i64), ("pre_h", i32), ("pre_w", i32),
+        ("pre", vp), ("ld_pre", i64), ("pre_h", i32), ("pre_w", i32), ("a2_cols", i32),
     ]
 
 

@@ -56,6 +56,7 @@ struct GemmParams {
   const float* pre;    // accumulator seed: nearest-2x upsampled rows of a half-resolution product (moy_gemm_args.pre)
   int64_t ld_pre;
   int pre_w, pre_hw, pre_loww, pre_lowhw;
+  int a2_cols;         // A2 applies to column tiles below this column (block-uniform)
   FastDiv fd_pre_hw, fd_pre_w;
 };
 
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
       const bool ktail = kt * BK + kc0 >= p.K; // only the zero-padded tail of K (Kpad > K)
 #pragma unroll
       for (int j = 0; j < RA2; ++j) areg[SET][j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ktail ? OOB : a_voff[j], soff, 0);
-      if (A2g) {                                // prologue add (q = k = x + pos): second stream, same offsets
+      if (A2g && n0 < p.a2_cols) {              // prologue add (q = k = x + pos): second stream, same offsets; block-uniform
         u32x4 t2[RA2];
 #pragma unroll
         for (int j = 0; j < RA2; ++j) t2[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA2, ktail ? OOB : a_voff[j], soff, 0);
@@ -925,6 +926,7 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
   if (a->ksize != 1 && a->ksize != 3) return MOY_EINVAL;
   if ((a->lda * esz) % 16 || !aligned16(a->A) || !aligned16(a->W)) return MOY_EINVAL;
   if (a->A2 && (!aligned16(a->A2) || a->ksize != 1)) return MOY_EINVAL;
+  if (a->a2_cols < 0 || (a->a2_cols % 256) || (a->a2_cols && !a->A2)) return MOY_EINVAL;
   const int out_esz = a->out_f32 ? 4 : esz;
   if ((a->ldc * out_esz) % (4 * out_esz) || (reinterpret_cast<uintptr_t>(a->C) % (4 * out_esz))) return MOY_EINVAL;
   if (a->R && ((a->ldr * esz) % (4 * esz) || reinterpret_cast<uintptr_t>(a->R) % (4 * esz))) return MOY_EINVAL;
@@ -969,6 +971,7 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
     p.pre_loww = a->pre_w / 2; p.pre_lowhw = (a->pre_h / 2) * (a->pre_w / 2);
     p.fd_pre_hw = make_fastdiv((uint32_t)p.pre_hw); p.fd_pre_w = make_fastdiv((uint32_t)p.pre_w);
   }
+  p.a2_cols = a->a2_cols ? a->a2_cols : 0x7fffffff;
   p.wide_store = a->dtype != MOY_F32 && !a->out_f32 && !ln && a->N % 8 == 0 && (a->ldc % 8) == 0 && aligned16(a->C) &&
                  (!a->R || ((a->ldr % 8) == 0 && aligned16(a->R)));
   if (a->ksize == 1) {

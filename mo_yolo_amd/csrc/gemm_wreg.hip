@@ -25,7 +25,7 @@
 
 namespace moy {
 
-struct WregParams {
+struct WregParams {   // ngroups = N / (columns per block)
   const void* A;
   int64_t lda;
   const void* W;
@@ -77,22 +77,24 @@ __device__ __forceinline__ f32x4 mfma16<f16_t>(f32x4 acc, u32x4 w, u32x4 a) {
 }
 
 constexpr int WREG_MAXDOT = 4;           // classes of the fused narrow head in score mode
-template <int BM, int NBUF, bool LN>
+template <int BM, int NBUF, bool LN, int NW = 4>
 constexpr int wreg_lds_bytes() {
   // A ring | (store mode) 4 epilogue strips | scale, shift | (score mode) g*w per class, G/B constants, row partials [BM][6][16]
-  return NBUF * BM * 512 + (LN ? 0 : 4 * BM * 136) + 2048 + (LN ? WREG_MAXDOT * 1024 + 64 + BM * ((2 + WREG_MAXDOT) * 64 + 16) : 0);
+  return NBUF * BM * 512 + (LN ? 0 : NW * BM * 136) + NW * 512 + (LN ? WREG_MAXDOT * 1024 + 64 + BM * ((2 + WREG_MAXDOT) * 64 + 16) : 0);
 }
 
-template <typename T, int BM, int NBUF, int OCC, bool LN>
-__global__ __launch_bounds__(256, OCC) void gemm_wreg_kernel(const WregParams p) {
+template <typename T, int BM, int NBUF, int OCC, bool LN, int NW>
+__global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParams p) {
+  static_assert((NW == 4 || NW == 8) && (!LN || NW == 4), "4 waves = 256 columns per block, or 8 waves = 512 (store mode)");
+  constexpr int BNB = NW * 64;             // output columns per block
   constexpr int MT = BM / 16;              // row sub-tiles per wave (every wave covers all BM rows)
   constexpr int NT = 4;                    // 64 columns per wave
   constexpr int TILE_BYTES = BM * 512;
-  constexpr int IPW = TILE_BYTES / 1024 / 4;   // DMA instructions per wave and tile
+  constexpr int IPW = TILE_BYTES / 1024 / NW;  // DMA instructions per wave and tile
   constexpr int DIST = NBUF - 1;           // tiles in flight ahead of the one being computed
   constexpr int EP_PITCH = 136;            // bytes per row of the wave's epilogue strip (64 x 2 B + 8)
   constexpr int NST = LN ? 0 : BM / 8;     // 16-byte store instructions per wave and tile (score mode: see below)
-  constexpr int EP_BYTES = LN ? 0 : 4 * BM * EP_PITCH;
+  constexpr int EP_BYTES = LN ? 0 : NW * BM * EP_PITCH;
   static_assert(BM % 16 == 0 && IPW >= 1, "tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -110,14 +112,14 @@ __global__ __launch_bounds__(256, OCC) void gemm_wreg_kernel(const WregParams p)
 
   unsigned char* ep = smem + NBUF * TILE_BYTES + wave * (BM * EP_PITCH);
   float* ssc = reinterpret_cast<float*>(smem + NBUF * TILE_BYTES + EP_BYTES);
-  float* ssh = ssc + 256;
-  float* gw = ssh + 256;                   // score mode: ln_g[n] * dot_w[c][n]
+  float* ssh = ssc + BNB;
+  float* gw = ssh + BNB;                   // score mode: ln_g[n] * dot_w[c][n]
   float* GB = gw + WREG_MAXDOT * 256;      // [0..3] sum_n gw[c][n]; [4..7] sum_n ln_b[n] * dot_w[c][n] + dot_b[c]
   constexpr int PROW = (2 + WREG_MAXDOT) * 16 + 4;   // floats per row of P: [quantity][wave * 4 + lane group]; +4: rows 4 banks apart
   float* P = GB + 16;                      // row partials, reduced by wave 0 after one barrier
   uint32_t* mbits = reinterpret_cast<uint32_t*>(P + BM * PROW);   // valid-token bitmask (mask_period bits), dynamic tail of the LDS
   const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);
-  const int nb = grp * 256;                // first output column of the block
+  const int nb = grp * BNB;                // first output column of the block
   {
     ssc[tid] = p.scale ? p.scale[nb + tid] : 1.0f;
     ssh[tid] = p.shift ? p.shift[nb + tid] : 0.0f;
@@ -368,10 +370,10 @@ static int wreg_num_cus() {
   return n;
 }
 
-template <typename T, int BM, int NBUF, int OCC, bool LN = false>
+template <typename T, int BM, int NBUF, int OCC, bool LN = false, int NW = 4>
 static int launch_wreg(WregParams& p, hipStream_t st) {
-  const int lds = wreg_lds_bytes<BM, NBUF, LN>() + (LN && p.a_mask ? ((p.mask_period + 31) / 32) * 4 : 0);
-  auto kern = gemm_wreg_kernel<T, BM, NBUF, OCC, LN>;
+  const int lds = wreg_lds_bytes<BM, NBUF, LN, NW>() + (LN && p.a_mask ? ((p.mask_period + 31) / 32) * 4 : 0);
+  auto kern = gemm_wreg_kernel<T, BM, NBUF, OCC, LN, NW>;
   static int attr_lds = 0;
   if (lds > 65536 && lds > attr_lds) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -380,9 +382,10 @@ static int launch_wreg(WregParams& p, hipStream_t st) {
   }
   const int slots = wreg_num_cus() / 8 * OCC;          // resident blocks per XCD
   p.ntiles = (p.M + BM - 1) / BM;
+  p.ngroups = p.N / (NW * 64);
   p.lanes = slots / p.ngroups;
   if (p.lanes < 1) return MOY_ENOSYS;
-  hipLaunchKernelGGL(kern, dim3(8 * p.lanes * p.ngroups), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(8 * p.lanes * p.ngroups), dim3(64 * NW), lds, st, p);
   return launch_status();
 }
 
@@ -416,14 +419,17 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   }
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("MOY_WREG_VARIANT"); variant = e ? atoi(e) : 0; }
-  // measured on the value projection (M = 1.3 M, N = 1536, bf16): BM 32 / 3 buffers / 2 blocks per CU 1168 us,
-  // BM 64 / 3 buffers / 1 block per CU 1254 us, BM 64 / 2 buffers 1274 us (tiled kernel: 1951 us)
+  // measured on the value projection (M = 1.3 M, N = 1536, bf16; tiled kernel 1951 us): 4 waves x 256 columns, BM 32 / 3 buffers /
+  // 2 blocks per CU 1168 us; BM 64 / 3 buffers / 1 block per CU 1254 us; BM 64 / 2 buffers 1274 us; BM 32 / 4 buffers 1458 us (one
+  // block per CU fits); 8 waves x 512 columns, BM 32 / 3 buffers, one block per CU: 6 % faster than the first (same device) -- half as
+  // many blocks re-fetch an activation tile that has left the L2
   if (a->dtype == MOY_BF16) {
     if (variant == 1) return launch_wreg<bf16_t, 64, 3, 1>(p, st);
-    if (variant == 2) return launch_wreg<bf16_t, 32, 4, 2>(p, st);
-    return launch_wreg<bf16_t, 32, 3, 2>(p, st);
+    if (variant == 2 || a->N % 512) return launch_wreg<bf16_t, 32, 3, 2>(p, st);
+    return launch_wreg<bf16_t, 32, 3, 1, false, 8>(p, st);
   }
-  return launch_wreg<f16_t, 32, 3, 2>(p, st);
+  if (a->N % 512) return launch_wreg<f16_t, 32, 3, 2>(p, st);
+  return launch_wreg<f16_t, 32, 3, 1, false, 8>(p, st);
 }
 
 }  // namespace moy

@@ -129,7 +129,7 @@ class TrackEngine:
 
     def _gemm(self, A: View, Wt, N, K, C_: View, M, *, ksize=1, stride=1, geom=None, scale=None, shift=None, act=0,
               A2: View | None = None, a_rows=None, a_mask=None, mask_period=0, R: View | None = None, ln=None,
-              out_f32=False, c_rpb=0, c_bstride=0, dot=None, pre=None):
+              out_f32=False, c_rpb=0, c_bstride=0, dot=None, pre=None, a2_cols=0):
         a = L.GemmArgs()
         a.A, a.lda = A.ptr, A.ld
         a.A2 = A2.ptr if A2 is not None else None
@@ -156,6 +156,7 @@ class TrackEngine:
         a.c_rows_per_batch, a.c_batch_stride = c_rpb, c_bstride
         if dot is not None:
             a.dot_w, a.dot_b, a.dot_out, a.dot_n = dot[0].data_ptr(), dot[1].data_ptr(), dot[2].data_ptr(), dot[0].shape[0]
+        a.a2_cols = a2_cols
         if pre is not None:
             pt, ph, pw = pre
             a.pre, a.ld_pre, a.pre_h, a.pre_w = pt.data_ptr(), pt.stride(0), ph, pw
@@ -464,11 +465,10 @@ class TrackEngine:
         ecur, enxt = 0, 1
         for i in range(ndl):
             q = f"{d}.decoder.layers.{i}"
-            Wqk, bqk = self._linear_w_raw(sd[q + ".self_attn.in_proj_weight"][:2 * hd], sd[q + ".self_attn.in_proj_bias"][:2 * hd])
-            Wvv, bvv = self._linear_w_raw(sd[q + ".self_attn.in_proj_weight"][2 * hd:], sd[q + ".self_attn.in_proj_bias"][2 * hd:])
+            # q | k | v in one launch: q = k = x + pos for the first 2*hd columns, v = x for the rest (transformer.py:637-640)
+            Wqkv, bqkv = self._linear_w_raw(sd[q + ".self_attn.in_proj_weight"], sd[q + ".self_attn.in_proj_bias"])
             x = embed[ecur]
-            self._gemm(x, Wqk, 2 * hd, hd, qkv.slice(0, 2 * hd), M, shift=bqk, A2=qpos)
-            self._gemm(x, Wvv, hd, hd, qkv.slice(2 * hd, hd), M, shift=bvv)
+            self._gemm(x, Wqkv, 3 * hd, hd, qkv, M, shift=bqkv, A2=qpos, a2_cols=2 * hd)
             if n_max:   # keys: live track slots + this frame's detect queries
                 self._add(lib.moy_mha_core_masked, qkv.ptr, qkv.ld, B, Lq, arch.nh, hd, self.trk["n"].data_ptr(), n_max, attn.ptr,
                           attn.ld, code)

@@ -145,6 +145,11 @@ def test_gemm_layernorm_residual_prologue_add_gather_mask(dt):
     xin = q(x + p, dt) if dt == torch.bfloat16 else x + p
     ref = F.layer_norm(xin @ w.T + b + r, (N,), g, be, 1e-5)
     assert torch.allclose(y.float().cpu(), ref, atol=tol(dt, 3e-5, 4e-2))
+    # prologue add on the first 512 of 768 columns only (q | k | v of the decoder's self-attention in one launch)
+    w3 = q(rnd(768, K, seed=13, scale=1 / math.sqrt(K)), dt)
+    y3 = ops.gemm(x.to(DEV, dt), ops.pad_weight(w3.to(DEV), dt), 768, K, A2=p.to(DEV, dt), a2_cols=512)
+    ref3 = torch.cat([xin @ w3[:512].T, x @ w3[512:].T], 1)
+    assert torch.allclose(y3.float().cpu(), ref3, atol=tol(dt, 3e-5, 4e-2))
     # narrow head fused behind the LayerNorm (enc_score_head on enc_output)
     dw, db = rnd(3, N, seed=11, scale=0.1), rnd(3, seed=12)
     y2, sc = ops.gemm(x.to(DEV, dt), wd, N, K, shift=b.to(DEV), A2=p.to(DEV, dt), R=r.to(DEV, dt), ln=(g.to(DEV), be.to(DEV)),
