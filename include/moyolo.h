@@ -120,6 +120,12 @@ typedef struct moy_gemm_args {
   /* with A2: only output columns n < a2_cols see A + A2, the others see A (0 = all columns; a multiple of 256).  One launch
    * then makes q | k | v of nn.MultiheadAttention: q = k = x + pos, v = x (transformer.py:637-640). */
   int32_t a2_cols;
+  /* optional column planes (0 = off; ksize 1, plane_cols a multiple of 256): output column n is stored at
+   *   C[(n / plane_cols) * plane_stride + m * ldc + n % plane_cols]
+   * -- one launch over concatenated weights writes each 256-column group as its own contiguous [M, 256] matrix (the six
+   * value_proj outputs of the decoder layers: a layer's slice is then dense in HBM for the deformable gather). */
+  int32_t plane_cols;
+  int64_t plane_stride;
 } moy_gemm_args;
 
 int moy_gemm(const moy_gemm_args* args, void* stream);

@@ -28,6 +28,7 @@ class GemmArgs(C.Structure):
         ("c_rows_per_batch", i32), ("c_batch_stride", i32),
         ("dot_w", vp), ("dot_b", vp), ("dot_out", vp), ("dot_n", i32),
         ("pre", vp), ("ld_pre", i64), ("pre_h", i32), ("pre_w", i32), ("a2_cols", i32),
+        ("plane_cols", i32), ("plane_stride", i64),
     ]
 
 

@@ -57,6 +57,8 @@ struct GemmParams {
   int64_t ld_pre;
   int pre_w, pre_hw, pre_loww, pre_lowhw;
   int a2_cols;         // A2 applies to column tiles below this column (block-uniform)
+  int plane_cols;      // 0, or: column n lives in plane n / plane_cols at C + plane * plane_stride (column n % plane_cols)
+  int64_t plane_stride;
   FastDiv fd_pre_hw, fd_pre_w;
 };
 
@@ -178,6 +180,13 @@ __device__ __forceinline__ void stage_acc(const GemmParams& p, f32x4 (&acc)[MT][
   }
 }
 
+// element offset of output column n inside C (column planes: moy_gemm_args.plane_cols)
+__device__ __forceinline__ int64_t col_off(const GemmParams& p, int n) {
+  if (!p.plane_cols) return n;
+  const int pl = n / p.plane_cols;
+  return (int64_t)pl * p.plane_stride + (n - pl * p.plane_cols);
+}
+
 // ---- epilogue, part 2 (after the barrier): row-wise pass over the LDS tile: residual add,
 // optional LayerNorm (wave shuffles), coalesced vector stores.  The pass is FULLY UNROLLED with all
 // residual loads issued up front: CDNA4's vmcnt counts stores too, so a wait placed inside a rolled
@@ -214,7 +223,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const float* 
     for (int c = 0; c < 8; ++c) dw[c] = c < p.dot_n ? *reinterpret_cast<const f32x4*>(p.dot_w + c * 256 + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int out_esz = p.out_f32 ? 4 : (int)sizeof(T);
-  unsigned char* cbase = static_cast<unsigned char*>(p.C) + (int64_t)n * out_esz;
+  unsigned char* cbase = static_cast<unsigned char*>(p.C) + col_off(p, n) * out_esz;
 #pragma unroll
   for (int k = 0; k < NPASS; ++k) {
     const int rr = rr0 + k * RSTEP, m = m0 + rr;
@@ -267,7 +276,7 @@ __device__ __forceinline__ void gemm_epilogue_bf16x8(const GemmParams& p, const 
       res[k] = *reinterpret_cast<const u32x4*>(rp + (int64_t)m * p.ldr);
     }
   }
-  T* cbase = static_cast<T*>(p.C) + n;
+  T* cbase = static_cast<T*>(p.C) + col_off(p, n);
 #pragma unroll
   for (int k = 0; k < NPASS; ++k) {
     const int rr = rr0 + k * RSTEP, m = m0 + rr;
@@ -296,7 +305,7 @@ __device__ __forceinline__ void gemm_epilogue_half(const GemmParams& p, const fl
   const int n = n0 + cc * 8;
   const bool col_ok = n < p.N;                       // N % 8 == 0 on this path (host-checked)
   const unsigned char* ch = reinterpret_cast<const unsigned char*>(Cs);
-  T* cbase = static_cast<T*>(p.C) + n;
+  T* cbase = static_cast<T*>(p.C) + col_off(p, n);
 #pragma unroll
   for (int k = 0; k < NPASS; ++k) {
     const int rr = rr0 + k * RSTEP, m = m0 + rr;
@@ -972,6 +981,8 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
     p.fd_pre_hw = make_fastdiv((uint32_t)p.pre_hw); p.fd_pre_w = make_fastdiv((uint32_t)p.pre_w);
   }
   p.a2_cols = a->a2_cols ? a->a2_cols : 0x7fffffff;
+  if (a->plane_cols < 0 || (a->plane_cols % 256) || (a->plane_cols && (a->ksize != 1 || a->plane_stride <= 0))) return MOY_EINVAL;
+  p.plane_cols = a->plane_cols; p.plane_stride = a->plane_stride;
   p.wide_store = a->dtype != MOY_F32 && !a->out_f32 && !ln && a->N % 8 == 0 && (a->ldc % 8) == 0 && aligned16(a->C) &&
                  (!a->R || ((a->ldr % 8) == 0 && aligned16(a->R)));
   if (a->ksize == 1) {

@@ -35,6 +35,8 @@ struct WregParams {   // ngroups = N / (columns per block)
   void* C;
   int64_t ldc;
   int M, N;
+  int plane_cols;       // column planes (moy_gemm_args.plane_cols), 0 = off
+  int64_t plane_stride;
   int ngroups;   // N / 256
   int lanes;     // row-tile sequences per XCD
   int ntiles;    // ceil(M / BM)
@@ -335,7 +337,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
       // rows past M fall outside the descriptor and are dropped by the range check: the NST stores are unconditional
       // (all strip reads first, then the stores back to back; the vmcnt bookkeeping below counts exactly NST)
       const int cc = lane & 7, rr0 = lane >> 3;
-      T* cb = static_cast<T*>(p.C) + (int64_t)m0 * p.ldc + nb + wave * 64;
+      const int ncol = nb + wave * 64;         // a wave's 64 columns never straddle a plane (plane_cols % 256 == 0)
+      const int pl = p.plane_cols ? ncol / p.plane_cols : 0;
+      T* cb = static_cast<T*>(p.C) + (int64_t)pl * p.plane_stride + (int64_t)m0 * p.ldc + (ncol - pl * p.plane_cols);
       const int64_t left = ((int64_t)(p.M - 1 - m0) * p.ldc + 64) * 2;
       const auto rsC = __builtin_amdgcn_make_buffer_rsrc(cb, 0, (uint32_t)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
       u32x2 lo[NST], hi[NST];
@@ -412,6 +416,7 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   WregParams p{};
   p.A = a->A; p.lda = a->lda; p.W = a->W; p.scale = a->scale; p.shift = a->shift; p.act = a->act;
   p.C = a->C; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.ngroups = a->N / 256;
+  p.plane_cols = a->plane_cols; p.plane_stride = a->plane_stride;
   if (score) {
     p.ln_g = a->ln_g; p.ln_b = a->ln_b; p.dot_w = a->dot_w; p.dot_b = a->dot_b; p.dot_out = a->dot_out; p.dot_n = a->dot_n;
     p.a_mask = a->a_mask; p.mask_period = a->mask_period; p.fd_mask = make_fastdiv(a->mask_period > 0 ? a->mask_period : 1);

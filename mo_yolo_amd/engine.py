@@ -129,7 +129,7 @@ class TrackEngine:
 
     def _gemm(self, A: View, Wt, N, K, C_: View, M, *, ksize=1, stride=1, geom=None, scale=None, shift=None, act=0,
               A2: View | None = None, a_rows=None, a_mask=None, mask_period=0, R: View | None = None, ln=None,
-              out_f32=False, c_rpb=0, c_bstride=0, dot=None, pre=None, a2_cols=0):
+              out_f32=False, c_rpb=0, c_bstride=0, dot=None, pre=None, a2_cols=0, planes=None):
         a = L.GemmArgs()
         a.A, a.lda = A.ptr, A.ld
         a.A2 = A2.ptr if A2 is not None else None
@@ -157,6 +157,8 @@ class TrackEngine:
         if dot is not None:
             a.dot_w, a.dot_b, a.dot_out, a.dot_n = dot[0].data_ptr(), dot[1].data_ptr(), dot[2].data_ptr(), dot[0].shape[0]
         a.a2_cols = a2_cols
+        if planes is not None:
+            a.plane_cols, a.plane_stride = planes
         if pre is not None:
             pt, ph, pw = pre
             a.pre, a.ld_pre, a.pre_h, a.pre_w = pt.data_ptr(), pt.stride(0), ph, pw
@@ -447,8 +449,15 @@ class TrackEngine:
         ndl = arch.ndl
         Wv = torch.cat([sd[f"{d}.decoder.layers.{i}.cross_attn.value_proj.weight"] for i in range(ndl)], 0)
         bv = torch.cat([sd[f"{d}.decoder.layers.{i}.cross_attn.value_proj.bias"] for i in range(ndl)], 0)
-        value = View(self._buf(B * S, ndl * hd))
-        self._gemm(feats, self._weight(Wv), ndl * hd, hd, value, B * S, shift=self._dev(bv))
+        # ... written as ndl contiguous [B*S, hd] planes: a layer's slice is dense in HBM for its deformable gather
+        if os.environ.get("MOY_VALUE_PLANES", "1") != "0":
+            self.value_planes = self._buf(ndl * B * S, hd)
+            value = [View(self.value_planes[i * B * S:(i + 1) * B * S]) for i in range(ndl)]
+            self._gemm(feats, self._weight(Wv), ndl * hd, hd, value[0], B * S, shift=self._dev(bv), planes=(hd, B * S * hd))
+        else:       # A/B: one [B*S, ndl*hd] matrix, a layer = a 512-byte column slice of 3072-byte rows
+            vall = View(self._buf(B * S, ndl * hd))
+            self._gemm(feats, self._weight(Wv), ndl * hd, hd, vall, B * S, shift=self._dev(bv))
+            value = [vall.slice(i * hd, hd) for i in range(ndl)]
         self.value = value
 
         M = Md                           # from here on: decoder rows
@@ -480,7 +489,7 @@ class TrackEngine:
             boa = torch.cat([sd[q + ".cross_attn.sampling_offsets.bias"], sd[q + ".cross_attn.attention_weights.bias"]], 0)
             Woa_d, boa_d = self._linear_w_raw(Woa, boa)
             self._gemm(e1, Woa_d, Woa.shape[0], hd, View(offaw), M, shift=boa_d, A2=qpos, out_f32=True)
-            vslice = value.slice(i * hd, hd)
+            vslice = value[i]
             self._add(lib.moy_msda_fused, vslice.ptr, vslice.ld, B, S, shapes_c, nl, offaw.data_ptr(), offaw.shape[1],
                       refs[cur].data_ptr(), Lq, samp.ptr, samp.ld, code)
             Wp, bp = self._linear_w(q + ".cross_attn.output_proj")

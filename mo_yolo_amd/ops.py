@@ -47,7 +47,7 @@ def pad_weight(w2d: torch.Tensor, dtype) -> torch.Tensor:
 
 def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shift=None, act=L.ACT_NONE, A2=None,
          a_rows=None, a_mask=None, mask_period=0, R=None, ln=None, out_f32=False, M=None, c_rpb=0, c_bstride=0,
-         dot=None, store=True, pre=None, a2_cols=0):
+         dot=None, store=True, pre=None, a2_cols=0, planes=None):
     """See moy_gemm.  store=False (with dot): C = NULL, only the fused head's output is produced (returned as (None, dot_out)).
     A: 2-D row-major view [rows, >=Cin] (channels-last pixels or tokens)."""
     _need_gpu(A, Wp)
@@ -92,6 +92,8 @@ def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shi
         assert pt.dtype == torch.float32
         a.pre, a.ld_pre, a.pre_h, a.pre_w = pt.data_ptr(), _ld(pt), ph, pw
     a.a2_cols = a2_cols
+    if planes is not None:   # (plane_cols, plane_stride in elements): `out` is the first plane [M, plane_cols]
+        a.plane_cols, a.plane_stride = planes
     dot_out = None
     if dot is not None:     # (w fp32 [n, 256], b fp32 [n]) fused behind the LayerNorm
         dw, db = dot

@@ -78,6 +78,14 @@ def test_gemm_weight_stationary_kernel_bit_identical_to_tiled(dt, M, N, act):
     two = torch.empty(M, N, device=DEV, dtype=dt)
     ops.gemm(xd[:h], wd, N, K, out=two[:h], **kw)
     ops.gemm(xd[h:], wd, N, K, out=two[h:], **kw)
+    if N % 512 == 0:   # column planes: every 256-column group as its own contiguous [M, 256] matrix, both kernels
+        pl = torch.full((N // 256, M + 1, 256), 7.0, device=DEV, dtype=dt)
+        ops.gemm(xd, wd, N, K, out=pl[0, :M], planes=(256, (M + 1) * 256), **kw)
+        sm = torch.empty(N // 256, 1000, 256, device=DEV, dtype=dt)
+        ops.gemm(xd[:1000], wd, N, K, out=sm[0], planes=(256, 1000 * 256), **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(pl[:, :M].permute(1, 0, 2).reshape(M, N), out[:M, :N]) and bool((pl[:, M] == 7.0).all())
+        assert torch.equal(sm.permute(1, 0, 2).reshape(1000, N), out[:1000, :N])
     torch.cuda.synchronize()
     assert torch.equal(out[:M, :N], two), "weight-stationary kernel differs from the tiled kernel"
     assert bool((out[M] == 7.0).all()) and bool((out[:, N:] == 7.0).all()), "wrote outside its rows / columns"
