@@ -198,12 +198,14 @@ int moy_mha_core_masked(const void* qkv, int64_t ld_qkv, int B, int L, int nh, i
  * after the three projections): softmax over the L*P attention logits, sampling locations
  * loc = ref_xy + off / P * ref_wh * 0.5, bilinear gather (zeros padding, align_corners=False),
  * weighted sum.  M = 8 heads x D = 32, L <= 4 levels, P = 4 points.
- *   value T [B, S, ldv] (head-major channels m*32+d), offaw fp32 [B*Lq, ld_oa]: columns
+ *   value T: channel d of head m of token (b, s) at value[(b*S + s)*ldv + m*head_stride + d] -- [B, S, 256] with
+ *   head_stride 32 (ldv >= 256), or head planes [8][B*S][32] with ldv 32 and head_stride B*S*32;
+ *   offaw fp32 [B*Lq, ld_oa]: columns
  *   [0, M*L*P*2) = offsets ([m][l][p][xy]) then [.., + M*L*P) = attention logits ([m][l*p]);
  *   ref fp32 [B*Lq, 4] (cx, cy, w, h in [0,1]); shapes int32 [L][2] = (H, W) on the HOST.
  *   out T [B*Lq, ldo]. */
-int moy_msda_fused(const void* value, int64_t ldv, int B, int S, const int32_t* shapes_hw, int L, const float* offaw,
-                   int64_t ld_oa, const float* ref, int Lq, void* out, int64_t ldo, int dtype, void* stream);
+int moy_msda_fused(const void* value, int64_t ldv, int64_t head_stride, int B, int S, const int32_t* shapes_hw, int L,
+                   const float* offaw, int64_t ld_oa, const float* ref, int Lq, void* out, int64_t ldo, int dtype, void* stream);
 
 /* ---- Temporal mode: carried track queries in a fixed-size query memory per sequence.
  * The shipped snapshot resets its state every frame and its carried branch crashes, so these entry points

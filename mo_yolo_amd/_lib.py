@@ -51,7 +51,7 @@ SIGNATURES = {
     "moy_temporal_assign": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, f32, f32, C.c_int, f32, f32, f32,
                                       vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "moy_temporal_commit": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
-    "moy_msda_fused": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, C.c_int, vp, i64, vp, C.c_int, vp, i64, C.c_int, vp]),
+    "moy_msda_fused": (C.c_int, [vp, i64, i64, C.c_int, C.c_int, vp, C.c_int, vp, i64, vp, C.c_int, vp, i64, C.c_int, vp]),
     "moy_msda_fwd_f32": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp, vp]),
     "moy_msda_fwd_bf16": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp, vp]),
     "moy_msda_fwd_f64": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp, vp]),

@@ -981,7 +981,7 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
     p.fd_pre_hw = make_fastdiv((uint32_t)p.pre_hw); p.fd_pre_w = make_fastdiv((uint32_t)p.pre_w);
   }
   p.a2_cols = a->a2_cols ? a->a2_cols : 0x7fffffff;
-  if (a->plane_cols < 0 || (a->plane_cols % 256) || (a->plane_cols && (a->ksize != 1 || a->plane_stride <= 0))) return MOY_EINVAL;
+  if (a->plane_cols < 0 || (a->plane_cols % 32) || (a->plane_cols && (a->ksize != 1 || a->plane_stride <= 0))) return MOY_EINVAL;
   p.plane_cols = a->plane_cols; p.plane_stride = a->plane_stride;
   p.wide_store = a->dtype != MOY_F32 && !a->out_f32 && !ln && a->N % 8 == 0 && (a->ldc % 8) == 0 && aligned16(a->C) &&
                  (!a->R || ((a->ldr % 8) == 0 && aligned16(a->R)));

@@ -337,11 +337,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
       // rows past M fall outside the descriptor and are dropped by the range check: the NST stores are unconditional
       // (all strip reads first, then the stores back to back; the vmcnt bookkeeping below counts exactly NST)
       const int cc = lane & 7, rr0 = lane >> 3;
-      const int ncol = nb + wave * 64;         // a wave's 64 columns never straddle a plane (plane_cols % 256 == 0)
-      const int pl = p.plane_cols ? ncol / p.plane_cols : 0;
-      T* cb = static_cast<T*>(p.C) + (int64_t)pl * p.plane_stride + (int64_t)m0 * p.ldc + (ncol - pl * p.plane_cols);
-      const int64_t left = ((int64_t)(p.M - 1 - m0) * p.ldc + 64) * 2;
-      const auto rsC = __builtin_amdgcn_make_buffer_rsrc(cb, 0, (uint32_t)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
+      const int ncol = nb + wave * 64;         // a wave's 64 columns: inside one plane (plane_cols % 64 == 0) or two planes of 32
       u32x2 lo[NST], hi[NST];
 #pragma unroll
       for (int k = 0; k < NST; ++k) {
@@ -349,10 +345,28 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
         lo[k] = *reinterpret_cast<const u32x2*>(ep + rr * EP_PITCH + cc * 16);
         hi[k] = *reinterpret_cast<const u32x2*>(ep + rr * EP_PITCH + cc * 16 + 8);
       }
-      const uint32_t voff0 = (uint32_t)(rr0 * (int)p.ldc + cc * 8) * 2, vstep = (uint32_t)p.ldc * 16;
+      if (p.plane_cols == 32) {
+        // head planes [plane][row][32]: lanes 0-3 / 4-7 of a row group write the row's 64 B of plane 2w / 2w+1, so a store
+        // instruction lays down 512 contiguous bytes per plane; rows past M get an out-of-range offset (dropped)
+        T* cb = static_cast<T*>(p.C) + (int64_t)(ncol >> 5) * p.plane_stride + (int64_t)m0 * 32;
+        const auto rsC = __builtin_amdgcn_make_buffer_rsrc(cb, 0, 0x7fffffffu, 0x00020000);
+        const uint32_t pofs = (uint32_t)((cc >> 2) * p.plane_stride * 2 + (cc & 3) * 16);
 #pragma unroll
-      for (int k = 0; k < NST; ++k)
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[k].x, lo[k].y, hi[k].x, hi[k].y}, rsC, voff0 + k * vstep, 0, 0);
+        for (int k = 0; k < NST; ++k) {
+          const int rr = rr0 + k * 8;
+          const uint32_t vo = m0 + rr < p.M ? pofs + (uint32_t)rr * 64u : 0x80000000u;
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[k].x, lo[k].y, hi[k].x, hi[k].y}, rsC, vo, 0, 0);
+        }
+      } else {
+        const int pl = p.plane_cols ? ncol / p.plane_cols : 0;
+        T* cb = static_cast<T*>(p.C) + (int64_t)pl * p.plane_stride + (int64_t)m0 * p.ldc + (ncol - pl * p.plane_cols);
+        const int64_t left = ((int64_t)(p.M - 1 - m0) * p.ldc + 64) * 2;
+        const auto rsC = __builtin_amdgcn_make_buffer_rsrc(cb, 0, (uint32_t)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
+        const uint32_t voff0 = (uint32_t)(rr0 * (int)p.ldc + cc * 8) * 2, vstep = (uint32_t)p.ldc * 16;
+#pragma unroll
+        for (int k = 0; k < NST; ++k)
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[k].x, lo[k].y, hi[k].x, hi[k].y}, rsC, voff0 + k * vstep, 0, 0);
+      }
     }
     }
     // tile it+1 must have landed; the younger DMA tiles and the stores issued since stay in flight
@@ -413,6 +427,8 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   if (a->M < 65536) return MOY_ENOSYS;     // persistent row-tile walk: needs many tiles per block
   if ((a->lda % 8) || !aligned16(a->A) || !aligned16(a->W)) return MOY_ENOSYS;
   if (!score && ((a->ldc % 8) || !aligned16(a->C))) return MOY_ENOSYS;
+  if (a->plane_cols && a->plane_cols != 32 && (a->plane_cols % 64)) return MOY_ENOSYS;
+  if (a->plane_cols == 32 && (a->ldc != 32 || a->plane_stride * 2 > 0x3fffffffLL)) return MOY_ENOSYS;
   WregParams p{};
   p.A = a->A; p.lda = a->lda; p.W = a->W; p.scale = a->scale; p.shift = a->shift; p.act = a->act;
   p.C = a->C; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.ngroups = a->N / 256;

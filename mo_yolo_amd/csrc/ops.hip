@@ -620,7 +620,7 @@ struct LevelInfo {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void msda_fused_kernel(const T* __restrict__ value, int64_t ldv, int S, LevelInfo lv, int L,
+__global__ __launch_bounds__(256) void msda_fused_kernel(const T* __restrict__ value, int64_t ldv, int64_t head_stride, int S, LevelInfo lv, int L,
                                                          const float* __restrict__ offaw, int64_t ld_oa,
                                                          const float* __restrict__ ref, int Lq, int nrows,
                                                          T* __restrict__ out, int64_t ldo) {
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const T* __restrict__ v
     if (i < LP) { logit[i] = expf(logit[i] - mx); den += logit[i]; }
   const float inv_den = 1.0f / den;
   const f32x4 rb = *reinterpret_cast<const f32x4*>(ref + (long)row * 4);
-  const T* vb = value + (long)b * S * ldv + m * 32 + sub * 4;
+  const T* vb = value + (long)b * S * ldv + m * head_stride + sub * 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int l = 0; l < 4; ++l)
@@ -1578,10 +1578,10 @@ extern "C" int moy_mha_core(const void* qkv, int64_t ld_qkv, int B, int L, int n
   return mha_host(qkv, ld_qkv, B, L, nh, E, nullptr, L, out, ldo, dtype, stream);
 }
 
-extern "C" int moy_msda_fused(const void* value, int64_t ldv, int B, int S, const int32_t* shapes_hw, int L, const float* offaw,
+extern "C" int moy_msda_fused(const void* value, int64_t ldv, int64_t head_stride, int B, int S, const int32_t* shapes_hw, int L, const float* offaw,
                               int64_t ld_oa, const float* ref, int Lq, void* out, int64_t ldo, int dtype, void* stream) {
   if (!value || !shapes_hw || !offaw || !ref || !out || B <= 0 || S <= 0 || L <= 0 || L > 4 || Lq <= 0) return MOY_EINVAL;
-  if (ldv < 256 || (ldv % 4) || ld_oa < 8 * L * 4 * 3 || (ld_oa % 4) || ldo < 256 || (ldo % 4) || !aligned16(ref)) return MOY_EINVAL;
+  if (head_stride < 32 || (head_stride % 4) || ldv < (head_stride == 32 ? 256 : 32) || (ldv % 4) || ld_oa < 8 * L * 4 * 3 || (ld_oa % 4) || ldo < 256 || (ldo % 4) || !aligned16(ref)) return MOY_EINVAL;
   LevelInfo lv{};
   int s = 0;
   for (int l = 0; l < L; ++l) {
@@ -1596,7 +1596,7 @@ extern "C" int moy_msda_fused(const void* value, int64_t ldv, int B, int S, cons
     if (reinterpret_cast<uintptr_t>(value) % (4 * sizeof(T)) || !aligned16(offaw) ||
         reinterpret_cast<uintptr_t>(out) % (4 * sizeof(T)))
       return MOY_EINVAL;
-    hipLaunchKernelGGL((msda_fused_kernel<T>), dim3((nrows + 3) / 4), dim3(256), 0, st, static_cast<const T*>(value), ldv, S, lv, L,
+    hipLaunchKernelGGL((msda_fused_kernel<T>), dim3((nrows + 3) / 4), dim3(256), 0, st, static_cast<const T*>(value), ldv, head_stride, S, lv, L,
                        offaw, ld_oa, ref, Lq, nrows, static_cast<T*>(out), ldo);
     return launch_status();
   })

@@ -450,14 +450,22 @@ class TrackEngine:
         Wv = torch.cat([sd[f"{d}.decoder.layers.{i}.cross_attn.value_proj.weight"] for i in range(ndl)], 0)
         bv = torch.cat([sd[f"{d}.decoder.layers.{i}.cross_attn.value_proj.bias"] for i in range(ndl)], 0)
         # ... written as ndl contiguous [B*S, hd] planes: a layer's slice is dense in HBM for its deformable gather
-        if os.environ.get("MOY_VALUE_PLANES", "1") != "0":
+        vmode = os.environ.get("MOY_VALUE_PLANES", "2")
+        dh = hd // arch.nh
+        if vmode == "2":
+            # [layer][head][token][32]: a head's map is a dense [B*S, 32] matrix, so the two x-taps of a bilinear sample are
+            # 128 contiguous bytes and the GEMM's stores are contiguous runs
+            self.value_planes = self._buf(ndl * arch.nh * B * S, dh)
+            value = [(View(self.value_planes[i * arch.nh * B * S:(i * arch.nh + 1) * B * S]), B * S * dh) for i in range(ndl)]
+            self._gemm(feats, self._weight(Wv), ndl * hd, hd, value[0][0], B * S, shift=self._dev(bv), planes=(dh, B * S * dh))
+        elif vmode == "1":      # A/B: one contiguous [B*S, hd] matrix per layer
             self.value_planes = self._buf(ndl * B * S, hd)
-            value = [View(self.value_planes[i * B * S:(i + 1) * B * S]) for i in range(ndl)]
-            self._gemm(feats, self._weight(Wv), ndl * hd, hd, value[0], B * S, shift=self._dev(bv), planes=(hd, B * S * hd))
-        else:       # A/B: one [B*S, ndl*hd] matrix, a layer = a 512-byte column slice of 3072-byte rows
+            value = [(View(self.value_planes[i * B * S:(i + 1) * B * S]), dh) for i in range(ndl)]
+            self._gemm(feats, self._weight(Wv), ndl * hd, hd, value[0][0], B * S, shift=self._dev(bv), planes=(hd, B * S * hd))
+        else:                   # A/B: one [B*S, ndl*hd] matrix, a layer = a 512-byte column slice of 3072-byte rows
             vall = View(self._buf(B * S, ndl * hd))
             self._gemm(feats, self._weight(Wv), ndl * hd, hd, vall, B * S, shift=self._dev(bv))
-            value = [vall.slice(i * hd, hd) for i in range(ndl)]
+            value = [(vall.slice(i * hd, hd), dh) for i in range(ndl)]
         self.value = value
 
         M = Md                           # from here on: decoder rows
@@ -489,8 +497,8 @@ class TrackEngine:
             boa = torch.cat([sd[q + ".cross_attn.sampling_offsets.bias"], sd[q + ".cross_attn.attention_weights.bias"]], 0)
             Woa_d, boa_d = self._linear_w_raw(Woa, boa)
             self._gemm(e1, Woa_d, Woa.shape[0], hd, View(offaw), M, shift=boa_d, A2=qpos, out_f32=True)
-            vslice = value[i]
-            self._add(lib.moy_msda_fused, vslice.ptr, vslice.ld, B, S, shapes_c, nl, offaw.data_ptr(), offaw.shape[1],
+            vslice, vhs = value[i]
+            self._add(lib.moy_msda_fused, vslice.ptr, vslice.ld, vhs, B, S, shapes_c, nl, offaw.data_ptr(), offaw.shape[1],
                       refs[cur].data_ptr(), Lq, samp.ptr, samp.ld, code)
             Wp, bp = self._linear_w(q + ".cross_attn.output_proj")
             self._gemm(samp, Wp, hd, hd, e2, M, shift=bp, R=e1, ln=self._ln(q + ".norm2"))

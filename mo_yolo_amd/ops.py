@@ -194,12 +194,16 @@ def mha_core(qkv, B, Lq, nh):
     return out
 
 
-def msda_fused(value, B, S, shapes, offaw, ref, Lq):
+def msda_fused(value, B, S, shapes, offaw, ref, Lq, head_planes=False):
+    """value: [B*S, 256] (head-major channels), or with head_planes [8, B*S, 32] contiguous."""
     _need_gpu(value, offaw, ref)
     nl = len(shapes)
     sh = (C.c_int32 * (2 * nl))(*[int(v) for hw in shapes for v in hw])
     out = torch.empty(B * Lq, 256, device=value.device, dtype=value.dtype)
-    L.check(L.lib().moy_msda_fused(value.data_ptr(), _ld(value), B, S, sh, nl, offaw.data_ptr(), _ld(offaw), ref.data_ptr(),
+    ldv, hs = (32, B * S * 32) if head_planes else (_ld(value), 32)
+    if head_planes:
+        assert value.is_contiguous() and tuple(value.shape) == (8, B * S, 32)
+    L.check(L.lib().moy_msda_fused(value.data_ptr(), ldv, hs, B, S, sh, nl, offaw.data_ptr(), _ld(offaw), ref.data_ptr(),
                                    Lq, out.data_ptr(), 256, _code(value), _st()), "moy_msda_fused")
     return out
 

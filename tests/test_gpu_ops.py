@@ -86,6 +86,13 @@ def test_gemm_weight_stationary_kernel_bit_identical_to_tiled(dt, M, N, act):
         torch.cuda.synchronize()
         assert torch.equal(pl[:, :M].permute(1, 0, 2).reshape(M, N), out[:M, :N]) and bool((pl[:, M] == 7.0).all())
         assert torch.equal(sm.permute(1, 0, 2).reshape(1000, N), out[:1000, :N])
+        hp = torch.full((N // 32, M + 1, 32), 7.0, device=DEV, dtype=dt)      # head planes of 32 columns
+        ops.gemm(xd, wd, N, K, out=hp[0, :M], planes=(32, (M + 1) * 32), **kw)
+        hs = torch.empty(N // 32, 1000, 32, device=DEV, dtype=dt)
+        ops.gemm(xd[:1000], wd, N, K, out=hs[0], planes=(32, 1000 * 32), **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(hp[:, :M].permute(1, 0, 2).reshape(M, N), out[:M, :N]) and bool((hp[:, M] == 7.0).all())
+        assert torch.equal(hs.permute(1, 0, 2).reshape(1000, N), out[:1000, :N])
     torch.cuda.synchronize()
     assert torch.equal(out[:M, :N], two), "weight-stationary kernel differs from the tiled kernel"
     assert bool((out[M] == 7.0).all()) and bool((out[:, N:] == 7.0).all()), "wrote outside its rows / columns"
@@ -337,6 +344,10 @@ def test_msda_fused_vs_oracle(dt):
     loc = rb[..., :2] + off / 4 * rb[..., 2:] * 0.5
     ref = O.msda_core(value.view(B, S, 8, 32), shapes, loc, aw).view(B * Lq, 256)
     assert torch.allclose(y.float().cpu(), ref, atol=tol(dt, 2e-5, 1e-2))
+    # head planes [8][B*S][32] (the layout the value projection writes for the gather): same result, bit for bit
+    vp = value.view(B * S, 8, 32).permute(1, 0, 2).contiguous().to(DEV, dt)
+    y2 = ops.msda_fused(vp, B, S, shapes, offaw.to(DEV), ref_box.to(DEV), Lq, head_planes=True)
+    assert torch.equal(y2, y)
 
 
 @pytest.mark.parametrize("dt", DT)
