@@ -170,6 +170,15 @@ int moy_rowdot(const void* X, int64_t ldx, const int32_t* x_rows, int M, int K, 
                const float* bias, int N, int mode, const float* aux, const int32_t* aux_rows, float* y, int dtype,
                void* stream);
 
+/* Three-layer box head in one launch (MLP(256, 256, 4, num_layers=3), nn/modules/transformer.py:149-161):
+ *   y[m, :] = W2 . relu(W1 . relu(W0 . x[xrow(m)] + b0) + b1) + b2, then mode as moy_rowdot (1: box refinement
+ *   transformer.py:709, 2: + anchors head.py:1045).  X dtype T (bf16 / fp16; fp32 returns MOY_ENOSYS: use moy_gemm x 2 +
+ *   moy_rowdot), W0, W1: T [256, 256] (rows = output channels); b0, b1 fp32 [256]; w2 fp32 [4, 256]; b2 fp32 [4]; y fp32 [M, 4].
+ *   The hidden activations are rounded to T exactly where the three separate launches store them. */
+int moy_mlp_head(const void* X, int64_t ldx, const int32_t* x_rows, int M, const void* W0, const float* b0, const void* W1,
+                 const float* b1, const float* w2, const float* b2, int mode, const float* aux, const int32_t* aux_rows,
+                 float* y, int dtype, void* stream);
+
 /* Query selection: per frame b, indices of the nq largest max_c scores[b, s, c], sorted
  * descending (torch.topk(enc_outputs_scores.max(-1).values, nq), head.py:1048).  Ties: lower
  * token index first.  scores fp32 [B, S, nc].  valid (optional) uint8 [S]: n_masked[b] receives

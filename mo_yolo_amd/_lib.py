@@ -42,6 +42,7 @@ SIGNATURES = {
     "moy_sppf_pool": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, i64, C.c_int, vp]),
     "moy_upsample2x": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
     "moy_rowdot": (C.c_int, [vp, i64, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]),
+    "moy_mlp_head": (C.c_int, [vp, i64, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp]),
     "moy_topk": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "moy_pos2posemb": (C.c_int, [vp, C.c_int, vp, i64, C.c_int, vp]),
     "moy_mha_core": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, vp]),

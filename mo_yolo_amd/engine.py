@@ -405,6 +405,13 @@ class TrackEngine:
             W0, b0 = self._linear_w(prefix + ".layers.0")
             W1, b1 = self._linear_w(prefix + ".layers.1")
             w2, b2 = self._dev(sd[prefix + ".layers.2.weight"]), self._dev(sd[prefix + ".layers.2.bias"])
+            if self.dtype != torch.float32 and os.environ.get("MOY_MLP_HEAD", "1") != "0":
+                # the whole head in one launch (csrc/mlp_head.hip): hidden activations stay in LDS
+                self._add(lib.moy_mlp_head, x.ptr, x.ld, a_rows.data_ptr() if a_rows is not None else None, M, W0.data_ptr(),
+                          b0.data_ptr(), W1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), mode, aux.data_ptr(),
+                          aux_rows.data_ptr() if aux_rows is not None else None, out_t.data_ptr(), code,
+                          meta=dict(name=f"mlp_head M{M}", bytes=(M * hd + 2 * hd * hd) * 2 + M * 16, flops=4 * M * hd * hd))
+                return
             self._gemm(x, W0, hd, hd, t1, M, shift=b0, act=L.ACT_RELU, a_rows=a_rows)
             self._gemm(t1, W1, hd, hd, t2, M, shift=b1, act=L.ACT_RELU)
             self._add(lib.moy_rowdot, t2.ptr, t2.ld, None, M, hd, w2.data_ptr(), b2.data_ptr(), 4, mode,

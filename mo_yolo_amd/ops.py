@@ -166,6 +166,19 @@ def rowdot(X, Wt, bias, mode=0, aux=None, aux_rows=None, x_rows=None):
     return y
 
 
+def mlp_head(X, W0p, b0, W1p, b1, w2, b2, mode=0, aux=None, aux_rows=None, x_rows=None):
+    """See moy_mlp_head: X [rows, 256] 16-bit, W0p / W1p padded [256, 256] in X's dtype, b0 / b1 / w2 [4, 256] / b2 fp32."""
+    _need_gpu(X)
+    M = x_rows.numel() if x_rows is not None else X.shape[0]
+    y = torch.empty(M, 4, device=X.device, dtype=torch.float32)
+    L.check(L.lib().moy_mlp_head(X.data_ptr(), _ld(X), x_rows.data_ptr() if x_rows is not None else None, M, W0p.data_ptr(),
+                                 b0.data_ptr(), W1p.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), mode,
+                                 aux.data_ptr() if aux is not None else None,
+                                 aux_rows.data_ptr() if aux_rows is not None else None, y.data_ptr(), _code(X), _st()),
+            "moy_mlp_head")
+    return y
+
+
 def topk(scores, nq, valid=None):
     """scores fp32 [B, S, nc] -> (idx_local int32 [B, nq], idx_global, n_masked int32 [B])."""
     _need_gpu(scores)

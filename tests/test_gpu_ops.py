@@ -290,6 +290,36 @@ def test_rowdot_modes(dt):
     assert torch.allclose(y.cpu(), x[rows.long()] @ w.T + b, atol=2e-5)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,mode", [(300, 1), (1000 + 7, 2), (33, 0)])
+def test_mlp_head_one_launch_equals_three(dt, M, mode):
+    """moy_mlp_head (box head in one launch) vs moy_gemm x 2 + moy_rowdot: identical hidden activations (same rounding points,
+    same k order), the 4 outputs equal up to the fp32 summation order; and vs the torch fp32 MLP."""
+    x = q(rnd(M + 50, 256, seed=1), dt)
+    W0, W1 = q(rnd(256, 256, seed=2, scale=1 / 16), dt), q(rnd(256, 256, seed=3, scale=1 / 16), dt)
+    b0, b1, w2, b2 = rnd(256, seed=4, scale=0.1), rnd(256, seed=5, scale=0.1), rnd(4, 256, seed=6, scale=0.1), rnd(4, seed=7)
+    rows = torch.randperm(M + 50, generator=torch.Generator().manual_seed(8))[:M].int() if mode == 2 else None
+    aux = torch.rand(M if mode != 2 else 77, 4, generator=torch.Generator().manual_seed(9))
+    aux_rows = (torch.arange(M) % 77).int() if mode == 2 else None
+    xd, W0d, W1d = x.to(DEV, dt), ops.pad_weight(W0.to(DEV), dt), ops.pad_weight(W1.to(DEV), dt)
+    kw = dict(mode=mode, aux=aux.to(DEV) if mode else None, aux_rows=aux_rows.to(DEV) if aux_rows is not None else None)
+    xin = xd if rows is not None else xd[:M]
+    y = ops.mlp_head(xin, W0d, b0.to(DEV), W1d, b1.to(DEV), w2.to(DEV), b2.to(DEV), x_rows=rows.to(DEV) if rows is not None else None, **kw)
+    t1 = ops.gemm(xin, W0d, 256, 256, shift=b0.to(DEV), act=L.ACT_RELU, a_rows=rows.to(DEV) if rows is not None else None)
+    t2 = ops.gemm(t1, W1d, 256, 256, shift=b1.to(DEV), act=L.ACT_RELU)
+    y3 = ops.rowdot(t2, w2.to(DEV), b2.to(DEV), **kw)
+    assert torch.allclose(y, y3, atol=2e-5, rtol=1e-5)
+    xs = x[rows.long()] if rows is not None else x[:M]
+    ref = F.relu(q(F.relu(xs @ W0.T + b0), dt) @ W1.T + b1)
+    ref = q(ref, dt) @ w2.T + b2
+    if mode == 1:
+        a = aux.clamp(0, 1)
+        ref = torch.sigmoid(ref + torch.log(a.clamp(min=1e-5) / (1 - a).clamp(min=1e-5)))
+    elif mode == 2:
+        ref = ref + aux[aux_rows.long()]
+    assert torch.allclose(y.cpu(), ref, atol=tol(dt, 1e-5, 3e-2))
+
+
 @pytest.mark.parametrize("B,S,nc,nq", [(1, 13566, 1, 300), (3, 315, 1, 50), (2, 126, 3, 20), (1, 42840, 1, 500), (2, 1000, 2, 1000)])
 def test_topk_matches_torch_and_flags_masked(B, S, nc, nq):
     sc = rnd(B, S, nc, seed=B + S)
