@@ -179,6 +179,32 @@ int moy_mlp_head(const void* X, int64_t ldx, const int32_t* x_rows, int M, const
                  const float* b1, const float* w2, const float* b2, int mode, const float* aux, const int32_t* aux_rows,
                  float* y, int dtype, void* stream);
 
+/* The row-wise tail of a decoder layer in one launch (MOTRDecoderLayer.forward after the deformable sampling,
+ * nn/modules/transformer.py:642-652, + the box refinement of MOTRTransformerDecoder.forward, :705-709):
+ *   e2      = LayerNorm(samp . Wp^T + bp + e1)                     (cross_attn.output_proj, norm2)
+ *   out     = LayerNorm(relu(e2 . W1^T + b1) . W2^T + b2 + e2)     (linear1, linear2, norm3)
+ *   ref_out = sigmoid(MLP3(out) + inverse_sigmoid(ref_in))         (dec_bbox_head[i]; eps 1e-5)
+ * T = bf16 / fp16 (fp32 returns MOY_ENOSYS: moy_gemm x 3 + moy_mlp_head / moy_rowdot, the parity path).  All weight matrices
+ * are T, [out features, in features] row-major with the in-feature pitch of their own width (256, or d_ffn for W2);
+ * biases / LayerNorm vectors fp32; w2 fp32 [4, 256]; d_ffn a multiple of 256; hidden width 256.  Every intermediate is rounded
+ * to T where the separate launches store it; the LayerNorm statistics are one-pass (E[v^2] - mean^2). */
+typedef struct moy_decoder_tail_args {
+  const void* samp; int64_t ld_samp;   /* T [M, 256] */
+  const void* e1;   int64_t ld_e1;     /* T [M, 256] residual */
+  int32_t M;
+  const void* Wp; const float* bp; const float* ln2_g; const float* ln2_b;
+  const void* W1; const float* b1;     /* [d_ffn, 256], [d_ffn] */
+  const void* W2; const float* b2;     /* [256, d_ffn], [256] */
+  int32_t d_ffn;
+  const float* ln3_g; const float* ln3_b;
+  void* out; int64_t ld_out;           /* T [M, 256] */
+  const void* B0; const float* c0; const void* B1; const float* c1; const float* w2; const float* c2;
+  const float* ref_in; float* ref_out; /* fp32 [M, 4] */
+  int32_t dtype;
+} moy_decoder_tail_args;
+
+int moy_decoder_tail(const moy_decoder_tail_args* args, void* stream);
+
 /* Query selection: per frame b, indices of the nq largest max_c scores[b, s, c], sorted
  * descending (torch.topk(enc_outputs_scores.max(-1).values, nq), head.py:1048).  Ties: lower
  * token index first.  scores fp32 [B, S, nc].  valid (optional) uint8 [S]: n_masked[b] receives

@@ -32,6 +32,18 @@ class GemmArgs(C.Structure):
     ]
 
 
+class DecoderTailArgs(C.Structure):
+    """Mirror of `moy_decoder_tail_args` (include/moyolo.h)."""
+    _fields_ = [
+        ("samp", vp), ("ld_samp", i64), ("e1", vp), ("ld_e1", i64), ("M", i32),
+        ("Wp", vp), ("bp", vp), ("ln2_g", vp), ("ln2_b", vp),
+        ("W1", vp), ("b1", vp), ("W2", vp), ("b2", vp), ("d_ffn", i32),
+        ("ln3_g", vp), ("ln3_b", vp), ("out", vp), ("ld_out", i64),
+        ("B0", vp), ("c0", vp), ("B1", vp), ("c1", vp), ("w2", vp), ("c2", vp),
+        ("ref_in", vp), ("ref_out", vp), ("dtype", i32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol declared in include/moyolo.h
 SIGNATURES = {
     "moy_version": (C.c_int, []),
@@ -43,6 +55,7 @@ SIGNATURES = {
     "moy_upsample2x": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
     "moy_rowdot": (C.c_int, [vp, i64, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]),
     "moy_mlp_head": (C.c_int, [vp, i64, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp]),
+    "moy_decoder_tail": (C.c_int, [C.POINTER(DecoderTailArgs), vp]),
     "moy_topk": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "moy_pos2posemb": (C.c_int, [vp, C.c_int, vp, i64, C.c_int, vp]),
     "moy_mha_core": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, vp]),

@@ -508,12 +508,33 @@ class TrackEngine:
             self._add(lib.moy_msda_fused, vslice.ptr, vslice.ld, vhs, B, S, shapes_c, nl, offaw.data_ptr(), offaw.shape[1],
                       refs[cur].data_ptr(), Lq, samp.ptr, samp.ld, code)
             Wp, bp = self._linear_w(q + ".cross_attn.output_proj")
-            self._gemm(samp, Wp, hd, hd, e2, M, shift=bp, R=e1, ln=self._ln(q + ".norm2"))
             W1, b1 = self._linear_w(q + ".linear1")
             W2, b2 = self._linear_w(q + ".linear2")
-            self._gemm(e2, W1, arch.d_ffn, hd, ffn, M, shift=b1, act=L.ACT_RELU)
-            self._gemm(ffn, W2, hd, arch.d_ffn, embed[enxt], M, shift=b2, R=e2, ln=self._ln(q + ".norm3"))
-            bbox_mlp(f"{d}.dec_bbox_head.{i}", embed[enxt], None, 1, refs[cur], None, refs[nxt], M=M)
+            if self.dtype != torch.float32 and arch.d_ffn % 256 == 0 and os.environ.get("MOY_DEC_TAIL", "1") != "0":
+                # output_proj + norm2, FFN + norm3 and the box refinement as one launch (csrc/dec_tail.hip)
+                ln2, ln3 = self._ln(q + ".norm2"), self._ln(q + ".norm3")
+                hp = f"{d}.dec_bbox_head.{i}"
+                B0, c0 = self._linear_w(hp + ".layers.0")
+                B1, c1 = self._linear_w(hp + ".layers.1")
+                w2h, c2 = self._dev(sd[hp + ".layers.2.weight"]), self._dev(sd[hp + ".layers.2.bias"])
+                t = L.DecoderTailArgs()
+                t.samp, t.ld_samp, t.e1, t.ld_e1, t.M = samp.ptr, samp.ld, e1.ptr, e1.ld, M
+                t.Wp, t.bp, t.ln2_g, t.ln2_b = Wp.data_ptr(), bp.data_ptr(), ln2[0].data_ptr(), ln2[1].data_ptr()
+                t.W1, t.b1, t.W2, t.b2, t.d_ffn = W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), arch.d_ffn
+                t.ln3_g, t.ln3_b, t.out, t.ld_out = ln3[0].data_ptr(), ln3[1].data_ptr(), embed[enxt].ptr, embed[enxt].ld
+                t.B0, t.c0, t.B1, t.c1, t.w2, t.c2 = (B0.data_ptr(), c0.data_ptr(), B1.data_ptr(), c1.data_ptr(), w2h.data_ptr(),
+                                                      c2.data_ptr())
+                t.ref_in, t.ref_out, t.dtype = refs[cur].data_ptr(), refs[nxt].data_ptr(), code
+                self._keep.append(t)
+                wb = (3 * hd * hd + 2 * hd * arch.d_ffn) * 2
+                self._add(lib.moy_decoder_tail, C.byref(t),
+                          meta=dict(name=f"decoder_tail M{M}", bytes=3 * M * hd * 2 + wb + M * 32,
+                                    flops=2 * M * hd * (3 * hd + 2 * arch.d_ffn)))
+            else:
+                self._gemm(samp, Wp, hd, hd, e2, M, shift=bp, R=e1, ln=self._ln(q + ".norm2"))
+                self._gemm(e2, W1, arch.d_ffn, hd, ffn, M, shift=b1, act=L.ACT_RELU)
+                self._gemm(ffn, W2, hd, arch.d_ffn, embed[enxt], M, shift=b2, R=e2, ln=self._ln(q + ".norm3"))
+                bbox_mlp(f"{d}.dec_bbox_head.{i}", embed[enxt], None, 1, refs[cur], None, refs[nxt], M=M)
             self.layer_out.append((embed[enxt], refs[nxt]))
             cur, nxt = nxt, cur
             ecur, enxt = enxt, (2 if enxt == 1 else 1)

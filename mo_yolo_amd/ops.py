@@ -179,6 +179,24 @@ def mlp_head(X, W0p, b0, W1p, b1, w2, b2, mode=0, aux=None, aux_rows=None, x_row
     return y
 
 
+def decoder_tail(samp, e1, Wp, bp, ln2, W1, b1, W2, b2, ln3, B0, c0, B1, c1, w2, c2, ref_in):
+    """See moy_decoder_tail.  samp / e1 [M, 256] 16-bit; weights in that dtype ([out, in]); vectors fp32; ref_in fp32 [M, 4].
+    Returns (out [M, 256], ref_out fp32 [M, 4])."""
+    _need_gpu(samp, e1)
+    M = samp.shape[0]
+    out = torch.empty(M, 256, device=samp.device, dtype=samp.dtype)
+    ref_out = torch.empty(M, 4, device=samp.device, dtype=torch.float32)
+    t = L.DecoderTailArgs()
+    t.samp, t.ld_samp, t.e1, t.ld_e1, t.M = samp.data_ptr(), _ld(samp), e1.data_ptr(), _ld(e1), M
+    t.Wp, t.bp, t.ln2_g, t.ln2_b = Wp.data_ptr(), bp.data_ptr(), ln2[0].data_ptr(), ln2[1].data_ptr()
+    t.W1, t.b1, t.W2, t.b2, t.d_ffn = W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W1.shape[0]
+    t.ln3_g, t.ln3_b, t.out, t.ld_out = ln3[0].data_ptr(), ln3[1].data_ptr(), out.data_ptr(), 256
+    t.B0, t.c0, t.B1, t.c1, t.w2, t.c2 = B0.data_ptr(), c0.data_ptr(), B1.data_ptr(), c1.data_ptr(), w2.data_ptr(), c2.data_ptr()
+    t.ref_in, t.ref_out, t.dtype = ref_in.data_ptr(), ref_out.data_ptr(), _code(samp)
+    L.check(L.lib().moy_decoder_tail(C.byref(t), _st()), "moy_decoder_tail")
+    return out, ref_out
+
+
 def topk(scores, nq, valid=None):
     """scores fp32 [B, S, nc] -> (idx_local int32 [B, nq], idx_global, n_masked int32 [B])."""
     _need_gpu(scores)

@@ -320,6 +320,46 @@ def test_mlp_head_one_launch_equals_three(dt, M, mode):
     assert torch.allclose(y.cpu(), ref, atol=tol(dt, 1e-5, 3e-2))
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,dffn", [(300, 1024), (1000 + 7, 512)])
+def test_decoder_tail_one_launch_equals_separate(dt, M, dffn):
+    """moy_decoder_tail (output_proj + norm2, FFN + norm3, box refinement in one launch) vs the separate launches
+    (moy_gemm x 3 + moy_mlp_head) and vs the torch fp32 chain with the same rounding points (transformer.py:642-652, 705-709)."""
+    g = lambda *s_, seed, scale=1.0: rnd(*s_, seed=seed, scale=scale)
+    samp, e1 = q(g(M, 256, seed=1), dt), q(g(M, 256, seed=2), dt)
+    Wp, W1, W2 = q(g(256, 256, seed=3, scale=1 / 16), dt), q(g(dffn, 256, seed=4, scale=1 / 16), dt), q(g(256, dffn, seed=5, scale=1 / 32), dt)
+    B0, B1 = q(g(256, 256, seed=6, scale=1 / 16), dt), q(g(256, 256, seed=7, scale=1 / 16), dt)
+    bp, b1, b2, c0, c1 = (g(256, seed=8, scale=0.1), g(dffn, seed=9, scale=0.1), g(256, seed=10, scale=0.1), g(256, seed=11, scale=0.1),
+                          g(256, seed=12, scale=0.1))
+    g2, be2, g3, be3 = g(256, seed=13) * 0.2 + 1, g(256, seed=14, scale=0.1), g(256, seed=15) * 0.2 + 1, g(256, seed=16, scale=0.1)
+    w2, c2 = g(4, 256, seed=17, scale=0.1), g(4, seed=18)
+    ref_in = torch.rand(M, 4, generator=torch.Generator().manual_seed(19))
+    d = lambda t: t.to(DEV)
+    pw = lambda w: ops.pad_weight(w.to(DEV), dt)
+    sd_, e1d = samp.to(DEV, dt), e1.to(DEV, dt)
+    out, ref_out = ops.decoder_tail(sd_, e1d, pw(Wp), d(bp), (d(g2), d(be2)), pw(W1), d(b1), pw(W2), d(b2), (d(g3), d(be3)),
+                                    pw(B0), d(c0), pw(B1), d(c1), d(w2), d(c2), d(ref_in))
+    # separate launches
+    e2 = ops.gemm(sd_, pw(Wp), 256, 256, shift=d(bp), R=e1d, ln=(d(g2), d(be2)))
+    h = ops.gemm(e2, pw(W1), dffn, 256, shift=d(b1), act=L.ACT_RELU)
+    e3 = ops.gemm(h, pw(W2), 256, dffn, shift=d(b2), R=e2, ln=(d(g3), d(be3)))
+    r3 = ops.mlp_head(e3, pw(B0), d(c0), pw(B1), d(c1), d(w2), d(c2), mode=1, aux=d(ref_in))
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    # a handful of elements may land on the other side of a rounding boundary (one-pass vs two-pass LayerNorm statistics)
+    diff = (out.float() - e3.float()).abs()
+    assert float(diff.max()) <= 4 * ulp * float(e3.float().abs().max()) and float((diff > 0).float().mean()) < 0.02
+    assert torch.allclose(ref_out, r3, atol=3e-3 if dt == torch.bfloat16 else 5e-4)
+    # torch fp32 chain with the storage-type rounding points
+    r_e2 = q(F.layer_norm(samp @ Wp.T + bp + e1, (256,), g2, be2, 1e-5), dt)
+    r_h = q(F.relu(r_e2 @ W1.T + b1), dt)
+    r_e3 = q(F.layer_norm(r_h @ W2.T + b2 + r_e2, (256,), g3, be3, 1e-5), dt)
+    assert torch.allclose(out.float().cpu(), r_e3, atol=tol(dt, 1e-5, 4e-2))
+    t2 = q(F.relu(q(F.relu(r_e3 @ B0.T + c0), dt) @ B1.T + c1), dt)
+    a = ref_in.clamp(0, 1)
+    r_box = torch.sigmoid(t2 @ w2.T + c2 + torch.log(a.clamp(min=1e-5) / (1 - a).clamp(min=1e-5)))
+    assert torch.allclose(ref_out.cpu(), r_box, atol=tol(dt, 1e-5, 2e-2))
+
+
 @pytest.mark.parametrize("B,S,nc,nq", [(1, 13566, 1, 300), (3, 315, 1, 50), (2, 126, 3, 20), (1, 42840, 1, 500), (2, 1000, 2, 1000)])
 def test_topk_matches_torch_and_flags_masked(B, S, nc, nq):
     sc = rnd(B, S, nc, seed=B + S)
