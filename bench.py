@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=2,
                     help="split the batch into this many sub-batches, each on its own HIP stream + hipGraph")
+    ap.add_argument("--split-priority", type=int, default=int(os.environ.get("MOY_SPLIT_PRIORITY", "0")),
+                    help="1: the query-sized chain of each sub-batch replays as its own hipGraph on a high-priority stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=12)
     ap.add_argument("--dump-launches", default=None, help="write the per-launch timing table (json) here")
@@ -93,7 +95,8 @@ def main():
     S = max(1, a.streams)
     assert B % S == 0, "--batch must be a multiple of --streams"
     Bs = B // S
-    pipe = StreamedEngines(arch, sd, cfg["H"], cfg["W"], batch=B, streams=S, graph=not a.no_graph, dtype=dtype, device=dev)
+    pipe = StreamedEngines(arch, sd, cfg["H"], cfg["W"], batch=B, streams=S, graph=not a.no_graph, dtype=dtype, device=dev,
+                           split_priority=bool(a.split_priority))
     eng = pipe.engines[0]
 
     # sequence shard of this rank (sequence i -> GPU i, no cross-GPU term)

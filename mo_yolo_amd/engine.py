@@ -369,6 +369,30 @@ class TrackEngine:
         self.anchors = self._dev(anchors[0])                        # [S, 4] (+inf at masked tokens)
         self.valid = self._dev(valid[0, :, 0].to(torch.uint8))     # [S]
 
+        # value projections of all decoder layers in ONE GEMM over the S tokens: feats is layer
+        # invariant (transformer.py:700-706 passes the same `feats` to every layer)
+        ndl = arch.ndl
+        Wv = torch.cat([sd[f"{d}.decoder.layers.{i}.cross_attn.value_proj.weight"] for i in range(ndl)], 0)
+        bv = torch.cat([sd[f"{d}.decoder.layers.{i}.cross_attn.value_proj.bias"] for i in range(ndl)], 0)
+        # ... written as ndl contiguous [B*S, hd] planes: a layer's slice is dense in HBM for its deformable gather
+        vmode = os.environ.get("MOY_VALUE_PLANES", "2")
+        dh = hd // arch.nh
+        if vmode == "2":
+            # [layer][head][token][32]: a head's map is a dense [B*S, 32] matrix, so the two x-taps of a bilinear sample are
+            # 128 contiguous bytes and the GEMM's stores are contiguous runs
+            self.value_planes = self._buf(ndl * arch.nh * B * S, dh)
+            value = [(View(self.value_planes[i * arch.nh * B * S:(i * arch.nh + 1) * B * S]), B * S * dh) for i in range(ndl)]
+            self._gemm(feats, self._weight(Wv), ndl * hd, hd, value[0][0], B * S, shift=self._dev(bv), planes=(dh, B * S * dh))
+        elif vmode == "1":      # A/B: one contiguous [B*S, hd] matrix per layer
+            self.value_planes = self._buf(ndl * B * S, hd)
+            value = [(View(self.value_planes[i * B * S:(i + 1) * B * S]), dh) for i in range(ndl)]
+            self._gemm(feats, self._weight(Wv), ndl * hd, hd, value[0][0], B * S, shift=self._dev(bv), planes=(hd, B * S * hd))
+        else:                   # A/B: one [B*S, ndl*hd] matrix, a layer = a 512-byte column slice of 3072-byte rows
+            vall = View(self._buf(B * S, ndl * hd))
+            self._gemm(feats, self._weight(Wv), ndl * hd, hd, vall, B * S, shift=self._dev(bv))
+            value = [(vall.slice(i * hd, hd), dh) for i in range(ndl)]
+        self.value = value
+
         # enc_output (Linear + LayerNorm, head.py:1036-1040) is row-wise and only the nq selected rows are ever read again
         # (head.py:1048-1113), so the pass over all S tokens produces the enc_score_head logits ONLY (C = NULL): no [B*S, 256]
         # write.  The selected rows are recomputed below by the same GEMM on gathered rows.
@@ -390,6 +414,7 @@ class TrackEngine:
         self.topk_global = torch.zeros(B, nq, device=self.dev, dtype=torch.int32)
         self.n_masked = torch.zeros(B, device=self.dev, dtype=torch.int32)
         self._topk_step = len(self._steps)
+        self._split = len(self._steps)      # [0, _split): bandwidth-bound launches over all tokens; [_split, end): the query-sized chain
         self._add(lib.moy_topk, self.scores_all.data_ptr(), B, S, nc, nq, self.valid.data_ptr(),
                   self.topk_local.data_ptr(), self.topk_global.data_ptr(), self.n_masked.data_ptr())
 
@@ -450,30 +475,6 @@ class TrackEngine:
                       det_embed.ptr, det_embed.ld, det_qpos.ptr, det_qpos.ld, self.refer_logit.data_ptr(), B, n_max, nq,
                       embed[0].ptr, embed[0].ld, qpos.ptr, qpos.ld, self.refer_all.data_ptr(), refs[0].data_ptr(), code)
         self.query_pos = qpos
-
-        # value projections of all decoder layers in ONE GEMM over the S tokens: feats is layer
-        # invariant (transformer.py:700-706 passes the same `feats` to every layer)
-        ndl = arch.ndl
-        Wv = torch.cat([sd[f"{d}.decoder.layers.{i}.cross_attn.value_proj.weight"] for i in range(ndl)], 0)
-        bv = torch.cat([sd[f"{d}.decoder.layers.{i}.cross_attn.value_proj.bias"] for i in range(ndl)], 0)
-        # ... written as ndl contiguous [B*S, hd] planes: a layer's slice is dense in HBM for its deformable gather
-        vmode = os.environ.get("MOY_VALUE_PLANES", "2")
-        dh = hd // arch.nh
-        if vmode == "2":
-            # [layer][head][token][32]: a head's map is a dense [B*S, 32] matrix, so the two x-taps of a bilinear sample are
-            # 128 contiguous bytes and the GEMM's stores are contiguous runs
-            self.value_planes = self._buf(ndl * arch.nh * B * S, dh)
-            value = [(View(self.value_planes[i * arch.nh * B * S:(i * arch.nh + 1) * B * S]), B * S * dh) for i in range(ndl)]
-            self._gemm(feats, self._weight(Wv), ndl * hd, hd, value[0][0], B * S, shift=self._dev(bv), planes=(dh, B * S * dh))
-        elif vmode == "1":      # A/B: one contiguous [B*S, hd] matrix per layer
-            self.value_planes = self._buf(ndl * B * S, hd)
-            value = [(View(self.value_planes[i * B * S:(i + 1) * B * S]), dh) for i in range(ndl)]
-            self._gemm(feats, self._weight(Wv), ndl * hd, hd, value[0][0], B * S, shift=self._dev(bv), planes=(hd, B * S * hd))
-        else:                   # A/B: one [B*S, ndl*hd] matrix, a layer = a 512-byte column slice of 3072-byte rows
-            vall = View(self._buf(B * S, ndl * hd))
-            self._gemm(feats, self._weight(Wv), ndl * hd, hd, vall, B * S, shift=self._dev(bv))
-            value = [(vall.slice(i * hd, hd), dh) for i in range(ndl)]
-        self.value = value
 
         M = Md                           # from here on: decoder rows
         qkv = View(self._buf(M, 3 * hd))
@@ -744,6 +745,25 @@ class TrackEngine:
         self._graph = g
         return g
 
+    def capture_split(self, warmup: int = 2):
+        """Two hipGraphs: launches [0, _split) (backbone, projections and score pass over all tokens) and [_split, end) (query
+        selection + decoder: a dependent chain of query-sized launches).  StreamedEngines replays the second on a high-priority
+        stream so that its small launches are dispatched ahead of the other sub-batch's full-chip kernels."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.run_steps()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g0, g1 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g0):
+            self.run_steps(0, self._split)
+        with torch.cuda.graph(g1):
+            self.run_steps(self._split)
+        self._graph_lo, self._graph_hi = g0, g1
+        return g0, g1
+
     def outputs(self):
         if self.arch.head_kind == "detect":
             return dict(y=self.y, rows=self.rows, n_rows=self.n_rows)
@@ -772,13 +792,16 @@ class StreamedEngines:
     (measured: 2 streams x 96 frames 8.8k FPS vs 1 x 96 8.2k, same device).  Frames stay independent (per-frame reset
     semantics), so the split is result-neutral (tests/test_gpu_engine.py)."""
 
-    def __init__(self, arch, sd, H, W, batch, streams=2, graph=True, **kw):
+    def __init__(self, arch, sd, H, W, batch, streams=2, graph=True, split_priority=False, **kw):
         if batch % streams:
             raise ValueError("batch must be a multiple of streams")
         self.B, self.S, self.Bs = batch, streams, batch // streams
         self.engines = [TrackEngine(arch, sd, H, W, batch=self.Bs, **kw) for _ in range(streams)]
         dev = self.engines[0].dev
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(streams)]
+        # split_priority: the query-sized chain of every sub-batch replays from its own hipGraph on a high-priority stream
+        self._split = bool(split_priority and graph and hasattr(self.engines[0], "_split"))
+        self.hi_streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(streams)] if self._split else []
         self._graph = graph
         self._warm = False
 
@@ -788,7 +811,10 @@ class StreamedEngines:
         torch.cuda.synchronize()
         if self._graph:
             for e in self.engines:
-                e.capture()
+                if self._split:
+                    e.capture_split()
+                else:
+                    e.capture()
         self._warm = True
 
     def forward(self, frames):
@@ -798,12 +824,22 @@ class StreamedEngines:
         cur = torch.cuda.current_stream()
         for k, (e, st) in enumerate(zip(self.engines, self.streams)):
             st.wait_stream(cur)                                   # the frames were produced on the caller's stream
-            with torch.cuda.stream(st):
-                e.forward(frames[k * self.Bs:(k + 1) * self.Bs])
+            if self._split:
+                hi = self.hi_streams[k]
+                st.wait_stream(hi)                                # the previous step's chain still reads this engine's buffers
+                with torch.cuda.stream(st):
+                    e.input.copy_(frames[k * self.Bs:(k + 1) * self.Bs], non_blocking=True)
+                    e._graph_lo.replay()
+                hi.wait_stream(st)
+                with torch.cuda.stream(hi):
+                    e._graph_hi.replay()
+            else:
+                with torch.cuda.stream(st):
+                    e.forward(frames[k * self.Bs:(k + 1) * self.Bs])
         return [e.outputs() for e in self.engines]
 
     def synchronize(self):
-        for st in self.streams:
+        for st in self.streams + self.hi_streams:
             st.synchronize()
 
     def outputs(self):
