@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=192, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=576, help="frames per step per GPU (288 per sub-batch engine is the largest whose buffers stay inside 2 GiB descriptors)")
     ap.add_argument("--config", default="c2", choices=["c2", "c4"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
