@@ -37,6 +37,8 @@ struct WregParams {   // ngroups = N / (columns per block)
   int M, N;
   int plane_cols;       // column planes (moy_gemm_args.plane_cols), 0 = off
   int64_t plane_stride;
+  int c_rpb, c_bstride; // output row remap (moy_gemm_args.c_rows_per_batch / c_batch_stride), 0 = off
+  FastDiv fd_rpb;
   int ngroups;   // N / 256
   int lanes;     // row-tile sequences per XCD
   int ntiles;    // ceil(M / BM)
@@ -79,25 +81,32 @@ __device__ __forceinline__ f32x4 mfma16<f16_t>(f32x4 acc, u32x4 w, u32x4 a) {
 }
 
 constexpr int WREG_MAXDOT = 4;           // classes of the fused narrow head in score mode
-template <int BM, int NBUF, bool LN, int NW = 4>
+template <int BM, int NBUF, bool LN, int NW = 4, int WC = 64, int K = 256>
 constexpr int wreg_lds_bytes() {
   // A ring | (store mode) 4 epilogue strips | scale, shift | (score mode) g*w per class, G/B constants, row partials [BM][6][16]
-  return NBUF * BM * 512 + (LN ? 0 : NW * BM * 136) + NW * 512 + (LN ? WREG_MAXDOT * 1024 + 64 + BM * ((2 + WREG_MAXDOT) * 64 + 16) : 0);
+  return NBUF * BM * K * 2 + (LN ? 0 : NW * BM * (WC * 2 + 8)) + NW * WC * 8 + (LN ? WREG_MAXDOT * 1024 + 64 + BM * ((2 + WREG_MAXDOT) * 64 + 16) : 0);
 }
 
-template <typename T, int BM, int NBUF, int OCC, bool LN, int NW>
+// WC = output columns per wave (64: K = 256 only; 32: K up to 512 fits the registers), K = reduction length (multiple of 128).
+template <typename T, int BM, int NBUF, int OCC, bool LN, int NW, int WC, int K>
 __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParams p) {
-  static_assert((NW == 4 || NW == 8) && (!LN || NW == 4), "4 waves = 256 columns per block, or 8 waves = 512 (store mode)");
-  constexpr int BNB = NW * 64;             // output columns per block
+  static_assert((NW == 4 || NW == 8) && (!LN || (NW == 4 && WC == 64 && K == 256)), "score mode: 4 waves x 64 columns, K = 256");
+  static_assert((WC == 32 || WC == 64) && K % 128 == 0 && K <= 512, "column width per wave / reduction length");
+  constexpr int BNB = NW * WC;             // output columns per block
   constexpr int MT = BM / 16;              // row sub-tiles per wave (every wave covers all BM rows)
-  constexpr int NT = 4;                    // 64 columns per wave
-  constexpr int TILE_BYTES = BM * 512;
+  constexpr int NT = WC / 16;              // column sub-tiles per wave
+  constexpr int KB = K * 2;                // bytes per activation row
+  constexpr int CPR = K / 8;               // 16-byte chunks per row (a multiple of 16: the swizzle stays inside groups of 16)
+  constexpr int KP = K / 32;               // MFMA k panels
+  constexpr int TILE_BYTES = BM * KB;
   constexpr int IPW = TILE_BYTES / 1024 / NW;  // DMA instructions per wave and tile
   constexpr int DIST = NBUF - 1;           // tiles in flight ahead of the one being computed
-  constexpr int EP_PITCH = 136;            // bytes per row of the wave's epilogue strip (64 x 2 B + 8)
-  constexpr int NST = LN ? 0 : BM / 8;     // 16-byte store instructions per wave and tile (score mode: see below)
+  constexpr int EP_PITCH = WC * 2 + 8;     // bytes per row of the wave's epilogue strip
+  constexpr int LPR = WC / 8;              // lanes per row in the store pass (16 bytes each)
+  constexpr int RPI = 64 / LPR;            // rows per store instruction
+  constexpr int NST = LN ? 0 : BM / RPI;   // 16-byte store instructions per wave and tile (score mode: see below)
   constexpr int EP_BYTES = LN ? 0 : NW * BM * EP_PITCH;
-  static_assert(BM % 16 == 0 && IPW >= 1, "tile");
+  static_assert(BM % 16 == 0 && IPW >= 1 && IPW * NW * 1024 == TILE_BYTES && BM % RPI == 0, "tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -123,8 +132,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
   const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);
   const int nb = grp * BNB;                // first output column of the block
   {
-    ssc[tid] = p.scale ? p.scale[nb + tid] : 1.0f;
-    ssh[tid] = p.shift ? p.shift[nb + tid] : 0.0f;
+    if (tid < BNB) {
+      ssc[tid] = p.scale ? p.scale[nb + tid] : 1.0f;
+      ssh[tid] = p.shift ? p.shift[nb + tid] : 0.0f;
+    }
   }
   if constexpr (LN) {
     // score_c = sum_n LN(v)_n w_cn + b_c = rstd * (sum_n v_n g_n w_cn - mean * G_c) + B_c: every row quantity is a plain sum over
@@ -157,14 +168,19 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
     // (ordered before the first use by the barrier that ends the prologue)
   }
 
-  // ---- DMA geometry (loop invariant): instruction I = wave*IPW + jj fills LDS bytes [I*1024, +1024) = tile rows 2I, 2I+1.
+  // ---- DMA geometry (loop invariant): instruction I = wave*IPW + jj fills LDS bytes [I*1024, +1024) of the tile image, i.e. the
+  // 64 16-byte chunks X = I*64 + lane (row X / CPR, slot X % CPR; the slot holds source chunk slot ^ (row & 15)).
   // Source address = scalar tile base + per-lane 32-bit offset; rows past M (last tile only) re-read row M-1, never stored.
   const unsigned char* Ab = static_cast<const unsigned char*>(p.A);
-  const int drow0 = wave * IPW * 2 + (lane >> 5);                  // + 2*jj
   const uint32_t lds_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_base + wave * IPW * 1024));
+  int drow[IPW];                                                   // tile row of this lane's chunk
   uint32_t dcol[IPW];                                              // byte offset of the source chunk inside its row
 #pragma unroll
-  for (int jj = 0; jj < IPW; ++jj) dcol[jj] = (uint32_t)(((lane & 31) ^ ((drow0 + 2 * jj) & 15)) * 16);
+  for (int jj = 0; jj < IPW; ++jj) {
+    const int X = (wave * IPW + jj) * 64 + lane;
+    drow[jj] = X / CPR;
+    dcol[jj] = (uint32_t)(((X % CPR) ^ (drow[jj] & 15)) * 16);
+  }
   const uint32_t row_bytes = (uint32_t)(p.lda * 2);
   auto issue_tile = [&](int tile, int buf) {
     const int m0 = min(tile, p.ntiles - 1) * BM;                   // over-fetch tiles past the end re-read the last one
@@ -172,19 +188,19 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
     const int last = p.M - 1 - m0;                                 // last valid row of this tile (>= BM-1 except in the tail)
 #pragma unroll
     for (int jj = 0; jj < IPW; ++jj) {
-      const int row = min(drow0 + 2 * jj, last);
+      const int row = min(drow[jj], last);
       glds16(tb, (uint32_t)row * row_bytes + dcol[jj], lds_w + buf * TILE_BYTES + jj * 1024);
     }
   };
 
   // ---- weights of this wave's 64 columns -> registers (MFMA A operand: lane (r,q) holds W[n = j*16 + r][k = pn*32 + q*8 ..+7])
-  u32x4 wf[NT][8];
+  u32x4 wf[NT][KP];
   {
-    const T* Wg = static_cast<const T*>(p.W) + (int64_t)(nb + wave * 64) * 256;
+    const T* Wg = static_cast<const T*>(p.W) + (int64_t)(nb + wave * WC) * K;
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int pn = 0; pn < 8; ++pn) wf[j][pn] = *reinterpret_cast<const u32x4*>(Wg + (j * 16 + r) * 256 + pn * 32 + q * 8);
+      for (int pn = 0; pn < KP; ++pn) wf[j][pn] = *reinterpret_cast<const u32x4*>(Wg + (j * 16 + r) * K + pn * 32 + q * 8);
   }
 
   // prologue: DIST tiles in flight (tiles past the end are clamped re-reads that nobody consumes: the counts stay uniform)
@@ -193,7 +209,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
   wait_vmcnt<(DIST - 1) * IPW>();
   __syncthreads();
 
-  const int lbase = r * 512 + ((q ^ r) << 4);      // fragment read: row i*16 + r, chunk (pn*4 + q) ^ r  ==  lbase ^ (pn*64) + i*8192
+  // fragment read: row i*16 + r, chunk (pn*4 + q) ^ r  ==  byte (i*16 + r)*KB + ((pn*64) ^ ((q ^ r) << 4))
+  const int rbase = r * KB, xq = (q ^ r) << 4;
   int buf = 0;
   for (int it = 0; it < n_mine; ++it) {
     const int tile = t0 + it * tstep;
@@ -211,13 +228,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
     // else hides the LDS latency
     u32x4 af[2][MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) af[0][i] = *reinterpret_cast<const u32x4*>(As + (lbase + i * 8192));
+    for (int i = 0; i < MT; ++i) af[0][i] = *reinterpret_cast<const u32x4*>(As + (rbase + xq + i * 16 * KB));
 #pragma unroll
-    for (int pn = 0; pn < 8; ++pn) {
-      if (pn + 1 < 8) {
+    for (int pn = 0; pn < KP; ++pn) {
+      if (pn + 1 < KP) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
-          af[(pn + 1) & 1][i] = *reinterpret_cast<const u32x4*>(As + ((lbase ^ ((pn + 1) * 64)) + i * 8192));
+          af[(pn + 1) & 1][i] = *reinterpret_cast<const u32x4*>(As + (rbase + (((pn + 1) * 64) ^ xq) + i * 16 * KB));
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs (the scheduler otherwise sinks them back)
 #pragma unroll
@@ -314,8 +331,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
       constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(ssc + wave * 64 + j * 16 + q * 4);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(ssh + wave * 64 + j * 16 + q * 4);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(ssc + wave * WC + j * 16 + q * 4);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(ssh + wave * WC + j * 16 + q * 4);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           f32x4 v = acc[i][j] * sc + sh;
@@ -336,16 +353,16 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
     {
       // rows past M fall outside the descriptor and are dropped by the range check: the NST stores are unconditional
       // (all strip reads first, then the stores back to back; the vmcnt bookkeeping below counts exactly NST)
-      const int cc = lane & 7, rr0 = lane >> 3;
-      const int ncol = nb + wave * 64;         // a wave's 64 columns: inside one plane (plane_cols % 64 == 0) or two planes of 32
+      const int cc = lane % LPR, rr0 = lane / LPR;
+      const int ncol = nb + wave * WC;         // a wave's columns: inside one plane (plane_cols % 64 == 0) or two planes of 32
       u32x2 lo[NST], hi[NST];
 #pragma unroll
       for (int k = 0; k < NST; ++k) {
-        const int rr = rr0 + k * 8;
+        const int rr = rr0 + k * RPI;
         lo[k] = *reinterpret_cast<const u32x2*>(ep + rr * EP_PITCH + cc * 16);
         hi[k] = *reinterpret_cast<const u32x2*>(ep + rr * EP_PITCH + cc * 16 + 8);
       }
-      if (p.plane_cols == 32) {
+      if (WC == 64 && p.plane_cols == 32) {
         // head planes [plane][row][32]: lanes 0-3 / 4-7 of a row group write the row's 64 B of plane 2w / 2w+1, so a store
         // instruction lays down 512 contiguous bytes per plane; rows past M get an out-of-range offset (dropped)
         T* cb = static_cast<T*>(p.C) + (int64_t)(ncol >> 5) * p.plane_stride + (int64_t)m0 * 32;
@@ -353,16 +370,28 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
         const uint32_t pofs = (uint32_t)((cc >> 2) * p.plane_stride * 2 + (cc & 3) * 16);
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
-          const int rr = rr0 + k * 8;
+          const int rr = rr0 + k * RPI;
           const uint32_t vo = m0 + rr < p.M ? pofs + (uint32_t)rr * 64u : 0x80000000u;
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[k].x, lo[k].y, hi[k].x, hi[k].y}, rsC, vo, 0, 0);
+        }
+      } else if (p.c_rpb) {
+        // output row remap (level-major token scatter of input_proj, head.py:1023-1028): the row offset is per lane, rows past
+        // M get an out-of-range offset; the host guarantees that the whole C buffer is addressable with 31 bits
+        const auto rsC = __builtin_amdgcn_make_buffer_rsrc(static_cast<T*>(p.C) + ncol, 0, 0x7fffffffu, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+          const int m = m0 + rr0 + k * RPI;
+          const int bq = (int)fdiv((uint32_t)m, p.fd_rpb);
+          const uint32_t mo = (uint32_t)(bq * p.c_bstride + (m - bq * p.c_rpb));
+          const uint32_t vo = m < p.M ? (mo * (uint32_t)p.ldc + cc * 8) * 2u : 0x80000000u;
           __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[k].x, lo[k].y, hi[k].x, hi[k].y}, rsC, vo, 0, 0);
         }
       } else {
         const int pl = p.plane_cols ? ncol / p.plane_cols : 0;
         T* cb = static_cast<T*>(p.C) + (int64_t)pl * p.plane_stride + (int64_t)m0 * p.ldc + (ncol - pl * p.plane_cols);
-        const int64_t left = ((int64_t)(p.M - 1 - m0) * p.ldc + 64) * 2;
+        const int64_t left = ((int64_t)(p.M - 1 - m0) * p.ldc + WC) * 2;
         const auto rsC = __builtin_amdgcn_make_buffer_rsrc(cb, 0, (uint32_t)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
-        const uint32_t voff0 = (uint32_t)(rr0 * (int)p.ldc + cc * 8) * 2, vstep = (uint32_t)p.ldc * 16;
+        const uint32_t voff0 = (uint32_t)(rr0 * (int)p.ldc + cc * 8) * 2, vstep = (uint32_t)p.ldc * 2 * RPI;
 #pragma unroll
         for (int k = 0; k < NST; ++k)
           __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[k].x, lo[k].y, hi[k].x, hi[k].y}, rsC, voff0 + k * vstep, 0, 0);
@@ -388,10 +417,10 @@ static int wreg_num_cus() {
   return n;
 }
 
-template <typename T, int BM, int NBUF, int OCC, bool LN = false, int NW = 4>
+template <typename T, int BM, int NBUF, int OCC, bool LN = false, int NW = 4, int WC = 64, int K = 256>
 static int launch_wreg(WregParams& p, hipStream_t st) {
-  const int lds = wreg_lds_bytes<BM, NBUF, LN, NW>() + (LN && p.a_mask ? ((p.mask_period + 31) / 32) * 4 : 0);
-  auto kern = gemm_wreg_kernel<T, BM, NBUF, OCC, LN, NW>;
+  const int lds = wreg_lds_bytes<BM, NBUF, LN, NW, WC, K>() + (LN && p.a_mask ? ((p.mask_period + 31) / 32) * 4 : 0);
+  auto kern = gemm_wreg_kernel<T, BM, NBUF, OCC, LN, NW, WC, K>;
   static int attr_lds = 0;
   if (lds > 65536 && lds > attr_lds) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -400,11 +429,23 @@ static int launch_wreg(WregParams& p, hipStream_t st) {
   }
   const int slots = wreg_num_cus() / 8 * OCC;          // resident blocks per XCD
   p.ntiles = (p.M + BM - 1) / BM;
-  p.ngroups = p.N / (NW * 64);
+  p.ngroups = p.N / (NW * WC);
   p.lanes = slots / p.ngroups;
   if (p.lanes < 1) return MOY_ENOSYS;
   hipLaunchKernelGGL(kern, dim3(8 * p.lanes * p.ngroups), dim3(64 * NW), lds, st, p);
   return launch_status();
+}
+
+// 8 waves x 32 columns = 256 columns per block, any K in {128, 256, 384, 512}: the 1x1 convs / input_proj with 256 outputs
+template <typename T>
+static int launch_wreg_k(WregParams& p, int K, hipStream_t st) {
+  switch (K) {
+    case 128: return launch_wreg<T, 32, 3, 1, false, 8, 32, 128>(p, st);
+    case 256: return launch_wreg<T, 32, 3, 1, false, 8, 32, 256>(p, st);
+    case 384: return launch_wreg<T, 32, 3, 1, false, 8, 32, 384>(p, st);
+    case 512: return launch_wreg<T, 32, 3, 1, false, 8, 32, 512>(p, st);
+    default: return MOY_ENOSYS;
+  }
 }
 
 // Eligibility + dispatch; MOY_ENOSYS = not this kernel's shape (moy_gemm falls through to the tiled kernel).
@@ -413,16 +454,25 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   if (mode < 0) { const char* e = getenv("MOY_GEMM_WREG"); mode = e ? atoi(e) : 1; }
   if (!mode) return MOY_ENOSYS;
   if (a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_ENOSYS;
-  if (a->ksize != 1 || a->K != 256 || a->N % 256 || a->N / 256 > 16) return MOY_ENOSYS;
-  if (a->A2 || a->a_rows || a->R || a->out_f32 || a->c_rows_per_batch || a->pre) return MOY_ENOSYS;
+  if (a->ksize != 1 || a->N % 256 || a->N / 256 > 16) return MOY_ENOSYS;
+  if (a->K != 128 && a->K != 256 && a->K != 384 && a->K != 512) return MOY_ENOSYS;
+  if (a->A2 || a->a_rows || a->R || a->out_f32 || a->pre) return MOY_ENOSYS;
   // score mode: LayerNorm + narrow head with NO feature output (C == NULL; moy_gemm documents it); the normalised rows
   // themselves are the tiled kernel's job
   const bool score = a->ln_g && !a->C;
   if (score) {
-    if (a->N != 256 || a->dot_n < 1 || a->dot_n > WREG_MAXDOT || a->act != MOY_ACT_NONE) return MOY_ENOSYS;
+    if (a->K != 256 || a->N != 256 || a->dot_n < 1 || a->dot_n > WREG_MAXDOT || a->act != MOY_ACT_NONE || a->c_rows_per_batch) return MOY_ENOSYS;
     if (a->a_mask && (a->mask_period < 64 || a->mask_period > 262144)) return MOY_ENOSYS;
   } else if (a->ln_g || a->a_mask || a->dot_n || !a->C) {
     return MOY_ENOSYS;
+  }
+  static int kgen = -1;                    // MOY_WREG_KGEN=0: only the K = 256 forms (A/B runs)
+  if (kgen < 0) { const char* e = getenv("MOY_WREG_KGEN"); kgen = e ? atoi(e) : 1; }
+  const bool general = a->K != 256 || a->c_rows_per_batch;       // the 8 x 32-column form
+  if (general && (!kgen || a->plane_cols)) return MOY_ENOSYS;
+  if (a->c_rows_per_batch) {               // per-lane 32-bit byte offsets into the remapped C
+    const int64_t rows = ((int64_t)a->M / a->c_rows_per_batch + 1) * a->c_batch_stride;
+    if (rows * a->ldc * 2 > 0x7fffffffLL) return MOY_ENOSYS;
   }
   if (a->M < 65536) return MOY_ENOSYS;     // persistent row-tile walk: needs many tiles per block
   if ((a->lda % 8) || !aligned16(a->A) || !aligned16(a->W)) return MOY_ENOSYS;
@@ -433,6 +483,8 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   p.A = a->A; p.lda = a->lda; p.W = a->W; p.scale = a->scale; p.shift = a->shift; p.act = a->act;
   p.C = a->C; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.ngroups = a->N / 256;
   p.plane_cols = a->plane_cols; p.plane_stride = a->plane_stride;
+  p.c_rpb = a->c_rows_per_batch; p.c_bstride = a->c_batch_stride; p.fd_rpb = make_fastdiv(p.c_rpb > 0 ? p.c_rpb : 1);
+  if (general) return a->dtype == MOY_BF16 ? launch_wreg_k<bf16_t>(p, a->K, st) : launch_wreg_k<f16_t>(p, a->K, st);
   if (score) {
     p.ln_g = a->ln_g; p.ln_b = a->ln_b; p.dot_w = a->dot_w; p.dot_b = a->dot_b; p.dot_out = a->dot_out; p.dot_n = a->dot_n;
     p.a_mask = a->a_mask; p.mask_period = a->mask_period; p.fd_mask = make_fastdiv(a->mask_period > 0 ? a->mask_period : 1);

@@ -101,6 +101,49 @@ def test_gemm_weight_stationary_kernel_bit_identical_to_tiled(dt, M, N, act):
     assert torch.allclose(out[:M, :N].float().cpu(), ref, atol=tol(dt), rtol=tol(dt, 1e-5, 1e-2))
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("K,N,act,rpb", [(128, 256, "silu", 0), (384, 256, "silu", 0), (512, 512, "none", 0), (128, 256, "none", 2584),
+                                          (256, 256, "none", 646)])
+def test_gemm_weight_stationary_general_k_and_row_remap(dt, K, N, act, rpb):
+    """The 8-wave x 32-column form of the weight-stationary kernel (K in {128, 256, 384, 512}, N % 256 == 0, M >= 65536; 1x1 convs
+    with 256 outputs and input_proj with its level-major token scatter, head.py:1023-1028): bit-identical to the tiled kernel
+    (two launches of < 65536 rows), ragged last tile, guard rows / columns untouched."""
+    nb = 27 if rpb else 0
+    M = nb * rpb if rpb else 66000 + 37
+    x, w = q(rnd(M, K, seed=41), dt), q(rnd(N, K, seed=42, scale=1 / math.sqrt(K)), dt)
+    b = rnd(N, seed=43, scale=0.1)
+    sc = (rnd(N, seed=44) * 0.2 + 1.0) if act == "silu" else None
+    xd, wd = x.to(DEV, dt), ops.pad_weight(w.to(DEV), dt)
+    kw = dict(shift=b.to(DEV), scale=sc.to(DEV) if sc is not None else None, act=L.ACT_SILU if act == "silu" else L.ACT_NONE)
+    if rpb:
+        bstride = rpb + 500                                           # rows of other levels in between
+        out = torch.full((nb * bstride + 1, N + 32), 7.0, device=DEV, dtype=dt)
+        ops.gemm(xd, wd, N, K, out=out[:nb * bstride, :N], c_rpb=rpb, c_bstride=bstride, **kw)
+        two = torch.full((nb * bstride, N), 7.0, device=DEV, dtype=dt)
+        h = (nb // 2) * rpb
+        ops.gemm(xd[:h], wd, N, K, out=two[:(nb // 2) * bstride], c_rpb=rpb, c_bstride=bstride, **kw)
+        ops.gemm(xd[h:], wd, N, K, out=two[(nb // 2) * bstride:], c_rpb=rpb, c_bstride=bstride, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(out[:nb * bstride, :N], two)
+        got = out[:nb * bstride, :N].view(nb, bstride, N)
+        assert bool((got[:, rpb:] == 7.0).all()) and bool((out[-1] == 7.0).all()) and bool((out[:, N:] == 7.0).all())
+        got = got[:, :rpb].reshape(M, N)
+    else:
+        out = torch.full((M + 1, N + 32), 7.0, device=DEV, dtype=dt)
+        ops.gemm(xd, wd, N, K, out=out[:M, :N], **kw)
+        h = M // 2
+        two = torch.empty(M, N, device=DEV, dtype=dt)
+        ops.gemm(xd[:h], wd, N, K, out=two[:h], **kw)
+        ops.gemm(xd[h:], wd, N, K, out=two[h:], **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(out[:M, :N], two), "weight-stationary kernel differs from the tiled kernel"
+        assert bool((out[M] == 7.0).all()) and bool((out[:, N:] == 7.0).all()), "wrote outside its rows / columns"
+        got = out[:M, :N]
+    ref = x @ w.T
+    ref = F.silu(ref * sc + b) if act == "silu" else ref + b
+    assert torch.allclose(got.float().cpu(), ref, atol=tol(dt), rtol=tol(dt, 1e-5, 1e-2))
+
+
 @pytest.mark.parametrize("dt,M,nc", [(torch.bfloat16, 70001, 1), (torch.float16, 66000, 3), (torch.float32, 700, 2),
                                      (torch.bfloat16, 1000, 5)])
 def test_gemm_score_only_layernorm_head(dt, M, nc):
