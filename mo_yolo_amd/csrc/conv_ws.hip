@@ -1,0 +1,438 @@
+// Weight-stationary direct 3x3 convolution (stride 1, pad 1, Cin == Cout in {32, 64, 128}) + BN + SiLU (+ residual) for 16-bit
+// types: the Bottleneck convs of the C2f blocks (ultralytics/nn/modules/block.py:271-283 over conv.py:36-38).
+//
+// Why a third convolution kernel.  The tile-per-block direct kernel (gemm.hip: conv3x3_direct_kernel) re-stages the weight taps
+// through LDS for every 128-256 output pixels (one barrier per tap), loads its halo patch with nothing else in flight and ran at
+// 0.25-0.4 of its floor (profiles/r01_*).  Here a block lives for the whole launch (one per CU, 8 waves):
+//   * the weights never touch LDS: wave (wn, wm) keeps W[its 16*NTw output channels][9 taps][C] in REGISTERS as MFMA A-operand
+//     fragments (C = 128: 144 VGPRs, C = 64: 72, C = 32: 36) -- no weight traffic and no barrier inside a tile;
+//   * halo patches ((TH+2) x 18 pixels x C) and, for the shortcut, the residual tile arrive by LDS-DMA
+//     (`buffer_load_dwordx4 ... lds`: no VGPRs, no ds_write) into a ring of NBUF buffer sets, DIST = NBUF-1 tiles ahead of the
+//     MFMAs, retired by a counted vmcnt that leaves the younger pieces and the output stores in flight.  Pixels outside the image
+//     are out-of-range buffer offsets: the DMA writes zeros (= the conv's zero padding; probed: tools/probes/ldsdma_oob.hip);
+//   * the LDS image of a patch pixel is its C/8 16-byte chunks with the chunk index XORed by a function of the pixel (the
+//     conflict-free maps of gemm.hip); the DMA destination is lane-linear, so the XOR is applied to the per-lane SOURCE address;
+//   * a fragment row (16 pixels x 32 channels) read for tap column kx serves the three tap rows ky of up to three output rows:
+//     (MT+2) ds_read_b128 per 3*MT MFMAs instead of one read per MFMA;
+//   * epilogue: BN + SiLU on the accumulators -> tile in the output type in LDS (for the shortcut: added in place to the
+//     DMA'd residual tile, one rounding) -> whole-line 16-byte stores through a per-image descriptor (pixels past the image edge
+//     are out-of-range offsets, so the store count per wave is constant and the vmcnt bookkeeping exact);
+//   * tiles are dealt so that the blocks of one XCD work on 32 consecutive tiles at a time: halo pixels shared by neighbouring
+//     tiles are served by that XCD's L2.
+#include "common.hpp"
+
+#include <type_traits>
+
+namespace moy {
+
+struct ConvWsParams {
+  const void* A; int64_t lda;
+  const void* W; int Kpad;
+  const float* scale; const float* shift;
+  const void* R; int64_t ldr;
+  void* C; int64_t ldc;
+  int H, Wd;                        // image size (stride 1: input == output)
+  int tiles_x, tiles_img, ntiles;
+  int per_xcd, bpx;                 // tiles per XCD chunk, blocks per XCD
+  FastDiv fd_timg, fd_tx;
+};
+
+template <int C>
+__device__ __forceinline__ int cws_swz(int pix) {   // same maps as conv_swz in gemm.hip
+  return C == 32 ? ((pix >> 1) & 3) : (C == 64 ? (pix & 7) : ((pix & 7) << 1));
+}
+
+// LDS-DMA of 16 bytes per lane: LDS[lds_dst + lane*16 ..] <- buffer[voff] (zeros when voff fails the range check).
+__device__ __forceinline__ void cws_dma16(uint32_t voff, __amdgpu_buffer_rsrc_t rs, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(lds_dst), "s"(rs)
+               : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void cws_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T>
+__device__ __forceinline__ f32x4 cws_mfma(f32x4 acc, u32x4 w, u32x4 a);
+template <>
+__device__ __forceinline__ f32x4 cws_mfma<bf16_t>(f32x4 acc, u32x4 w, u32x4 a) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4 cws_mfma<f16_t>(f32x4 acc, u32x4 w, u32x4 a) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
+}
+
+template <int C, int N, int TH, int NBUF, bool RES>
+struct CwsGeom {
+  static constexpr int PH = TH + 2, PW = 18, NPIX = PH * PW;
+  static constexpr int CPP = C / 8, NCP = N / 8;            // 16-byte chunks per input / output pixel
+  static constexpr int PATCH_PIECES = (NPIX * CPP + 63) / 64;
+  static constexpr int TPX = TH * 16;
+  static constexpr int RES_PIECES = RES ? TPX * NCP / 64 : 0;
+  static constexpr int PIECES = PATCH_PIECES + RES_PIECES;
+  static constexpr int IPW = (PIECES + 7) / 8;              // DMA instructions per wave and tile (dummies pad the last round)
+  static constexpr int SETB = PIECES * 1024;
+  static constexpr int STGB = TPX * N * 2;
+  static constexpr int LDS = NBUF * SETB + (RES ? 0 : STGB) + 1024;
+  static constexpr int NPASS = TPX * NCP / 512;             // 16-byte stores per thread and tile
+};
+
+template <typename T, int C, int N, int TH, int WN, int NBUF, bool RES, int OCC, bool SPREAD, int ABL = 0>   // ABL: timing-only ablation builds (tools/bench_gemm.py)
+__global__ __launch_bounds__(512, 2 * OCC) void conv_ws_kernel(const ConvWsParams p) {
+  using G = CwsGeom<C, N, TH, NBUF, RES>;
+  constexpr int PW = G::PW, CPP = G::CPP, NCP = G::NCP, IPW = G::IPW, NPASS = G::NPASS;
+  constexpr int WM = 8 / WN, MT = TH / WM, NT = N / 16 / WN, KC = C / 32;
+  constexpr int DIST = NBUF - 1;
+  constexpr int RG = MT < 4 ? MT : 4;      // output rows per fragment-row group
+  constexpr uint32_t OOB = 0x80000000u;
+  static_assert(TH % WM == 0 && (N / 16) % WN == 0 && G::TPX * NCP % 512 == 0, "tile vs waves");
+  static_assert(sizeof(T) == 2, "16-bit types");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int wn = wave % WN, wm = wave / WN;
+
+  // ---- this block's tiles: XCD x owns the tile range [x * per_xcd, (x + 1) * per_xcd); its blocks take consecutive tiles
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int t_first = xcd * p.per_xcd + slot;
+  const int t_limit = min((xcd + 1) * p.per_xcd, p.ntiles);
+  if (t_first >= t_limit) return;
+  const int n_mine = (t_limit - t_first + p.bpx - 1) / p.bpx;
+
+  const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+  const uint32_t scratch = lds_base + NBUF * G::SETB + (RES ? 0 : G::STGB);
+
+  // ---- DMA geometry: piece pc = wave + 8k fills LDS bytes [pc*1024, +1024) of a buffer set.
+  // Patch pieces: chunk X = pc*64 + lane -> patch pixel X / CPP, LDS slot X % CPP <- source chunk slot ^ swz(pixel).
+  // Residual pieces: chunk X -> output pixel X / NCP of the tile, slot X % NCP <- source chunk slot ^ (pixel & (NCP-1)).
+  // Recomputed per tile (a dozen VALU operations per piece in the shadow of the MFMAs) instead of held in 2*IPW registers.
+  auto piece_geom = [&](int pc, int& dy, int& dx, int& rel) {   // offsets relative to the tile origin; dy = -4096: never valid
+    dy = -4096; dx = 0; rel = 0;
+    int lv = lane;
+    asm volatile("" : "+v"(lv));   // opaque: keeps the per-piece geometry out of loop-invariant registers
+    if (pc < G::PATCH_PIECES) {
+      const int X = pc * 64 + lv, pix = X / CPP, sl = X % CPP;
+      const int py = pix / PW, px = pix - py * PW;
+      if (pix < G::NPIX) dy = py - 1;
+      dx = px - 1;
+      rel = ((dy * p.Wd + dx) * (int)p.lda + ((sl ^ cws_swz<C>(pix)) * 8)) * 2;
+    } else if (RES && pc < G::PIECES) {
+      const int X = (pc - G::PATCH_PIECES) * 64 + lv, opx = X / NCP, sl = X % NCP;
+      dy = opx >> 4; dx = opx & 15;
+      rel = ((dy * p.Wd + dx) * (int)p.ldr + ((sl ^ (opx & (NCP - 1))) * 8)) * 2;
+    }
+  };
+
+  const T* __restrict__ Ag = static_cast<const T*>(p.A);
+  const T* __restrict__ Rg = static_cast<const T*>(p.R);
+  T* __restrict__ Cg = static_cast<T*>(p.C);
+  const int64_t img_a = (int64_t)p.H * p.Wd * p.lda, img_r = (int64_t)p.H * p.Wd * p.ldr, img_c = (int64_t)p.H * p.Wd * p.ldc;
+
+  auto tile_coords = [&](int t, int& b, int& y0, int& x0) {
+    b = (int)fdiv((uint32_t)t, p.fd_timg);
+    const int rem = t - b * p.tiles_img;
+    const int ty = (int)fdiv((uint32_t)rem, p.fd_tx);
+    y0 = ty * TH;
+    x0 = (rem - ty * p.tiles_x) * 16;
+  };
+
+  // DMA of one tile = scalar set-up (descriptors, tile origin) + IPW independent pieces, so the pieces can be issued all at
+  // once (prologue) or one by one between the MFMA groups of the tile being computed (SPREAD).
+  struct TileDma {
+    __amdgpu_buffer_rsrc_t rsA, rsR;
+    int y0, x0, off_a, off_r;
+    uint32_t dst;
+    bool live;
+  };
+  auto tile_setup = [&](int it, int set) {
+    TileDma d;
+    d.live = it < n_mine;                                       // tiles past the end: every lane out of range (uniform counts)
+    int b;
+    tile_coords(min(t_first + it * p.bpx, p.ntiles - 1), b, d.y0, d.x0);
+    d.rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Ag + (int64_t)b * img_a), 0, (uint32_t)(img_a * 2), 0x00020000);
+    d.rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>((RES ? Rg : Ag) + (int64_t)b * (RES ? img_r : img_a)), 0,
+                                              (uint32_t)((RES ? img_r : img_a) * 2), 0x00020000);
+    const int org = d.y0 * p.Wd + d.x0;
+    d.off_a = org * (int)p.lda * 2;
+    d.off_r = org * (int)p.ldr * 2;
+    d.dst = lds_base + set * G::SETB;
+    return d;
+  };
+  auto issue_piece = [&](const TileDma& d, int k) {
+    const int pc = wave + 8 * k;                                // wave-uniform
+    const bool is_res = RES && pc >= G::PATCH_PIECES;
+    int dy, dx, rel;
+    piece_geom(pc, dy, dx, rel);
+    const int yy = d.y0 + dy, xx = d.x0 + dx;
+    const bool ok = d.live && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.Wd;
+    const uint32_t voff = ok ? (uint32_t)((is_res ? d.off_r : d.off_a) + rel) : OOB;
+    const uint32_t dst = pc < G::PIECES ? d.dst + pc * 1024 : scratch;
+    if (ABL == 2) return;
+    if (is_res) cws_dma16(voff, d.rsR, dst);
+    else cws_dma16(voff, d.rsA, dst);
+  };
+  auto issue_tile = [&](int it, int set) {
+    const TileDma d = tile_setup(it, set);
+#pragma unroll
+    for (int k = 0; k < IPW; ++k) issue_piece(d, k);
+  };
+
+  // ---- weights of this wave -> registers (MFMA A operand: lane (r, q) holds W[n = .. + r][k = tap*C + cc*32 + q*8 .. +7])
+  u32x4 wf[NT][9][KC];
+  f32x4 sc[NT], sh[NT];
+  {
+    const T* Wg = static_cast<const T*>(p.W);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = (wn * NT + j) * 16;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int cc = 0; cc < KC; ++cc)
+          wf[j][tap][cc] = *reinterpret_cast<const u32x4*>(Wg + (int64_t)(n + r) * p.Kpad + tap * C + cc * 32 + q * 8);
+      sc[j] = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n + q * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+      sh[j] = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
+  // ---- store-pass geometry of this thread: chunk X = k*512 + tid of the [pixel][N] tile image (pass k advances 512/NCP pixels,
+  // a multiple of 16: the tile column and the swizzle term stay, the tile row advances by 32/NCP)
+  const int s_px = tid / NCP, s_c = tid % NCP;
+  const int s_ty = s_px >> 4, s_tx = s_px & 15;
+  const int s_lds = s_px * (N * 2) + ((s_c ^ (s_px & (NCP - 1))) * 16);
+  const int s_rel = ((s_ty * p.Wd + s_tx) * (int)p.ldc + s_c * 8) * 2;
+  constexpr int PASS_ROWS = 512 / NCP / 16, PASS_LDS = (512 / NCP) * N * 2;
+  const int s_pass_rel = PASS_ROWS * p.Wd * (int)p.ldc * 2;
+
+  // prologue: DIST tiles in flight
+#pragma unroll
+  for (int d = 0; d < DIST; ++d) issue_tile(d, d);
+  cws_wait_vmcnt<(DIST - 1) * IPW>();
+  __syncthreads();
+
+  const int pix0 = wm * MT * PW + r;      // patch pixel of this lane for output row 0 of the wave, tap column 0
+  int set = 0;
+  // ABL == 5: diagnostic build, s_memtime stamps at the phase boundaries of wave 0 (sums over the block's tiles go to the start
+  // of the output tensor of block 0: the build's outputs are garbage by design)
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+  auto stamp = [&](int i) {
+    if constexpr (ABL == 5) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      ph[i] += t - tprev;
+      tprev = t;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if constexpr (ABL == 5) tprev = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < n_mine; ++it) {
+    int nset = set + DIST; if (nset >= NBUF) nset -= NBUF;
+    const TileDma nd = tile_setup(it + DIST, nset);
+    if constexpr (!SPREAD) {
+#pragma unroll
+      for (int k = 0; k < IPW; ++k) issue_piece(nd, k);
+    }
+    stamp(0);                              // loop top: tile set-up + DMA issue (unless SPREAD)
+    const unsigned char* patch = smem + set * G::SETB;
+    int pixv = pix0;
+    asm volatile("" : "+v"(pixv));       // opaque per tile: the 3*(MT+2)*KC fragment addresses are formed where they are used, not hoisted into registers
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // output rows in groups of RG: RG + 2 fragment rows are live at a time
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+      for (int cc = 0; cc < KC; ++cc) {
+#pragma unroll
+        for (int g = 0; g < MT / RG; ++g) {
+          if constexpr (SPREAD) {          // the next tile's pieces, spread over the NG MFMA groups of this tile
+            constexpr int NG = 3 * KC * (MT / RG);
+            const int gi = (kx * KC + cc) * (MT / RG) + g;
+#pragma unroll
+            for (int k = 0; k < IPW; ++k)
+              if (k * NG / IPW == gi) issue_piece(nd, k);
+          }
+          if (ABL == 3 && (kx | cc)) continue;
+          u32x4 a[RG + 2];
+#pragma unroll
+          for (int y = 0; y < RG + 2; ++y) {
+            const int pix = pixv + (g * RG + y) * PW + kx;
+            a[y] = *reinterpret_cast<const u32x4*>(patch + pix * (C * 2) + (((cc * 4 + q) ^ cws_swz<C>(pix)) * 16));
+          }
+#pragma unroll
+          for (int y = 0; y < RG; ++y)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+              for (int j = 0; j < NT; ++j)
+                acc[g * RG + y][j] = cws_mfma<T>(acc[g * RG + y][j], wf[j][ky * 3 + kx][cc], a[y + ky]);
+        }
+      }
+    }
+
+    stamp(1);                              // MFMA main loop
+    // ---- epilogue: BN + SiLU (+ residual, in place) -> tile image [pixel][N] in the output type
+    unsigned char* stg = RES ? smem + set * G::SETB + G::PATCH_PIECES * 1024 : smem + NBUF * G::SETB;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int ch = (wn * NT + j) * 16 + q * 4;
+#pragma unroll
+      for (int y = 0; y < MT; ++y) {
+        f32x4 v = acc[y][j] * sc[j] + sh[j];
+        if (ABL != 1) { v.x = siluf_(v.x); v.y = siluf_(v.y); v.z = siluf_(v.z); v.w = siluf_(v.w); }
+        const int opx = (wm * MT + y) * 16 + r;
+        unsigned char* cell = stg + opx * (N * 2) + ((((ch >> 3) ^ (opx & (NCP - 1))) * 16) + ((ch >> 2) & 1) * 8);
+        if (RES) {
+          const u32x2 res = *reinterpret_cast<const u32x2*>(cell);
+          v += f32x4{DT<T>::lo(res.x), DT<T>::hi(res.x), DT<T>::lo(res.y), DT<T>::hi(res.y)};
+        }
+        *reinterpret_cast<u32x2*>(cell) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+      }
+    }
+    stamp(2);                              // BN + SiLU + staging writes
+    __syncthreads();
+    stamp(3);                              // barrier
+    {
+      int b, y0, x0;
+      tile_coords(t_first + it * p.bpx, b, y0, x0);
+      const auto rsC = __builtin_amdgcn_make_buffer_rsrc(Cg + (int64_t)b * img_c, 0, (uint32_t)(img_c * 2), 0x00020000);
+      const int off_c = (y0 * p.Wd + x0) * (int)p.ldc * 2 + s_rel;
+      const bool xok = x0 + s_tx < p.Wd;
+      u32x4 vv[NPASS];
+#pragma unroll
+      for (int k = 0; k < NPASS; ++k) vv[k] = *reinterpret_cast<const u32x4*>(stg + s_lds + k * PASS_LDS);
+#pragma unroll
+      for (int k = 0; k < NPASS; ++k) {
+        const bool ok = ABL != 4 && xok && y0 + s_ty + k * PASS_ROWS < p.H;
+        __builtin_amdgcn_raw_buffer_store_b128(vv[k], rsC, ok ? (uint32_t)(off_c + k * s_pass_rel) : OOB, 0, 0);
+      }
+    }
+    // tile it+1 must have landed; the younger DMA pieces and the stores issued since stay in flight
+    stamp(4);                              // store pass
+    cws_wait_vmcnt<(DIST - 1) * (IPW + NPASS) + NPASS>();
+    stamp(5);                              // wait for the next tile's pieces
+    __syncthreads();
+    stamp(6);                              // barrier
+    if (++set == NBUF) set = 0;
+  }
+  if constexpr (ABL == 5) {
+    if (blockIdx.x == 0 && tid == 0) {
+      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.C);
+      for (int i = 0; i < 7; ++i) dbg[i] = ph[i];
+      dbg[7] = (unsigned long long)n_mine;
+    }
+  }
+  cws_wait_vmcnt<0>();   // over-fetch pieces still target this block's LDS
+}
+
+static int cws_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+template <typename T, int C, int N, int TH, int WN, int NBUF, bool RES, int OCC = 1, bool SPREAD = false, int ABL = 0>
+static int launch_conv_ws(ConvWsParams& p, int B, hipStream_t st) {
+  using G = CwsGeom<C, N, TH, NBUF, RES>;
+  static_assert(G::LDS * OCC <= 160 * 1024, "LDS budget");
+  if constexpr (ABL == 0 && std::is_same<T, bf16_t>::value && !RES) {
+    static int abl = -1;                   // MOY_CWS_ABL=1..4: timing-only builds (no SiLU / no DMA / one MFMA group / no stores)
+    if (abl < 0) { const char* e = getenv("MOY_CWS_ABL"); abl = e ? atoi(e) : 0; }
+    if (abl == 1) return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 1>(p, B, st);
+    if (abl == 2) return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 2>(p, B, st);
+    if (abl == 3) return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 3>(p, B, st);
+    if (abl == 4) return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 4>(p, B, st);
+    if (abl == 5) return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 5>(p, B, st);
+  }
+  auto kern = conv_ws_kernel<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, ABL>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (G::LDS > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess)
+      return MOY_ELAUNCH;
+    attr_set = true;
+  }
+  p.tiles_x = (p.Wd + 15) / 16;
+  const int tiles_y = (p.H + TH - 1) / TH;
+  p.tiles_img = p.tiles_x * tiles_y;
+  p.ntiles = B * p.tiles_img;
+  p.fd_timg = make_fastdiv((uint32_t)p.tiles_img);
+  p.fd_tx = make_fastdiv((uint32_t)p.tiles_x);
+  p.per_xcd = (p.ntiles + 7) / 8;
+  p.bpx = cws_num_cus() / 8 * OCC;         // resident blocks per XCD
+  if (p.bpx < 1) p.bpx = 1;
+  if (p.bpx > p.per_xcd) p.bpx = p.per_xcd;
+  hipLaunchKernelGGL(kern, dim3(8 * p.bpx), dim3(512), G::LDS, st, p);
+  return launch_status();
+}
+
+static int cws_variant() {                 // MOY_CWS_VARIANT: A/B knob (bit 0: spread the DMA pieces, bit 1: C = 32 with two blocks per CU)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MOY_CWS_VARIANT"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
+template <typename T>
+static int conv_ws_dispatch(ConvWsParams& p, int B, int C, bool res, hipStream_t st) {
+  const int v = cws_variant();
+  const bool sp = v & 1, occ2 = v & 2;
+  if (C == 32) {
+    if (occ2) return res ? launch_conv_ws<T, 32, 32, 16, 2, 2, true, 2>(p, B, st) : launch_conv_ws<T, 32, 32, 16, 2, 2, false, 2>(p, B, st);
+    if (sp) return res ? launch_conv_ws<T, 32, 32, 16, 2, 3, true, 1, true>(p, B, st) : launch_conv_ws<T, 32, 32, 16, 2, 3, false, 1, true>(p, B, st);
+    return res ? launch_conv_ws<T, 32, 32, 16, 2, 3, true>(p, B, st) : launch_conv_ws<T, 32, 32, 16, 2, 3, false>(p, B, st);
+  }
+  if (C == 64) {
+    if (sp) return res ? launch_conv_ws<T, 64, 64, 16, 4, 2, true, 1, true>(p, B, st) : launch_conv_ws<T, 64, 64, 16, 4, 3, false, 1, true>(p, B, st);
+    return res ? launch_conv_ws<T, 64, 64, 16, 4, 2, true>(p, B, st) : launch_conv_ws<T, 64, 64, 16, 4, 3, false>(p, B, st);
+  }
+  if (C == 128) {
+    if (sp) return res ? launch_conv_ws<T, 128, 128, 8, 8, 2, true, 1, true>(p, B, st) : launch_conv_ws<T, 128, 128, 8, 8, 2, false, 1, true>(p, B, st);
+    return res ? launch_conv_ws<T, 128, 128, 8, 8, 2, true>(p, B, st) : launch_conv_ws<T, 128, 128, 8, 8, 2, false>(p, B, st);
+  }
+  return MOY_ENOSYS;
+}
+
+// Eligibility + dispatch; MOY_ENOSYS = not this kernel's shape (moy_gemm falls through to the other convolution paths).
+int conv_ws_try(const moy_gemm_args* a, hipStream_t st) {
+  static int mode = -1;                    // MOY_CONV_WS: 0 = off, 1 = on for launches with enough tiles (default), 2 = whenever the shape fits
+  if (mode < 0) { const char* e = getenv("MOY_CONV_WS"); mode = e ? atoi(e) : 1; }
+  if (!mode) return MOY_ENOSYS;
+  if (a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_ENOSYS;
+  if (a->ksize != 3 || a->stride != 1 || a->act != MOY_ACT_SILU) return MOY_ENOSYS;
+  const int C = a->Cin;
+  if ((C != 32 && C != 64 && C != 128) || a->N != C || a->K != 9 * C) return MOY_ENOSYS;
+  if (a->ln_g || a->out_f32 || a->c_rows_per_batch || a->pre || a->plane_cols || a->dot_n || !a->C) return MOY_ENOSYS;
+  if ((a->lda % 8) || (a->ldc % 8) || !aligned16(a->A) || !aligned16(a->C) || !aligned16(a->W)) return MOY_ENOSYS;
+  if (a->R && ((a->ldr % 8) || !aligned16(a->R))) return MOY_ENOSYS;
+  if ((a->scale && !aligned16(a->scale)) || (a->shift && !aligned16(a->shift))) return MOY_ENOSYS;
+  const int64_t ldmax = a->lda > a->ldc ? (a->lda > a->ldr ? a->lda : a->ldr) : (a->ldc > a->ldr ? a->ldc : a->ldr);
+  if ((int64_t)a->Hin * a->Win * ldmax * 2 > 0x3fffffffLL) return MOY_ENOSYS;   // per-image descriptors, 32-bit lane offsets
+  const int TH = C == 128 ? 8 : 16;
+  const long tiles = (long)a->B * ((a->Hin + TH - 1) / TH) * ((a->Win + 15) / 16);
+  const double util = (double)a->Hin * a->Win * a->B / (double)(tiles * TH * 16);
+  if (mode == 1 && (tiles < 2 * cws_num_cus() || util < 0.7)) return MOY_ENOSYS;
+  ConvWsParams p{};
+  p.A = a->A; p.lda = a->lda; p.W = a->W;
+  p.Kpad = (a->K + 63) / 64 * 64;
+  p.scale = a->scale; p.shift = a->shift; p.R = a->R; p.ldr = a->R ? a->ldr : 0; p.C = a->C; p.ldc = a->ldc;
+  p.H = a->Hin; p.Wd = a->Win;
+  return a->dtype == MOY_BF16 ? conv_ws_dispatch<bf16_t>(p, a->B, C, a->R != nullptr, st)
+                              : conv_ws_dispatch<f16_t>(p, a->B, C, a->R != nullptr, st);
+}
+
+}  // namespace moy

@@ -250,6 +250,33 @@ def test_gemm_conv3x3(dt, B, H, W, Cin, Cout, s):
     assert torch.allclose(got, ref, atol=tol(dt, 2e-5, 3e-2), rtol=1e-5)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,B,H,W", [(32, 8, 120, 136), (64, 8, 120, 136), (128, 8, 60, 136)])
+@pytest.mark.parametrize("res", [False, True])
+def test_conv3x3_weight_stationary_kernel(dt, C, B, H, W, res):
+    """Bottleneck convs at launch sizes that take the persistent weight-stationary kernel (csrc/conv_ws.hip: >= 2 tiles per
+    CU): image edges that cut tiles in both directions, input / residual / output as channel slices of wider buffers
+    (block.py:281-283 `x + cv2(cv1(x))`, conv.py:36-38)."""
+    x = q(rnd(B, C, H, W, seed=1), dt)
+    w = q(rnd(C, C, 3, 3, seed=2, scale=1 / math.sqrt(9 * C)), dt)
+    sc, sh = rnd(C, seed=3) * 0.2 + 1, rnd(C, seed=4, scale=0.1)
+    rs = q(rnd(B, C, H, W, seed=5), dt)
+    ref = F.silu(F.conv2d(x, w, None, 1, 1) * sc[None, :, None, None] + sh[None, :, None, None])
+    if res:
+        ref = ref + rs
+    M = B * H * W
+    buf = torch.zeros(M, 3 * C + 8, device=DEV, dtype=dt)           # [x | residual | out | pad]
+    buf[:, :C] = x.permute(0, 2, 3, 1).reshape(M, C).to(DEV, dt)
+    buf[:, C:2 * C] = rs.permute(0, 2, 3, 1).reshape(M, C).to(DEV, dt)
+    wp = ops.pad_weight(w.permute(0, 2, 3, 1).reshape(C, 9 * C).to(DEV), dt)
+    ops.gemm(buf[:, :C], wp, C, 9 * C, ksize=3, stride=1, geom=(B, H, W, H, W, C), scale=sc.to(DEV), shift=sh.to(DEV),
+             act=L.ACT_SILU, R=buf[:, C:2 * C] if res else None, out=buf[:, 2 * C:3 * C])
+    got = buf[:, 2 * C:3 * C].float().cpu().view(B, H, W, C).permute(0, 3, 1, 2)
+    assert torch.allclose(got, ref, atol=tol(dt, 2e-5, 4e-2 if res else 3e-2), rtol=1e-5)
+    assert float(buf[:, 3 * C:].abs().max()) == 0                   # nothing written past the output slice
+    assert torch.equal(buf[:, :C].float().cpu(), x.permute(0, 2, 3, 1).reshape(M, C))   # input untouched
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_channel_slice_views(dt):
     """A / R / C as channel slices of wider concat buffers (C2f / Concat without copies)."""

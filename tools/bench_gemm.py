@@ -56,7 +56,9 @@ def make(s):
         kw.update(ln=(sc, sh), act=L.ACT_NONE)
     alg = (x.numel() + w.numel() + out.numel()) * 2
     flops = 2 * M * Cout * K
-    return (lambda: ops.gemm(x, w, Cout, K, **kw)), alg, flops, M
+    f = lambda: ops.gemm(x, w, Cout, K, **kw)
+    f.out = out
+    return f, alg, flops, M
 
 
 def main():
@@ -82,6 +84,12 @@ def main():
         ms = best[name]
         tot += ms
         print(f"{name:26s} M={M:8d} {ms*1e3:8.1f} us {alg/ms/1e6:7.0f} GB/s {flops/ms/1e9:7.1f} TF/s")
+        if os.environ.get("MOY_CWS_ABL") == "5":      # diagnostic build of csrc/conv_ws.hip: phase stamps of block 0, wave 0
+            d = f.out.view(torch.int64).flatten()[:8].cpu().tolist()
+            n = max(d[7], 1)
+            names = ["setup+dma", "mfma", "epilogue", "barrier1", "stores", "vmcnt", "barrier2"]
+            print("    cycles/tile (100 MHz ticks x clock ratio; shares matter): " +
+                  ", ".join(f"{nm} {v / n:.0f}" for nm, v in zip(names, d[:7])) + f"  tiles {d[7]}")
     print(f"sum {tot*1e3:.1f} us")
 
 
