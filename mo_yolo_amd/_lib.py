@@ -98,6 +98,10 @@ def lib():
             raise MoyoloError(
                 f"{LIB_PATH} is missing: build it with `python -m mo_yolo_amd.build` (hipcc, gfx950). "
                 "mo_yolo_amd has no CPU or eager fallback for its compute path.")
+        # PyTorch-ROCm ships its own libamdhip64: it must be the HIP runtime of the process BEFORE this library (linked against
+        # the same soname) is loaded, otherwise two runtimes coexist and torch's streams / pointers are foreign to our launches
+        # ("HIP launch error" on the first kernel; seen when build() loaded the library ahead of `import torch`).
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)          # AttributeError if the ABI drifted

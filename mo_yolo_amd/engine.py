@@ -62,12 +62,13 @@ class TrackEngine:
                  dtype: torch.dtype = torch.float32, device="cuda", input_format: str = "u8", conf: float = 0.25,
                  score_thresh: float = 0.4, scale_boxes: bool = True, head_only: bool = False,
                  level_shapes_override=None, side_state: bool = False, iou: float = 0.7, max_det: int = 300, orig_hw=None,
-                 temporal: int = 0, filter_score_thresh: float = 0.5, miss_tolerance: int = 5):
+                 temporal: int = 0, filter_score_thresh: float = 0.5, miss_tolerance: int = 5, n_inputs: int = 1):
         if not torch.cuda.is_available():
             raise L.MoyoloError("TrackEngine needs a HIP device (no CPU path)")
         self.lib = L.lib()
         self.arch, self.H, self.W, self.B = arch, H, W, batch
         self.dtype, self.code, self.dev = dtype, _code(dtype), torch.device(device)
+        self._esz = 4 if dtype == torch.float32 else 2
         self.input_format = input_format
         self.conf, self.score_thresh = conf, score_thresh
         # rows are scaled to the ORIGINAL frame (predict.py:61-76); it differs from (H, W) when the predictor stretch-resized
@@ -89,6 +90,11 @@ class TrackEngine:
         self.meta: List[dict] = []                   # per launch: name, algorithmic bytes, flops
         self.sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
         self._graph = None
+        # n_inputs static input buffers ("slots"): the producer of the frames (decoder / resize stage / test) writes slot i while
+        # the engine still reads slot j; every slot has its own captured graph, so a step never copies frames (round 1 copied
+        # B x H x W x 3 bytes into one static input per step)
+        self.n_inputs = max(1, int(n_inputs))
+        self._graphs: Dict[int, object] = {}
         with torch.no_grad():
             self._build()
 
@@ -222,11 +228,12 @@ class TrackEngine:
             head_src = [(v, hw_) for v, hw_ in zip(self.head_inputs, self.shapes)]
         else:
             if self.input_format == "u8":
-                self.input = torch.zeros(B, H, W, 3, device=self.dev, dtype=torch.uint8)
+                self.inputs = [torch.zeros(B, H, W, 3, device=self.dev, dtype=torch.uint8) for _ in range(self.n_inputs)]
             elif self.input_format == "f32":
-                self.input = torch.zeros(B, 3, H, W, device=self.dev, dtype=torch.float32)
+                self.inputs = [torch.zeros(B, 3, H, W, device=self.dev, dtype=torch.float32) for _ in range(self.n_inputs)]
             else:
                 raise ValueError(self.input_format)
+            self.input = self.inputs[0]
 
             # spatial size per layer output
             cur = (H, W)
@@ -286,11 +293,18 @@ class TrackEngine:
                         from .ops import stem_weights_mfma          # matrix-core stem (K 27 -> 32)
                         wpad = self._dev(stem_weights_mfma(sd[p + ".conv.weight"]))
                         self._add(lib.moy_stem_conv_mfma, self.input.data_ptr(), B, H, W, wpad.data_ptr(), scale.data_ptr(),
-                                  shift.data_ptr(), Ls.c2, o.ptr, o.ld)
+                                  shift.data_ptr(), Ls.c2, o.ptr, o.ld,
+                                  meta=dict(name=f"stem_mfma M{B * (H // 2) * (W // 2)} N{Ls.c2}", bytes=B * H * W * 3 + B * (H // 2) * (W // 2) * Ls.c2 * 2,
+                                            flops=2 * B * (H // 2) * (W // 2) * Ls.c2 * 27))
                     else:
                         wst = self._dev(sd[p + ".conv.weight"].permute(2, 3, 1, 0).reshape(27, Ls.c2))
+                        esz = 4 if self.dtype == torch.float32 else 2
                         self._add(lib.moy_stem_conv, self.input.data_ptr(), 0 if self.input_format == "u8" else 1, B, H, W,
-                                  wst.data_ptr(), scale.data_ptr(), shift.data_ptr(), Ls.c2, o.ptr, o.ld, code)
+                                  wst.data_ptr(), scale.data_ptr(), shift.data_ptr(), Ls.c2, o.ptr, o.ld, code,
+                                  meta=dict(name=f"stem M{B * (H // 2) * (W // 2)} N{Ls.c2}",
+                                            bytes=B * H * W * 3 * (1 if self.input_format == "u8" else 4) + B * (H // 2) * (W // 2) * Ls.c2 * esz,
+                                            flops=2 * B * (H // 2) * (W // 2) * Ls.c2 * 27))
+                    self._stem_step = len(self._steps) - 1       # its first argument is the input slot's pointer
                     outv[0] = o
                 elif Ls.kind == "Conv":
                     o = out_view(Ls.i, Ls.c2)
@@ -320,7 +334,8 @@ class TrackEngine:
                     cat = View(self._buf(B * h_ * w_, 4 * c_))
                     self._conv(p + ".cv1", x, hin, Ls.c1, c_, 1, 1, cat.slice(0, c_))
                     s0, s1, s2, s3 = (cat.slice(i * c_, c_) for i in range(4))
-                    self._add(lib.moy_sppf_pool, s0.ptr, s0.ld, B, h_, w_, c_, s1.ptr, s2.ptr, s3.ptr, cat.ld, code)
+                    self._add(lib.moy_sppf_pool, s0.ptr, s0.ld, B, h_, w_, c_, s1.ptr, s2.ptr, s3.ptr, cat.ld, code,
+                              meta=dict(name=f"sppf_pool M{B * h_ * w_} C{c_}", bytes=4 * B * h_ * w_ * c_ * self._esz, flops=0))
                     o = out_view(Ls.i, Ls.c2)
                     self._conv(p + ".cv2", cat, hin, 4 * c_, Ls.c2, 1, 1, o)
                     outv[Ls.i] = o
@@ -331,7 +346,8 @@ class TrackEngine:
                         outv[Ls.i] = None
                     else:
                         o = out_view(Ls.i, Ls.c2)
-                        self._add(lib.moy_upsample2x, x.ptr, x.ld, B, hin[0], hin[1], Ls.c1, o.ptr, o.ld, code)
+                        self._add(lib.moy_upsample2x, x.ptr, x.ld, B, hin[0], hin[1], Ls.c1, o.ptr, o.ld, code,
+                                  meta=dict(name=f"upsample2x M{B * hin[0] * hin[1]} C{Ls.c1}", bytes=5 * B * hin[0] * hin[1] * Ls.c1 * self._esz, flops=0))
                         outv[Ls.i] = o
                 elif Ls.kind == "Concat":
                     outv[Ls.i] = home[Ls.i]
@@ -408,7 +424,8 @@ class TrackEngine:
             allf = View(self._buf(B * S, hd))
             self._gemm(feats, Wt_enc, hd, hd, allf, B * S, shift=bias_enc, a_mask=self.valid, mask_period=S, ln=ln_enc)
             self._add(lib.moy_rowdot, allf.ptr, allf.ld, None, B * S, hd, wsc.data_ptr(), bsc.data_ptr(), nc, 0,
-                      None, None, self.scores_all.data_ptr(), code)
+                      None, None, self.scores_all.data_ptr(), code,
+                      meta=dict(name=f"rowdot M{B * S} N{nc}", bytes=B * S * (hd * self._esz + nc * 4), flops=2 * B * S * hd * nc))
 
         self.topk_local = torch.zeros(B, nq, device=self.dev, dtype=torch.int32)
         self.topk_global = torch.zeros(B, nq, device=self.dev, dtype=torch.int32)
@@ -416,7 +433,8 @@ class TrackEngine:
         self._topk_step = len(self._steps)
         self._split = len(self._steps)      # [0, _split): bandwidth-bound launches over all tokens; [_split, end): the query-sized chain
         self._add(lib.moy_topk, self.scores_all.data_ptr(), B, S, nc, nq, self.valid.data_ptr(),
-                  self.topk_local.data_ptr(), self.topk_global.data_ptr(), self.n_masked.data_ptr())
+                  self.topk_local.data_ptr(), self.topk_global.data_ptr(), self.n_masked.data_ptr(),
+                  meta=dict(name=f"topk B{B} S{S} k{nq}", bytes=B * (S * nc * 4 + S + nq * 8), flops=0))
 
         M = B * nq
         n_max = self.n_max
@@ -440,7 +458,8 @@ class TrackEngine:
             self._gemm(x, W0, hd, hd, t1, M, shift=b0, act=L.ACT_RELU, a_rows=a_rows)
             self._gemm(t1, W1, hd, hd, t2, M, shift=b1, act=L.ACT_RELU)
             self._add(lib.moy_rowdot, t2.ptr, t2.ld, None, M, hd, w2.data_ptr(), b2.data_ptr(), 4, mode,
-                      aux.data_ptr(), aux_rows.data_ptr() if aux_rows is not None else None, out_t.data_ptr(), code)
+                      aux.data_ptr(), aux_rows.data_ptr() if aux_rows is not None else None, out_t.data_ptr(), code,
+                      meta=dict(name=f"rowdot M{M} N4", bytes=M * (hd * self._esz + 32), flops=2 * M * hd * 4))
 
         # embed[0] = decoder input (never overwritten by the step), embed[1], embed[2] = layer outputs (ping-pong)
         embed = [View(self._buf(Md, hd)) for _ in range(3)]
@@ -455,8 +474,10 @@ class TrackEngine:
         bbox_mlp(d + ".enc_bbox_head", sel, None, 2, self.anchors, self.topk_local, self.refer_logit)
 
         if not n_max:
-            self._add(lib.moy_pos2posemb, self.refer_logit.data_ptr(), M, qpos.ptr, qpos.ld, code)
-            self._add(lib.moy_sigmoid_f32, self.refer_logit.data_ptr(), M * 4, refs[0].data_ptr())
+            self._add(lib.moy_pos2posemb, self.refer_logit.data_ptr(), M, qpos.ptr, qpos.ld, code,
+                      meta=dict(name=f"pos2posemb M{M}", bytes=M * (16 + hd * self._esz), flops=0))
+            self._add(lib.moy_sigmoid_f32, self.refer_logit.data_ptr(), M * 4, refs[0].data_ptr(),
+                      meta=dict(name=f"sigmoid M{M}", bytes=M * 32, flops=0))
             self.refer_all = self.refer_logit
         else:
             # per-sequence query memory (static shapes: the whole temporal step stays graph-capturable)
@@ -468,7 +489,8 @@ class TrackEngine:
                             n=torch.zeros(B, device=self.dev, dtype=i32),
                             max_obj_id=torch.zeros(B, device=self.dev, dtype=i64))
             det_embed, det_qpos = sel, View(self._buf(M, hd))
-            self._add(lib.moy_pos2posemb, self.refer_logit.data_ptr(), M, det_qpos.ptr, det_qpos.ld, code)
+            self._add(lib.moy_pos2posemb, self.refer_logit.data_ptr(), M, det_qpos.ptr, det_qpos.ld, code,
+                      meta=dict(name=f"pos2posemb M{M}", bytes=M * (16 + hd * self._esz), flops=0))
             self.refer_all = self._buf(Md, 4, torch.float32)
             t = self.trk
             self._add(lib.moy_temporal_assemble, t["embed"].data_ptr(), t["qpos"].data_ptr(), t["ref"].data_ptr(), t["n"].data_ptr(),
@@ -496,9 +518,10 @@ class TrackEngine:
             self._gemm(x, Wqkv, 3 * hd, hd, qkv, M, shift=bqkv, A2=qpos, a2_cols=2 * hd)
             if n_max:   # keys: live track slots + this frame's detect queries
                 self._add(lib.moy_mha_core_masked, qkv.ptr, qkv.ld, B, Lq, arch.nh, hd, self.trk["n"].data_ptr(), n_max, attn.ptr,
-                          attn.ld, code)
+                          attn.ld, code, meta=dict(name=f"mha_core B{B} L{Lq}", bytes=4 * M * hd * self._esz, flops=4 * B * Lq * Lq * hd))
             else:
-                self._add(lib.moy_mha_core, qkv.ptr, qkv.ld, B, nq, arch.nh, hd, attn.ptr, attn.ld, code)
+                self._add(lib.moy_mha_core, qkv.ptr, qkv.ld, B, nq, arch.nh, hd, attn.ptr, attn.ld, code,
+                          meta=dict(name=f"mha_core B{B} L{nq}", bytes=4 * M * hd * self._esz, flops=4 * B * nq * nq * hd))
             Wo, bo = self._linear_w(q + ".self_attn.out_proj")
             self._gemm(attn, Wo, hd, hd, e1, M, shift=bo, R=x, ln=self._ln(q + ".norm1"))
             Woa = torch.cat([sd[q + ".cross_attn.sampling_offsets.weight"], sd[q + ".cross_attn.attention_weights.weight"]], 0)
@@ -506,8 +529,12 @@ class TrackEngine:
             Woa_d, boa_d = self._linear_w_raw(Woa, boa)
             self._gemm(e1, Woa_d, Woa.shape[0], hd, View(offaw), M, shift=boa_d, A2=qpos, out_f32=True)
             vslice, vhs = value[i]
+            # gather: min(value slice of the layer, touched set = rows x heads x 12 samples x 4 taps x 32 channels) -- SURVEY §8(d)
+            taps = M * arch.nh * nl * arch.ndp * 4 * (hd // arch.nh) * self._esz
             self._add(lib.moy_msda_fused, vslice.ptr, vslice.ld, vhs, B, S, shapes_c, nl, offaw.data_ptr(), offaw.shape[1],
-                      refs[cur].data_ptr(), Lq, samp.ptr, samp.ld, code)
+                      refs[cur].data_ptr(), Lq, samp.ptr, samp.ld, code,
+                      meta=dict(name=f"msda_fused M{M}", bytes=min(B * S * hd * self._esz, taps) + M * (offaw.shape[1] * 4 + 16 + hd * self._esz),
+                                flops=2 * M * arch.nh * nl * arch.ndp * 4 * (hd // arch.nh)))
             Wp, bp = self._linear_w(q + ".cross_attn.output_proj")
             W1, b1 = self._linear_w(q + ".linear1")
             W2, b2 = self._linear_w(q + ".linear2")
@@ -545,7 +572,8 @@ class TrackEngine:
         wd = self._dev(sd[f"{d}.dec_score_head.{ndl - 1}.weight"])
         bd = self._dev(sd[f"{d}.dec_score_head.{ndl - 1}.bias"])
         self._add(lib.moy_rowdot, self.hs.ptr, self.hs.ld, None, M, hd, wd.data_ptr(), bd.data_ptr(), nc, 0, None, None,
-                  self.logits.data_ptr(), code)
+                  self.logits.data_ptr(), code,
+                  meta=dict(name=f"rowdot M{M} N{nc}", bytes=M * (hd * self._esz + nc * 4), flops=2 * M * hd * nc))
 
         self.y = torch.zeros(B, Lq, 4 + nc, device=self.dev)
         self.scores = torch.zeros(B, Lq, device=self.dev)
@@ -558,7 +586,8 @@ class TrackEngine:
             self._add(lib.moy_assign_post, self.logits.data_ptr(), self.boxes.data_ptr(), B, nq, nc,
                       C.c_float(self.score_thresh), C.c_float(self.conf), C.c_float(self.img_wh[0]), C.c_float(self.img_wh[1]),
                       self.y.data_ptr(), self.scores.data_ptr(), self.obj_idxes.data_ptr(), self.rows.data_ptr(),
-                      self.track_id.data_ptr(), self.n_rows.data_ptr(), self.n_ids.data_ptr())
+                      self.track_id.data_ptr(), self.n_rows.data_ptr(), self.n_ids.data_ptr(),
+                      meta=dict(name=f"assign_post B{B} nq{nq}", bytes=B * nq * ((nc + 4) * 4 + (4 + nc) * 4 + 4 + 8 + 24 + 8), flops=0))
         else:
             self._build_temporal_update(qpos)
 
@@ -693,23 +722,28 @@ class TrackEngine:
         return (self._dev(self.sd[p + ".weight"]), self._dev(self.sd[p + ".bias"]))
 
     # ------------------------------------------------------------------ run
-    def run_steps(self, start=0, stop=None):
-        """Enqueue launches [start, stop) on the current stream."""
+    def run_steps(self, start=0, stop=None, slot=0):
+        """Enqueue launches [start, stop) on the current stream, reading the frames from input slot `slot`."""
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for fn, args in self._steps[start:stop]:
+        stem = getattr(self, "_stem_step", -1) if slot else -1
+        for i, (fn, args) in enumerate(self._steps[start:stop], start):
+            if i == stem:
+                args = (self.inputs[slot].data_ptr(),) + args[1:]
             rc = fn(*args, st)
             if rc != 0:
                 L.check(rc, fn.__name__)
 
-    def forward(self, frames: torch.Tensor | None = None):
+    def forward(self, frames: torch.Tensor | None = None, slot: int = 0):
         """frames: uint8 [B,H,W,3] BGR (input_format 'u8') or float32 [B,3,H,W] RGB in [0,1] ('f32'),
-        already on the device; copied into the engine's static input.  Returns `outputs()`."""
+        already on the device; copied into input slot `slot`.  frames=None: the slot already holds them (a producer wrote
+        `self.inputs[slot]` in place) -- no copy at all.  Returns `outputs()`."""
         if frames is not None:
-            self.input.copy_(frames, non_blocking=True)
-        if self._graph is not None:
-            self._graph.replay()
+            self.inputs[slot].copy_(frames, non_blocking=True)
+        g = self._graphs.get(slot)
+        if g is not None:
+            g.replay()
         else:
-            self.run_steps()
+            self.run_steps(slot=slot)
         return self.outputs()
 
     def forward_head(self, feats):
@@ -731,7 +765,7 @@ class TrackEngine:
         return self.outputs()
 
     def capture(self, warmup: int = 2):
-        """Capture the step into a hipGraph (HIP streams + graphs instead of a tracing compiler)."""
+        """Capture the step into a hipGraph per input slot (HIP streams + graphs instead of a tracing compiler)."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -739,11 +773,14 @@ class TrackEngine:
                 self.run_steps()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.run_steps()
-        self._graph = g
-        return g
+        head_only = self.input is None
+        for slot in range(1 if head_only else self.n_inputs):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.run_steps(slot=slot)
+            self._graphs[slot] = g
+        self._graph = self._graphs[0]
+        return self._graph
 
     def capture_split(self, warmup: int = 2):
         """Two hipGraphs: launches [0, _split) (backbone, projections and score pass over all tokens) and [_split, end) (query
@@ -805,9 +842,15 @@ class StreamedEngines:
         self._graph = graph
         self._warm = False
 
-    def _warmup(self, frames):
+    def load(self, frames, slot=0):
+        """Write a batch [batch, ...] of device-resident frames into input slot `slot` of the sub-batch engines (the producer
+        side of the slot protocol: done once per batch, outside the step)."""
         for k, e in enumerate(self.engines):
-            e.forward(frames[k * self.Bs:(k + 1) * self.Bs])
+            e.inputs[slot].copy_(frames[k * self.Bs:(k + 1) * self.Bs], non_blocking=True)
+
+    def _warmup(self, frames, slot=0):
+        for k, e in enumerate(self.engines):
+            e.forward(frames[k * self.Bs:(k + 1) * self.Bs] if frames is not None else None, slot=slot)
         torch.cuda.synchronize()
         if self._graph:
             for e in self.engines:
@@ -817,25 +860,29 @@ class StreamedEngines:
                     e.capture()
         self._warm = True
 
-    def forward(self, frames):
-        """frames [batch, ...] resident on the device.  Enqueue-only: outputs are valid after `synchronize()`."""
+    def forward(self, frames=None, slot=0):
+        """frames [batch, ...] resident on the device (copied into input slot `slot`), or None when `load(frames, slot)` /
+        an in-place producer already filled the slot: the step then moves no frame bytes.  Enqueue-only: outputs are valid
+        after `synchronize()`."""
         if not self._warm:
-            self._warmup(frames)
+            self._warmup(frames, slot)
         cur = torch.cuda.current_stream()
         for k, (e, st) in enumerate(zip(self.engines, self.streams)):
             st.wait_stream(cur)                                   # the frames were produced on the caller's stream
+            sub = frames[k * self.Bs:(k + 1) * self.Bs] if frames is not None else None
             if self._split:
                 hi = self.hi_streams[k]
                 st.wait_stream(hi)                                # the previous step's chain still reads this engine's buffers
                 with torch.cuda.stream(st):
-                    e.input.copy_(frames[k * self.Bs:(k + 1) * self.Bs], non_blocking=True)
+                    if sub is not None:
+                        e.input.copy_(sub, non_blocking=True)
                     e._graph_lo.replay()
                 hi.wait_stream(st)
                 with torch.cuda.stream(hi):
                     e._graph_hi.replay()
             else:
                 with torch.cuda.stream(st):
-                    e.forward(frames[k * self.Bs:(k + 1) * self.Bs])
+                    e.forward(sub, slot=slot)
         return [e.outputs() for e in self.engines]
 
     def synchronize(self):

@@ -6,9 +6,9 @@ import os
 import numpy as np
 import torch
 
-from mo_yolo_amd.config import build_arch
+from mo_yolo_amd import fixtures as _fx
 from mo_yolo_amd.synth import SyntheticSequence, to_network_input
-from mo_yolo_amd.weights import apply_calibration, make_fixture_state_dict, state_dict_digest
+from mo_yolo_amd.weights import state_dict_digest
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -24,10 +24,9 @@ def fixture(name):
     """(cfg dict, arch, state_dict) for a golden config; weights are re-generated from the seed and
     checked against the digest stored when the goldens were made."""
     g = golden(name)
-    cfg = ast.literal_eval(str(g["cfg"]))
-    arch = build_arch(cfg["depth"], cfg["width"], cfg["nc"], cfg["nq"])
-    sd = make_fixture_state_dict(arch, cfg["seed"])
-    apply_calibration(sd, name)
+    cfg, arch, sd = _fx.fixture(name)
+    gcfg = ast.literal_eval(str(g["cfg"]))
+    assert all(cfg[k] == v for k, v in gcfg.items() if k in cfg), "fixture config drifted from the goldens"
     assert state_dict_digest(sd) == str(g["weights_sha256"]), "fixture weights drifted from the goldens"
     return cfg, arch, sd
 

@@ -94,6 +94,41 @@ def test_sharding_two_process_gloo(tmp_path):
     assert d["res"][0]["seqs"] == [0, 2, 4, 6] and d["res"][1]["seqs"] == [1, 3, 5, 7]
 
 
+def test_bench_control_flow_two_ranks_gloo_dry_run():
+    """The EXACT multi-GPU code of bench.py -- device pinning per local rank, rank -> sequence map (shard.py), barrier, MAX
+    over ranks, rank-0 JSON line -- under torch.distributed.run with 2 ranks on gloo, no GPU (`--dry-run`).  The 8-GPU
+    curve itself is the driver's to measure (sequences are independent, no collective on the data path)."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+           "--dry-run", "--backend", "gloo", "--config", "c5", "--batch", "8"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                               # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["config"]["dry_run"] is True
+    assert d["config"]["sequences_of_rank0"] == [0, 2, 4, 6]     # C5: 4 sequences per GPU, sequence i -> rank i mod N
+    assert d["config"]["control_backend"] == "gloo"
+    # value = frames of ALL ranks / MAX over ranks of the timed region: the slower synthetic rank (1.1x) sets the time
+    assert abs(d["value"] - 8 * 5 * 2 / (d["ms_per_step"] * 5 * 1e-3)) < 1e-4 * d["value"]      # (ms_per_step is rounded to 4 digits)
+    assert d["ms_per_step"] >= 2.2 * 0.99
+
+
+def test_bench_pins_one_device_per_local_rank(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    assert bench.pin_device(3) == "3"
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5,6,7")         # a driver that hands this job a subset of the node
+    assert bench.pin_device(2) == "6"
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "5")               # already pinned by the launcher
+    assert bench.pin_device(0) == "5"
+
+
 def _hota_case(g, case):
     T = int(g[f"{case}.T"])
     return {"num_timesteps": T, "num_gt_ids": int(g[f"{case}.num_gt_ids"]), "num_tracker_ids": int(g[f"{case}.num_tracker_ids"]),
