@@ -6,6 +6,8 @@ matched by token; reported per call:
   topk_overlap                 share of selected tokens common to both runs (mean over frames)
   box_max_err_matched          max |cxcywh difference| over matched rows
   score_max_err_matched        max |score difference| over matched rows
+  hs_max_err_matched           max |difference| of the decoder output embedding over matched rows (the well-conditioned
+                               quantity: the fixture score head amplifies it ~100x)
   birth_flip_frac_of_active    matched rows whose `obj_idxes >= 0` differs / rows active in the reference run
   ids_equal                    obj_idxes identical as arrays (same order, same ids)
 """
@@ -21,6 +23,9 @@ def engine_pair_stats(got, want, nq: int):
     sg, sw = got["scores"].float().cpu(), want["scores"].float().cpu()
     ig, iw = got["obj_idxes"].cpu(), want["obj_idxes"].cpu()
     overlap, box_err, score_err, flips, active_w, active_g, matched = 0.0, 0.0, 0.0, 0, 0, 0, 0
+    hs_err = 0.0
+    hg = got["hs"].float().cpu() if "hs" in got and "hs" in want else None
+    hw = want["hs"].float().cpu() if hg is not None else None
     order_same = 0
     for b in range(B):
         pos_w = {int(t): i for i, t in enumerate(tw[b].tolist())}
@@ -40,9 +45,11 @@ def engine_pair_stats(got, want, nq: int):
             box_err = max(box_err, float((bg[b, rg] - bw[b, rw]).abs().max()))
             score_err = max(score_err, float((sg[b, rg] - sw[b, rw]).abs().max()))
             flips += int(((ig[b, rg] >= 0) != (iw[b, rw] >= 0)).sum())
+            if hg is not None:
+                hs_err = max(hs_err, float((hg[b, rg] - hw[b, rw]).abs().max()))
     return {
         "frames": B, "topk_overlap": round(overlap / B, 5), "topk_order_equal_frames": order_same, "rows_matched": matched,
-        "box_max_err_matched": box_err, "score_max_err_matched": score_err,
+        "box_max_err_matched": box_err, "score_max_err_matched": score_err, "hs_max_err_matched": hs_err,
         "births_flipped": flips, "active_rows_reference": active_w, "active_rows": active_g,
         "birth_flip_frac_of_active": round(flips / max(1, active_w), 5),
         "ids_equal": bool(torch.equal(ig, iw)),

@@ -36,6 +36,11 @@ class SyntheticSequence:
         self.vx = rng.integers(-48, 49, size=n_obj).astype(np.int64)
         self.vy = rng.integers(-16, 17, size=n_obj).astype(np.int64)
         self.col = rng.integers(0, 256, size=(n_obj, 3), dtype=np.int64)
+        # Aperiodic pixel noise (drawn LAST, so the objects / ground truth above are unchanged): the 16-pixel background cells
+        # and the 32-pixel texture tile alone make many stride-8/16/32 tokens see IDENTICAL input windows -> identical features
+        # and encoder scores tied to the last bit, i.e. a query order that no two correct implementations agree on (round 1:
+        # adjacent top-k scores 8e-7 apart).  A frame takes a window of this plane at a frame-dependent offset.
+        self.noise = rng.integers(-10, 11, size=(H + 64, W + 64, 3), dtype=np.int64)
 
     def boxes(self, t: int):
         """xyxy pixel boxes (float32) and ids of the rectangles visible in frame t."""
@@ -52,6 +57,8 @@ class SyntheticSequence:
         H, W = self.H, self.W
         img = np.repeat(np.repeat(self.bg, 16, 0), 16, 1)
         img = img + np.tile(np.roll(self.tex, t % 32, 1), (H // 32, W // 32, 1))
+        oy, ox = (17 * t) % 64, (29 * t) % 64
+        img = img + self.noise[oy:oy + H, ox:ox + W]
         b, ids = self.boxes(t)
         for (x1, y1, x2, y2), i in zip(b.astype(np.int64), ids):
             img[y1:y2, x1:x2] = self.col[i]

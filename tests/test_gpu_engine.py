@@ -106,33 +106,73 @@ def test_engine_fp32_vs_reference_goldens_stream(name):
             assert np.array_equal(out["track_id"][t, :k].cpu().numpy(), g[f"post.{t}.track_id"].reshape(-1))
 
 
-def test_engine_fp32_c2_vs_reference_golden():
-    """Config C2 shape (s-scale, 1088x608, nq 300), 2 frames; rows matched by selected token."""
-    cfg, arch, sd = fixture("c2")
-    g = golden("c2")
-    B = 2
+def _direct_vs_golden(name, B):
+    """Free-running fp32 engine (its own top-k) against the reference's outputs on EVERY fixture frame, directly: same query
+    selection in the same order, y within 1e-3 (logit scale too), obj_idxes == the reference's obj_idxes.  The fixtures carry
+    the margins of SURVEY App. G (adjacent top-k scores > 1e-3 apart, boundary > 5e-3, no score within 1e-2 of 0.4 / 0.5)."""
+    cfg, arch, sd = fixture(name)
+    g = golden(name)
+    T = cfg["frames"]
+    assert float(g["topk_min_gap_all"]) > 1e-3 and float(g["topk_boundary_gap_all"]) > 5e-3 and float(g["score_margin"]) > 1e-2
+    assert int(g["n_masked_in_topk"]) == 0
     eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=torch.float32)
-    out = eng.forward(torch.from_numpy(frames_u8(cfg, 0, B)).to(DEV))
-    torch.cuda.synchronize()
-    assert out["n_masked"].cpu().tolist() == [0, 0]
-    tk = out["topk_ind"][0].cpu().numpy()
-    gk = g["t0.topk_ind"].reshape(-1)
-    assert set(tk.tolist()) == set(gk.tolist()), "selected token set"
-    # query order may differ only between near-tied encoder scores (min adjacent gap 8e-7 here)
-    pos = {int(t): i for i, t in enumerate(gk)}
-    perm = np.array([pos[int(t)] for t in tk])
-    assert np.abs(perm - np.arange(len(perm))).max() <= 2
-    y = out["y"][0].cpu().numpy()
-    assert np.allclose(y, g["y"][0][perm], atol=1e-3), np.abs(y - g["y"][0][perm]).max()
-    logit = lambda p: np.log(p / (1 - p))
-    assert np.allclose(logit(np.clip(y[:, 4], 1e-7, 1 - 1e-7)), logit(np.clip(g["y"][0][perm][:, 4], 1e-7, 1 - 1e-7)), atol=1e-3)
-    ids_expected = O.assign_ids(torch.from_numpy(g["scores"][0][perm])).numpy()
-    assert np.array_equal(out["obj_idxes"][0].cpu().numpy(), ids_expected)
-    # engine == oracle given the engine's own query order, second frame too
-    with torch.no_grad():
-        r = O.forward(net_input(cfg, 0, B), sd, arch, topk_ind=out["topk_ind"].cpu().long())
-    assert float((out["logits"].cpu() - r["dec_scores"]).abs().max()) < 1e-3
-    assert float((out["boxes"].cpu() - r["dec_bboxes"]).abs().max()) < 1e-4
+    logit = lambda p: np.log(np.clip(p, 1e-7, 1 - 1e-7) / (1 - np.clip(p, 1e-7, 1 - 1e-7)))
+    worst = 0.0
+    for t0 in range(0, T, B):
+        out = eng.forward(torch.from_numpy(frames_u8(cfg, t0, B)).to(DEV))
+        torch.cuda.synchronize()
+        assert out["n_masked"].cpu().tolist() == [0] * B
+        for b in range(min(B, T - t0)):
+            t = t0 + b
+            assert np.array_equal(out["topk_ind"][b].cpu().numpy(), g["topk_ind_all"][t]), f"frame {t}: query selection / order"
+            y = out["y"][b].cpu().numpy()
+            worst = max(worst, float(np.abs(y - g["y"][t]).max()))
+            assert np.allclose(y, g["y"][t], atol=1e-3), (t, np.abs(y - g["y"][t]).max())
+            assert np.allclose(logit(y[:, 4:]), logit(g["y"][t][:, 4:]), atol=1e-3), f"frame {t}: decoder logits"
+            assert np.array_equal(out["obj_idxes"][b].cpu().numpy(), g["obj_idxes"][t]), f"frame {t}: track ids"
+            n = int(out["n_rows"][b])
+            assert np.allclose(out["rows"][b, :n].cpu().numpy(), g[f"post.{t}.boxes"], atol=5e-2, rtol=1e-5), f"frame {t}: predictor rows"
+            if bool(g[f"post.{t}.is_track"]):
+                k = int(out["n_ids"][b])
+                assert np.array_equal(out["track_id"][b, :k].cpu().numpy(), g[f"post.{t}.track_id"].reshape(-1))
+    print(f"[{name}] {T} frames direct vs reference: max |y diff| {worst:.2e}")
+
+
+def test_engine_fp32_c2_vs_reference_golden():
+    """Config C2 (s-scale, 1088x608, nq 300): all 8 golden frames, direct comparison."""
+    _direct_vs_golden("c2", 4)
+
+
+@pytest.mark.slow
+def test_engine_fp32_c4_vs_reference_golden():
+    """Config C4 (1920x1088, nq 500): both golden frames, direct comparison."""
+    _direct_vs_golden("c4", 2)
+
+
+def test_engine_bench_scale_kernel_paths_vs_small_batch():
+    """at B <= 4 (B*S < 65536) moy_gemm never takes the weight-stationary kernels, the head-plane value layout or
+    the output row remap of input_proj, and the 3x3 convs stay on the per-tile kernels.  B = 6 at the C2 shape crosses those
+    thresholds (B*S = 81 396 rows; 6 x 45 conv tiles): the fp32 engine's query selection is the reference (previous test), and
+    the 16-bit engines at B = 6 must agree with the SAME dtype at B = 2 row for row -- every kernel is batch-invariant by
+    construction except for the kernel choice, so any difference is a bench-scale-only path going wrong."""
+    cfg, arch, sd = fixture("c2")
+    B = 6
+    fr = torch.from_numpy(frames_u8(cfg, 0, B)).to(DEV)
+    # (scores: the fixture's last score head amplifies the decoder output ~100x, DESIGN.md section 2 -- hs is the tight check)
+    for dt, tol_box, tol_score, tol_hs in ((torch.bfloat16, 0.02, 0.3, 0.06), (torch.float16, 2e-3, 0.05, 8e-3)):
+        big = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt)
+        ob = {k: v.clone() for k, v in big.forward(fr).items()}
+        small = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=2, dtype=dt)
+        from mo_yolo_amd.parity import engine_pair_stats
+        for t0 in range(0, B, 2):
+            os_ = small.forward(fr[t0:t0 + 2])
+            torch.cuda.synchronize()
+            st = engine_pair_stats({k: v[t0:t0 + 2] for k, v in ob.items() if hasattr(v, "shape") and v.shape[:1] == (B,)}, os_, arch.nq)
+            # (the 16-bit encoder scores are re-randomised at the 1e-3 level by the rounding of their inputs, so the two LayerNorm
+            # forms -- one pass in the weight-stationary score mode, two passes in the tiled kernel -- order a few near-ties differently)
+            assert st["topk_overlap"] > 0.9, st
+            assert st["box_max_err_matched"] < tol_box and st["score_max_err_matched"] < tol_score, (dt, st)
+            assert st["hs_max_err_matched"] < tol_hs, (dt, st)
 
 
 def test_engine_fp16_c5_batched_sequences_graph():
