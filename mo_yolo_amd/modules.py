@@ -522,8 +522,8 @@ class QueryInteractionModule(nn.Module):
 
 # ----------------------------------------------------------------------------- planned modules
 class MYDecoder(nn.Module):
-    """head.py:807-1137.  Parameters under the reference names; forward runs the head part of a
-    TrackEngine plan built for the incoming feature-map shapes."""
+    """head.py:807-1137.  Parameters under the reference names; `forward` (head.py:873-985) runs the head part of a
+    TrackEngine plan built for the incoming feature-map shapes and returns the reference's 7-tuple."""
 
     def __init__(self, nc=80, ch=(512, 1024, 2048), hd=256, nq=300, ndp=4, nh=8, ndl=6, d_ffn=1024, **_unused):
         super().__init__()
@@ -539,6 +539,45 @@ class MYDecoder(nn.Module):
         self.enc_bbox_head = MLP(hd, hd, 4, num_layers=3)
         self.dec_score_head = nn.ModuleList([_Linear(hd, nc) for _ in range(ndl)])
         self.dec_bbox_head = nn.ModuleList([MLP(hd, hd, 4, num_layers=3) for _ in range(ndl)])
+        self._engines: Dict = {}
+        self.register_load_state_dict_post_hook(lambda m, _k: m._engines.clear())
+
+    def _engine(self, feats):
+        """Head-only TrackEngine for these pyramid shapes (cached; cleared when weights are loaded)."""
+        from .engine import TrackEngine
+        B = feats[0].shape[0]
+        shapes = tuple((f.shape[2], f.shape[3]) for f in feats)
+        dt = feats[0].dtype if feats[0].dtype in (torch.bfloat16, torch.float16) else torch.float32
+        key = (B, shapes, dt, str(feats[0].device))
+        if key not in self._engines:
+            sd = {f"model.0.decoder.{k}": v for k, v in self.state_dict().items()}
+            arch = TrackArch(nc=self.nc, nq=self.num_queries, layers=[], head_ch=tuple(self.ch))
+            self._engines[key] = TrackEngine(arch, sd, shapes[0][0] * 8, shapes[0][1] * 8, batch=B, dtype=dt,
+                                             device=feats[0].device, head_only=True, level_shapes_override=shapes,
+                                             scale_boxes=False)
+        return self._engines[key]
+
+    def forward(self, x, track_ref_pts=None, batch=None, is_first=False, pre_class=None, track_query_pos=None):
+        """x = [P3, P4, P5] NCHW device tensors -> (dec_bboxes [1,bs,nq,4], dec_scores [1,bs,nq,nc], enc_bboxes [bs,nq,4],
+        enc_scores [bs,nq,nc], dn_meta = None, init_reference [bs,nq,4], dec_output_embedding [bs,nq,256]) as head.py:985.
+        The carried-track arguments select a branch that cannot run in the reference (SURVEY §0.3: IndexError at head.py:1235);
+        the carried design lives in TrackEngine(temporal=...) / TrackingModel.inference_single_image."""
+        if track_ref_pts is not None or pre_class is not None or track_query_pos is not None:
+            raise NotImplementedError("carried track queries: use TrackEngine(temporal=n) / TrackingModel.inference_single_image "
+                                      "(the reference's own branch for these arguments raises, head.py:1235)")
+        ops._need_gpu(*x)
+        eng = self._engine(x)
+        out = eng.forward_head(x)
+        return _x7(eng, out)
+
+
+def _x7(eng, out):
+    """The reference's 7-tuple (head.py:985) from engine outputs; fresh tensors (engine buffers are static)."""
+    B = eng.B
+    refer = out["refer_bbox_logit"]
+    enc_scores = eng.scores_all.view(B, eng.S, -1)[torch.arange(B, device=refer.device)[:, None], out["topk_ind"].long()]
+    return (out["boxes"].unsqueeze(0).clone(), out["logits"].unsqueeze(0).clone(), refer.sigmoid(), enc_scores, None,
+            refer.sigmoid(), out["hs"].clone())
 
 
 class MOTRTrack(nn.Module):
@@ -551,24 +590,10 @@ class MOTRTrack(nn.Module):
         self.decoder = MYDecoder(nc=nc, ch=ch, nq=nq)
         self.track_embed = QueryInteractionModule(None, d_model, self.decoder.hidden_dim, d_model * 2)
         self.track_instances = None
-        self._engines: Dict = {}
-
-    def _engine(self, feats):
-        from .engine import TrackEngine
-        B = feats[0].shape[0]
-        shapes = tuple((f.shape[2], f.shape[3]) for f in feats)
-        dt = feats[0].dtype if feats[0].dtype == torch.bfloat16 else torch.float32
-        key = (B, shapes, dt, str(feats[0].device))
-        if key not in self._engines:
-            sd = {f"model.0.{k}": v for k, v in self.state_dict().items()}
-            arch = TrackArch(nc=self.nc, nq=self.nq, layers=[], head_ch=tuple(self.decoder.ch))
-            self._engines[key] = TrackEngine(arch, sd, shapes[0][0] * 8, shapes[0][1] * 8, batch=B, dtype=dt,
-                                             device=feats[0].device, head_only=True, level_shapes_override=shapes,
-                                             scale_boxes=False)
-        return self._engines[key]
 
     def forward(self, x, batch=None, is_first=True):
-        eng = self._engine(x)
+        ops._need_gpu(*x)
+        eng = self.decoder._engine(x)            # one plan serves MYDecoder.forward and this (cleared when weights are loaded)
         out = eng.forward_head(x)
         return _reference_outputs(eng, out, self)
 
@@ -576,21 +601,30 @@ class MOTRTrack(nn.Module):
 def _reference_outputs(eng, out, owner):
     """Pack engine outputs into the reference's eval return structure (head.py:235-239):
     ((y, x7), Instances) with x7 = (dec_bboxes, dec_scores, enc_bboxes, enc_scores, dn_meta,
-    init_reference, dec_output_embedding)."""
+    init_reference, dec_output_embedding).  Everything returned is a FRESH tensor per call, like the reference's (only raw
+    `TrackEngine.outputs()` aliases the engine's static buffers, which the next step or graph replay overwrites).  The
+    Instances carry the 11 fields of `_generate_empty_tracks` (head.py:150-189); the five the shipped path never writes keep
+    their initial values (zeros / -1), `ref_pts` holds the queries' reference boxes in logit space (the reference leaves
+    `torch.rand` there, head.py:163: unused, not reproducible)."""
     B, nq = eng.B, eng.arch.nq
-    y = out["y"]
+    y = out["y"].clone()
+    x7 = _x7(eng, out)
     refer = out["refer_bbox_logit"]
-    enc_scores = eng.scores_all.view(B, eng.S, -1)[torch.arange(B, device=y.device)[:, None], out["topk_ind"].long()]
-    x7 = (out["boxes"].unsqueeze(0), out["logits"].unsqueeze(0), refer.sigmoid(), enc_scores, None, refer.sigmoid(), out["hs"])
+    dev = y.device
     insts = []
     for b in range(B):
         inst = Instances((1, 1))
-        inst.scores = out["scores"][b]
-        inst.pred_logits = out["logits"][b]
-        inst.pred_boxes = out["boxes"][b]
-        inst.output_embedding = out["hs"][b]
-        inst.obj_idxes = out["obj_idxes"][b].unsqueeze(1)
-        inst.disappear_time = torch.zeros_like(inst.obj_idxes)
+        inst.ref_pts = refer[b].clone()
+        inst.query_pos = torch.zeros(nq, 256, dtype=torch.float32, device=dev)
+        inst.output_embedding = out["hs"][b].clone()
+        inst.obj_idxes = out["obj_idxes"][b].unsqueeze(1).clone()
+        inst.matched_gt_idxes = torch.full((nq,), -1, dtype=torch.long, device=dev)
+        inst.disappear_time = torch.zeros(nq, 1, dtype=torch.long, device=dev)
+        inst.iou = torch.zeros(nq, dtype=torch.float32, device=dev)
+        inst.scores = out["scores"][b].clone()
+        inst.track_scores = torch.zeros(nq, 4, dtype=torch.float32, device=dev)
+        inst.pred_boxes = out["boxes"][b].clone()
+        inst.pred_logits = out["logits"][b].clone()
         insts.append(inst)
     owner.track_instances = insts[0] if B == 1 else insts     # the reference is batch-1 (head.py:235)
     return (y, x7), owner.track_instances
@@ -647,3 +681,49 @@ class TrackingModel(nn.Module):
 
     def forward(self, x, *args, **kwargs):
         return self.predict(x, *args, **kwargs)
+
+    @torch.no_grad()
+    def inference_single_image(self, img, ori_img_size, track_instances=None, track_slots: int = 100):
+        """Upstream MOTR's per-frame entry (MOTR/models/motr.py:580-598) over the temporal engine:
+        img float [1,3,H,W] in [0,1] (H, W multiples of 32); `track_instances=None` starts a sequence (`_generate_empty_tracks`
+        there, `reset_sequence` here), otherwise pass the Instances returned by the previous call -- the query memory itself
+        lives in HBM and is updated in place, the Instances is the caller's view of it (and the continuity token).
+        Returns {'track_instances': live tracks after the ID lifecycle + QIM update, with `boxes` (xyxy in `ori_img_size`
+        pixels, TrackerPostProcess motr.py:225-246), `scores`, `labels`, `obj_idxes`, `pred_boxes`, `pred_logits`,
+        `output_embedding`, `query_pos`, `ref_pts`; 'ref_pts': the decoder reference points in pixels}."""
+        from .engine import TrackEngine
+        ops._need_gpu(img)
+        if img.dim() != 4 or img.shape[0] != 1 or img.shape[1] != 3:
+            raise ValueError("img must be [1, 3, H, W]")
+        _, _, H, W = img.shape
+        key = ("temporal", H, W, str(img.device), int(track_slots))
+        if key not in self._engines:
+            self._engines[key] = TrackEngine(self.arch, self.state_dict(), H, W, batch=1, dtype=torch.float32, device=img.device,
+                                             input_format="f32", scale_boxes=False, temporal=int(track_slots))
+            self._temporal_token = None
+        eng = self._engines[key]
+        if track_instances is None:
+            eng.reset_sequence()
+        elif track_instances is not getattr(self, "_temporal_token", None):
+            raise ValueError("track_instances must be None (new sequence) or the Instances returned by the previous call: the "
+                             "query memory is device-resident state of this model")
+        out = eng.forward(img.float())
+        n = int(out["n_tracks"][0])
+        img_h, img_w = ori_img_size
+        scale = torch.tensor([img_w, img_h, img_w, img_h], dtype=torch.float32, device=img.device)
+        live = (out["obj_idxes"][0] >= 0).nonzero().view(-1)          # rows of this frame that are tracks now, in query order
+        inst = Instances((img_h, img_w))
+        pb = out["boxes"][0][live].clone()
+        inst.pred_boxes = pb
+        inst.boxes = torch.cat([pb[:, :2] - pb[:, 2:] / 2, pb[:, :2] + pb[:, 2:] / 2], -1) * scale
+        lg = out["logits"][0][live].clone()
+        inst.pred_logits = lg
+        inst.scores = out["scores"][0][live].clone()
+        inst.labels = lg.argmax(-1)
+        inst.obj_idxes = out["obj_idxes"][0][live].clone()
+        inst.output_embedding = out["hs"][0][live].clone()
+        inst.query_pos = out["trk_qpos"][0][:n].clone()                # memory slots (compacted in query order): the QIM-updated embedding
+        inst.ref_pts = out["trk_ref"][0][:n].clone()
+        self._temporal_token = inst
+        ref = eng.refer_all.view(1, -1, 4)[0, :, :2].sigmoid() * scale[:2]
+        return {"track_instances": inst, "ref_pts": ref.clone()}

@@ -12,6 +12,7 @@ Files written
   tests/golden/msda_kat.npz            deformable-attention KATs incl. zero-padding edge taps
   tests/golden/qim.npz                 isolated QueryInteractionModule._update_track_embedding
   tests/golden/hota.npz                HOTA scalars of the reference evaluator on synthetic data
+  tests/golden/state.npz               RuntimeTrackerBase.update's returned copy + FSQM memory over a many-birth stream
 """
 import hashlib
 import os
@@ -580,6 +581,83 @@ def dump_qim():
     print("[qim] wrote")
 
 
+def dump_state():
+    """Pins for the output-invisible side state (SURVEY §0.4, rows a16 copy half + a17): what `RuntimeTrackerBase.update`
+    RETURNS (the filtered, renumbered copy; head.py:1245-1283, _filter_tracks :1155-1171) and what `FSQM.online_update`
+    leaves in its memory (MOTR/models/fsqm.py:51-180), captured from the reference running a multi-frame stream with many
+    births (last score head biased by +6: some scores > 0.7, so the memory really fills).  Per frame the decoder outputs the
+    state machine consumed are stored too, so the restatement can be checked on the CPU without running the model."""
+    cfg = dict(CONFIGS["tiny"], name="tiny")
+    m, sd, arch = build_model(cfg, calibrated=True)
+    head = m.model[-1]
+    key_b = f"model.{len(arch.layers)}.decoder.dec_score_head.{arch.ndl - 1}.bias"
+    with torch.no_grad():
+        head.decoder.dec_score_head[arch.ndl - 1].bias += 6.0
+    import ultralytics.nn.modules.head as H
+    cap = {}
+    orig_update = H.RuntimeTrackerBase.update
+
+    def update(self, track_instances, g_size=1):
+        r = orig_update(self, track_instances, g_size)
+        cap["copy_ids"] = r.obj_idxes.detach().clone().view(-1)
+        cap["copy_boxes"] = r.pred_boxes.detach().clone()
+        cap["copy_scores"] = r.scores.detach().clone()
+        cap["max_obj_id"] = int(torch.as_tensor(self.max_obj_id).view(-1)[0])
+        return r
+    H.RuntimeTrackerBase.update = update
+    seq = SyntheticSequence(0, cfg["H"], cfg["W"], cfg["style"])
+    T = 7
+    out = {"bias_shift": np.array(6.0, np.float32), "frames": np.array(T), "weights_sha256": np.array(state_dict_digest(sd))}
+    fs = head.track_embed.fsqm
+    fs.reset()
+    try:
+        for t in range(T):
+            x = to_network_input(seq.frames(t, 1))
+            (y, x7), inst = m(x) if True else None
+            out[f"{t}.scores"] = inst.scores.detach().numpy().copy()
+            out[f"{t}.boxes"] = inst.pred_boxes.detach().numpy().copy()
+            out[f"{t}.obj_idxes"] = inst.obj_idxes.detach().view(-1).numpy().copy()
+            out[f"{t}.hs"] = inst.output_embedding.detach().numpy().copy()
+            out[f"{t}.copy_ids"] = cap["copy_ids"].numpy().copy()
+            out[f"{t}.copy_boxes"] = cap["copy_boxes"].numpy().copy()
+            out[f"{t}.copy_scores"] = cap["copy_scores"].numpy().copy()
+            out[f"{t}.max_obj_id"] = np.array(cap["max_obj_id"])
+            out[f"{t}.fsqm.mem"] = fs.query_memory.detach().numpy().copy()
+            out[f"{t}.fsqm.conf"] = fs.confidence.detach().numpy().copy()
+            out[f"{t}.fsqm.ids"] = fs.ids.detach().numpy().copy()
+            out[f"{t}.fsqm.boxes"] = fs.bounding_boxes.detach().numpy().copy()
+            out[f"{t}.fsqm.low"] = fs.consecutive_low_frames.detach().numpy().copy()
+            out[f"{t}.fsqm.pool"] = np.array(fs.global_id_pool, dtype=np.int64)
+            print(f"[state] frame {t}: active {int((inst.obj_idxes >= 0).sum())}, copy rows {len(cap['copy_ids'])}, "
+                  f"memory slots in use {int((fs.ids >= 0).sum())}, id pool {len(fs.global_id_pool)}")
+    finally:
+        H.RuntimeTrackerBase.update = orig_update
+    # Direct calls with clustered boxes, so that the greedy IoU > 0.8 suppression (incl. its cx/cy shortcut and the
+    # cxcywh-as-xywh reading) and the renumbering really act -- the fixture stream above never produces two overlapping rows.
+    from MOTR.models.structures import Instances
+    for case, (n, seed) in enumerate([(40, 11), (64, 12), (7, 13), (1, 14)]):
+        g = torch.Generator().manual_seed(seed)
+        base = torch.rand(max(1, n // 4), 4, generator=g) * torch.tensor([0.8, 0.8, 0.3, 0.3]) + torch.tensor([0.1, 0.1, 0.05, 0.05])
+        boxes = base[torch.randint(0, base.shape[0], (n,), generator=g)] + (torch.rand(n, 4, generator=g) - 0.5) * 0.02
+        scores = torch.rand(n, generator=g)
+        inst = Instances((1, 1))
+        inst.scores = scores.clone()
+        inst.pred_boxes = boxes.clone()
+        inst.obj_idxes = torch.full((n,), -1, dtype=torch.long)
+        inst.disappear_time = torch.zeros(n, dtype=torch.long)
+        inst.output_embedding = torch.rand(n, 8, generator=g)
+        tb = H.RuntimeTrackerBase()
+        r = tb.update(inst)
+        out[f"unit{case}.scores"] = scores.numpy(); out[f"unit{case}.boxes"] = boxes.numpy()
+        out[f"unit{case}.obj_idxes"] = inst.obj_idxes.view(-1).numpy().copy()
+        out[f"unit{case}.copy_ids"] = r.obj_idxes.view(-1).numpy().copy()
+        out[f"unit{case}.copy_boxes"] = r.pred_boxes.numpy().copy()
+        out[f"unit{case}.max_obj_id"] = np.array(int(torch.as_tensor(tb.max_obj_id).view(-1)[0]))
+        print(f"[state] unit case {case}: {n} rows, {int((inst.obj_idxes >= 0).sum())} born, {len(r.obj_idxes)} kept by the filter")
+    out["unit_cases"] = np.array(4)
+    np.savez_compressed(os.path.join(HERE, "state.npz"), **out)
+
+
 def dump_hota():
     """HOTA of the reference evaluator (utils/hota.py:24-164) on synthetic GT vs jittered tracks."""
     ref_shim.install()
@@ -623,7 +701,7 @@ def dump_hota():
 
 
 def main():
-    which = sys.argv[1:] or ["tiny", "tiny3", "c2", "c4", "c1", "msda", "qim", "hota"]
+    which = sys.argv[1:] or ["tiny", "tiny3", "c2", "c4", "c1", "msda", "qim", "hota", "state"]
     cal = {}
     for name in which:
         if name in CONFIGS:
@@ -639,6 +717,8 @@ def main():
         dump_qim()
     if "hota" in which:
         dump_hota()
+    if "state" in which:
+        dump_state()
 
 
 if __name__ == "__main__":

@@ -347,23 +347,30 @@ def test_side_state_copy_filter_and_fsqm_vs_oracle():
     assert int((eng.fsqm["ids"] >= 0).sum()) == 0 and eng.fsqm["pool_hc"].cpu().tolist() == [0, 300, 0]
 
 
-def test_engine_fp32_c4_vs_reference_golden():
-    """Config C4 shape (1920x1088, 500 queries: S = 42 840 tokens, radix-select top-k beyond one LDS
-    tile, 32-tile attention): frame 0 vs the reference golden, rows matched by selected token."""
-    cfg, arch, sd = fixture("c4")
-    g = golden("c4")
-    eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=1, dtype=torch.float32)
-    out = eng.forward(torch.from_numpy(frames_u8(cfg, 0, 1)).to(DEV))
-    torch.cuda.synchronize()
-    assert int(out["n_masked"][0]) == 0
-    tk, gk = out["topk_ind"][0].cpu().numpy(), g["t0.topk_ind"].reshape(-1)
-    assert set(tk.tolist()) == set(gk.tolist())
-    pos = {int(t): i for i, t in enumerate(gk)}
-    perm = np.array([pos[int(t)] for t in tk])
-    assert np.abs(perm - np.arange(len(perm))).max() <= 3          # near-tied encoder scores only (min gap 2.4e-7)
-    assert np.allclose(out["y"][0].cpu().numpy(), g["y"][0][perm], atol=1e-3)
-    ids_expected = O.assign_ids(torch.from_numpy(g["scores"][0][perm])).numpy()
-    assert np.array_equal(out["obj_idxes"][0].cpu().numpy(), ids_expected)
+def test_side_state_on_device_vs_reference_pins():
+    """The device side-state path (moy_track_state_update: copy filter + renumbering + FSQM memory in HBM) against the
+    REFERENCE's own state over the many-birth stream of tests/golden/state.npz (captured from RuntimeTrackerBase.update's
+    return value and FSQM.online_update, head.py:1245-1283, fsqm.py:51-180)."""
+    g = golden("state")
+    cfg, arch, sd = fixture("tiny")
+    sd = dict(sd)
+    key = f"model.{len(arch.layers)}.decoder.dec_score_head.{arch.ndl - 1}.bias"
+    sd[key] = sd[key] + float(g["bias_shift"])
+    eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=1, dtype=torch.float32, side_state=True)
+    for t in range(int(g["frames"])):
+        out = eng.forward(torch.from_numpy(frames_u8(cfg, t, 1)).to(DEV))
+        torch.cuda.synchronize()
+        assert np.array_equal(out["obj_idxes"][0].cpu().numpy(), g[f"{t}.obj_idxes"]), t
+        n = int(eng.n_copy[0])
+        assert eng.copy_ids[0, :n].cpu().tolist() == g[f"{t}.copy_ids"].tolist(), t
+        rows = eng.copy_rows[0, :n].cpu().long()
+        assert np.allclose(out["boxes"][0].cpu()[rows].numpy(), g[f"{t}.copy_boxes"], atol=2e-4)
+        f = {k: v.cpu().numpy() for k, v in eng.fsqm.items()}
+        assert np.array_equal(f["ids"], g[f"{t}.fsqm.ids"]) and np.array_equal(f["low"], g[f"{t}.fsqm.low"]), t
+        assert np.allclose(f["conf"], g[f"{t}.fsqm.conf"], atol=2e-4) and np.allclose(f["boxes"], g[f"{t}.fsqm.boxes"], atol=2e-4)
+        assert np.allclose(f["mem"], g[f"{t}.fsqm.mem"], atol=2e-3)
+        head, cnt, ovf = f["pool_hc"]
+        assert ovf == 0 and [int(f["pool"][(head + k) % len(f["pool"])]) for k in range(cnt)] == g[f"{t}.fsqm.pool"].tolist()
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

@@ -112,6 +112,132 @@ def test_tracking_model_predict_and_motrtrack_forward(name):
     assert np.array_equal(inst2.obj_idxes.view(-1).cpu().numpy(), g["obj_idxes"][0])
 
 
+def test_mydecoder_forward_seven_tuple_and_instances_fields():
+    """Boundary row b3: `MYDecoder.forward(x, ...)` returns the reference's 7-tuple (head.py:873-985) and the Instances of
+    `MOTRTrack.forward` carry the 11 fields of `_generate_empty_tracks` (head.py:150-189) with the reference's shapes/dtypes;
+    returned tensors are fresh per call (a second call must not change what the first returned); loading weights drops the
+    cached plan."""
+    cfg, arch, sd = fixture("tiny")
+    g = golden("tiny")
+    nq, nc = cfg["nq"], cfg["nc"]
+    model = M.TrackingModel(cfg["depth"], cfg["width"], nc, nq).load_reference(sd)
+    head = model.model[-1]
+    with torch.no_grad():
+        f0 = [f.to(DEV) for f in O.backbone_neck(net_input(cfg, 0, 1), sd, arch)]
+        f1 = [f.to(DEV) for f in O.backbone_neck(net_input(cfg, 1, 1), sd, arch)]
+    x7 = head.decoder(f0)
+    torch.cuda.synchronize()
+    assert isinstance(x7, tuple) and len(x7) == 7
+    dec_bboxes, dec_scores, enc_bboxes, enc_scores, dn_meta, init_ref, hs = x7
+    assert dec_bboxes.shape == (1, 1, nq, 4) and dec_scores.shape == (1, 1, nq, nc) and dn_meta is None
+    assert enc_bboxes.shape == (1, nq, 4) and enc_scores.shape == (1, nq, nc) and init_ref.shape == (1, nq, 4) and hs.shape == (1, nq, 256)
+    assert np.allclose(dec_bboxes[0, 0].cpu().numpy(), g["y"][0][:, :4], atol=2e-4)
+    assert np.allclose(dec_scores[0, 0].sigmoid().cpu().numpy(), g["y"][0][:, 4:], atol=2e-4)
+    assert np.allclose(enc_bboxes.cpu().numpy(), g["t0.enc_bboxes"], atol=1e-4)
+    assert np.allclose(enc_scores.cpu().numpy(), g["t0.enc_scores"], atol=2e-3, rtol=1e-5)
+    assert np.allclose(init_ref.cpu().numpy(), g["t0.enc_bboxes"], atol=1e-4)       # track_ref_pts.sigmoid() of the top-k boxes (head.py:960)
+    assert abs(float(hs.double().sum()) - float(g["t0.inst.output_embedding.sum"])) < 5e-2
+    with pytest.raises(NotImplementedError):
+        head.decoder(f0, track_ref_pts=torch.zeros(3, 4, device=DEV))
+    # MOTRTrack.forward: the 11 fields, and no aliasing of engine buffers
+    (y_a, x7_a), inst = head(f0)
+    want = {"ref_pts": (nq, 4), "query_pos": (nq, 256), "output_embedding": (nq, 256), "obj_idxes": (nq, 1), "matched_gt_idxes": (nq,),
+            "disappear_time": (nq, 1), "iou": (nq,), "scores": (nq,), "track_scores": (nq, 4), "pred_boxes": (nq, 4), "pred_logits": (nq, nc)}
+    assert set(inst.get_fields()) == set(want)
+    for k, shp in want.items():
+        assert tuple(inst.get(k).shape) == shp, k
+        assert inst.get(k).dtype == (torch.long if k in ("obj_idxes", "matched_gt_idxes", "disappear_time") else torch.float32), k
+    assert np.allclose(inst.pred_logits.cpu().numpy(), g["t0.inst.pred_logits"], atol=2e-3)
+    keep = {k: v.clone() for k, v in inst.get_fields().items()}
+    y_keep = y_a.clone()
+    (y_b, _), inst_b = head(f1)                                        # same cached plan, other frame
+    torch.cuda.synchronize()
+    assert torch.equal(y_a, y_keep) and all(torch.equal(inst.get(k), v) for k, v in keep.items()), "outputs alias engine buffers"
+    assert not torch.equal(y_b, y_a)
+    assert len(head.decoder._engines) == 1
+    head.load_state_dict(head.state_dict())                            # (re)loading weights must drop the cached plan
+    assert len(head.decoder._engines) == 0
+
+
+def test_inference_single_image_surface():
+    """Upstream MOTR's per-frame entry (MOTR/models/motr.py:580-598) over the temporal engine: first call with
+    track_instances=None, then the returned Instances is handed back; ids persist, boxes come in original-image pixels."""
+    cfg, arch, sd = fixture("tiny")
+    model = M.TrackingModel(cfg["depth"], cfg["width"], cfg["nc"], cfg["nq"]).load_reference(sd)
+    ori = (480, 800)
+    ti, seen = None, []
+    for t in range(4):
+        x = net_input(cfg, t, 1).to(DEV)
+        r = model.inference_single_image(x, ori, ti, track_slots=32)
+        torch.cuda.synchronize()
+        assert set(r) == {"track_instances", "ref_pts"}
+        ti = r["track_instances"]
+        n = len(ti.obj_idxes)
+        assert ti.boxes.shape == (n, 4) and ti.scores.shape == (n,) and ti.labels.shape == (n,) and ti.query_pos.shape == (n, 256)
+        if n:
+            b = ti.boxes.cpu()
+            pb = ti.pred_boxes.cpu()
+            assert torch.allclose(b[:, 2] - b[:, 0], pb[:, 2] * ori[1], atol=1e-3) and torch.allclose(b[:, 3] - b[:, 1], pb[:, 3] * ori[0], atol=1e-3)
+            assert len(set(ti.obj_idxes.tolist())) == n and int(ti.obj_idxes.min()) >= 0
+        assert r["ref_pts"].shape == (32 + cfg["nq"], 2)
+        seen.append(set(ti.obj_idxes.tolist()))
+    assert seen[0] and seen[0] & seen[1], "tracks born in frame 0 must survive into frame 1 with their ids"
+    with pytest.raises(ValueError):
+        model.inference_single_image(net_input(cfg, 0, 1).to(DEV), ori, M.Instances((1, 1)))
+    r0 = model.inference_single_image(net_input(cfg, 0, 1).to(DEV), ori, None, track_slots=32)    # None restarts the sequence
+    assert set(r0["track_instances"].obj_idxes.tolist()) == seen[0]
+
+
+def test_native_op_module_name_and_autograd_function_as_the_reference_binds_it():
+    """`import MultiScaleDeformableAttention as MSDA` + an autograd Function written exactly like the reference's
+    (MOTR/models/ops/functions/ms_deform_attn_func.py:21-41) drive libmoyolo's forward AND backward; checked against the torch
+    formulation of the same op (:44-64 there, restated in the oracle)."""
+    import MultiScaleDeformableAttention as MSDA
+    from torch.autograd import Function
+    from torch.autograd.function import once_differentiable
+
+    class MSDeformAttnFunction(Function):
+        @staticmethod
+        def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights, im2col_step):
+            ctx.im2col_step = im2col_step
+            output = MSDA.ms_deform_attn_forward(
+                value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights, ctx.im2col_step)
+            ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights)
+            return output
+
+        @staticmethod
+        @once_differentiable
+        def backward(ctx, grad_output):
+            value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights = ctx.saved_tensors
+            grad_value, grad_sampling_loc, grad_attn_weight = \
+                MSDA.ms_deform_attn_backward(
+                    value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights, grad_output, ctx.im2col_step)
+            return grad_value, None, None, grad_sampling_loc, grad_attn_weight, None
+
+    g = torch.Generator().manual_seed(3)
+    N, Mh, D, Lq, P = 2, 8, 32, 19, 4
+    shapes = torch.tensor([(12, 20), (6, 10), (3, 5)], dtype=torch.long)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    value = (torch.rand(N, S, Mh, D, generator=g) * 0.01)
+    loc = torch.rand(N, Lq, Mh, 3, P, 2, generator=g) * 1.2 - 0.1
+    aw = torch.rand(N, Lq, Mh, 3, P, generator=g) + 1e-5
+    aw = aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    v_d, l_d, a_d = (t.to(DEV).requires_grad_(True) for t in (value, loc, aw))
+    out = MSDeformAttnFunction.apply(v_d, shapes.to(DEV), lsi.to(DEV), l_d, a_d, 64)
+    go = torch.rand(out.shape, generator=g) - 0.5
+    out.backward(go.to(DEV))
+    v_c, l_c, a_c = (t.clone().requires_grad_(True) for t in (value, loc, aw))
+    ref = O.msda_core(v_c, [tuple(s) for s in shapes.tolist()], l_c, a_c)
+    ref.backward(go)
+    assert torch.allclose(out.detach().cpu(), ref.detach(), rtol=1e-2, atol=1e-3)       # the reference's own fp32 bar (ops/test.py:60)
+    assert torch.allclose(v_d.grad.cpu(), v_c.grad, rtol=1e-2, atol=1e-5)
+    assert torch.allclose(l_d.grad.cpu(), l_c.grad, rtol=1e-2, atol=1e-5)
+    assert torch.allclose(a_d.grad.cpu(), a_c.grad, rtol=1e-2, atol=1e-5)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, aw, 64)
+
+
 def test_qim_update_track_embedding_vs_golden():
     """QueryInteractionModule._update_track_embedding (qim.py:251-301), isolated, vs reference output."""
     _, arch, sd = fixture("tiny")

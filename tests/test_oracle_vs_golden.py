@@ -190,3 +190,34 @@ def test_resize_oracle_known_answers():
     assert np.array_equal(area, ((v[0::2, 0::2] + v[0::2, 1::2] + v[1::2, 0::2] + v[1::2, 1::2] + 2) >> 2))
     up = resize_linear_u8(r, (33, 40))
     assert up.shape == (33, 40, 3) and up.min() >= r.min() and up.max() <= r.max()     # convex taps stay in range
+
+
+def test_state_machine_copy_half_and_fsqm_vs_reference_pins():
+    """Rows a16 (copy half) + a17 pinned by the reference itself (tests/golden/state.npz, make_golden.py: dump_state):
+    `tracker_update_copy` against what RuntimeTrackerBase.update returned (head.py:1245-1283, greedy IoU filter
+    :1155-1196 incl. clustered boxes that it really suppresses), `FSQMOracle` against the reference FSQM's memory after every
+    frame of a many-birth stream (fsqm.py:51-180; the id pool that grows by recycled -1 ids included)."""
+    g = golden("state")
+    for c in range(int(g["unit_cases"])):
+        sc, bx = g[f"unit{c}.scores"], g[f"unit{c}.boxes"]
+        ids, _, nxt = O.assign_ids_loop(torch.from_numpy(sc))
+        assert ids == g[f"unit{c}.obj_idxes"].tolist()
+        rows, nid = O.tracker_update_copy(sc.tolist(), bx, ids)
+        assert nid == g[f"unit{c}.copy_ids"].tolist(), c
+        assert np.array_equal(bx[rows], g[f"unit{c}.copy_boxes"])
+        assert (max(nid) + 1 if nid else nxt) == int(g[f"unit{c}.max_obj_id"])
+    fs = O.FSQMOracle(300, 256)
+    used = 0
+    for t in range(int(g["frames"])):
+        sc, bx, ids, hs = g[f"{t}.scores"], g[f"{t}.boxes"], g[f"{t}.obj_idxes"], g[f"{t}.hs"]
+        assert O.assign_ids(torch.from_numpy(sc)).tolist() == ids.tolist()
+        rows, nid = O.tracker_update_copy(sc.tolist(), bx, ids.tolist())
+        assert nid == g[f"{t}.copy_ids"].tolist() and np.array_equal(bx[rows], g[f"{t}.copy_boxes"])
+        det = (sc[rows], bx[rows], hs[rows]) if rows else (sc, bx, hs)      # no active row: FSQM gets the full Instances
+        fs.online_update(det[0], det[1], det[2], sc, bx, ids)
+        assert np.array_equal(fs.ids, g[f"{t}.fsqm.ids"]) and np.array_equal(fs.low, g[f"{t}.fsqm.low"]), t
+        assert np.array_equal(fs.conf, g[f"{t}.fsqm.conf"]) and np.array_equal(fs.boxes, g[f"{t}.fsqm.boxes"])
+        assert np.array_equal(fs.mem, g[f"{t}.fsqm.mem"])
+        assert fs.pool == g[f"{t}.fsqm.pool"].tolist()
+        used = int((fs.ids >= 0).sum())
+    assert used > 20, "the stream must really fill the memory"
