@@ -392,6 +392,19 @@ int moy_cast_f32_to(const float* src, int64_t lds, int M, int N, void* dst, int6
 /* out fp32 [M, 4] = sigmoid(in fp32 [M, 4])  (refer_bbox.sigmoid(), transformer.py:694; enc_bboxes head.py:1080) */
 int moy_sigmoid_f32(const float* in, int n, float* out, void* stream);
 
+/* Upstream MSDeformAttn.forward between its linears and the native op (MOTR/models/ops/modules/ms_deform_attn.py:98-116; used by
+ * MOTRDeformableTransformerEncoderLayer, MOTR/models/deformable_transformer_plus.py:347-386):
+ *   offaw fp32 [rows, ld]: columns [col_off, +M*L*P*2) = sampling_offsets(query), [col_aw, +M*L*P) = attention_weights(query)
+ *   ref fp32 [rows, L, refdim], refdim 2 (points) or 4 (boxes); shapes_hw HOST int32 [L, 2] (H_l, W_l)
+ *   aw[row, m, l, p]  = softmax over the L*P samples of head m (sigmoid_attn != 0: sigmoid)
+ *   loc[row, m, l, p] = ref[l] + off / (W_l, H_l)                  (refdim 2)
+ *                     = ref[l].xy + off / P * ref[l].wh * 0.5      (refdim 4)
+ * loc / aw: T = fp32 or bf16, dense, in the layout moy_msda_fwd_* takes. */
+int moy_msda_prep(const float* offaw, int64_t ld, int col_off, int col_aw, const float* ref, int refdim, int rows, int n_heads,
+                  int n_levels, int n_points, const int32_t* shapes_hw, int sigmoid_attn, void* loc, void* aw, int dtype, void* stream);
+/* x T [M, N] (ld): rows with mask[m] != 0 are zeroed (value.masked_fill_(input_padding_mask[..., None], 0), ms_deform_attn.py:95-96). */
+int moy_mask_rows(void* x, int64_t ld, int M, int N, const uint8_t* mask, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

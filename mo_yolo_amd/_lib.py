@@ -81,6 +81,8 @@ SIGNATURES = {
     "moy_gather_rows": (C.c_int, [vp, i64, vp, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
     "moy_cast_f32_to": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
     "moy_sigmoid_f32": (C.c_int, [vp, C.c_int, vp, vp]),
+    "moy_msda_prep": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]),
+    "moy_mask_rows": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, C.c_int, vp]),
 }
 
 _lib = None

@@ -1388,6 +1388,57 @@ inline unsigned nblk(long total, int per = 256) { return (unsigned)((total + per
 
 using namespace moy;
 
+// ------------------------------------------------------------------------------------------------
+// Upstream MSDeformAttn (MOTR/models/ops/modules/ms_deform_attn.py:83-121), the part between its linears and the native op:
+// softmax (or sigmoid) of the attention logits over the L*P samples of a head and the sampling locations
+//   2-d reference points: loc = ref[l] + offset / (W_l, H_l);   4-d boxes: loc = ref[l].xy + offset / P * ref[l].wh * 0.5.
+// One thread per (query row, head); offsets and logits are two column ranges of one fp32 GEMM output row.
+struct PrepLevels { int h[8], w[8]; };
+template <typename T>
+__global__ __launch_bounds__(256) void msda_prep_kernel(const float* __restrict__ offaw, int64_t ld, int col_off, int col_aw,
+                                                        const float* __restrict__ ref, int refdim, int rows, int M, int L, int P,
+                                                        PrepLevels lv, int sigmoid_attn, T* __restrict__ loc, T* __restrict__ aw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * M) return;
+  const int row = i / M, m = i - row * M;
+  const int LP = L * P;
+  const float* lg = offaw + (int64_t)row * ld + col_aw + m * LP;
+  const float* of = offaw + (int64_t)row * ld + col_off + m * LP * 2;
+  float mx = -3.4e38f;
+  for (int k = 0; k < LP; ++k) mx = fmaxf(mx, lg[k]);
+  float den = 0.f;
+  for (int k = 0; k < LP; ++k) den += expf(lg[k] - mx);
+  typename AccOf<T>::type* dummy = nullptr; (void)dummy;
+  for (int l = 0; l < L; ++l) {
+    const float* rf = ref + ((int64_t)row * L + l) * refdim;
+    for (int p = 0; p < P; ++p) {
+      const int k = l * P + p;
+      const float a = sigmoid_attn ? sigmoidf_(lg[k]) : expf(lg[k] - mx) / den;
+      float x, y;
+      if (refdim == 2) {
+        x = rf[0] + of[2 * k] / (float)lv.w[l];
+        y = rf[1] + of[2 * k + 1] / (float)lv.h[l];
+      } else {
+        x = rf[0] + of[2 * k] / (float)P * rf[2] * 0.5f;
+        y = rf[1] + of[2 * k + 1] / (float)P * rf[3] * 0.5f;
+      }
+      const int64_t o = (int64_t)i * LP + k;
+      DT<T>::store1(aw + o, a);
+      DT<T>::store1(loc + 2 * o, x);
+      DT<T>::store1(loc + 2 * o + 1, y);
+    }
+  }
+}
+
+// value.masked_fill_(input_padding_mask[..., None], 0) (ms_deform_attn.py:95-96): rows with mask != 0 become zero
+template <typename T>
+__global__ __launch_bounds__(256) void mask_rows_kernel(T* __restrict__ x, int64_t ld, int M, int NC, const uint8_t* __restrict__ mask) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)M * NC) return;
+  const int row = (int)(i / NC), c = (int)(i - (long)row * NC);
+  if (mask[row]) *reinterpret_cast<u32x4*>(x + (int64_t)row * ld + c * DT<T>::KPB) = u32x4{0u, 0u, 0u, 0u};
+}
+
 #define MOY_DISPATCH_T(dtype, ...)                          \
   if ((dtype) == MOY_F32) { using T = float; __VA_ARGS__ }  \
   else if ((dtype) == MOY_BF16) { using T = bf16_t; __VA_ARGS__ } \
@@ -1827,3 +1878,35 @@ extern "C" int moy_sigmoid_f32(const float* in, int n, float* out, void* stream)
   hipLaunchKernelGGL(sigmoid_kernel, dim3(nblk(n)), dim3(256), 0, static_cast<hipStream_t>(stream), in, n, out);
   return launch_status();
 }
+
+extern "C" int moy_msda_prep(const float* offaw, int64_t ld, int col_off, int col_aw, const float* ref, int refdim, int rows,
+                             int n_heads, int n_levels, int n_points, const int32_t* shapes_hw, int sigmoid_attn, void* loc,
+                             void* aw, int dtype, void* stream) {
+  if (!offaw || !ref || !loc || !aw || !shapes_hw || rows <= 0 || n_heads <= 0 || n_levels <= 0 || n_levels > 8 || n_points <= 0)
+    return MOY_EINVAL;
+  if (refdim != 2 && refdim != 4) return MOY_EINVAL;
+  if (dtype != MOY_F32 && dtype != MOY_BF16) return MOY_ENOSYS;    // the operator entries that consume loc / aw: fp32, bf16 (fp64: moy_msda_fwd_f64 takes caller-made operands)
+  PrepLevels lv{};
+  for (int l = 0; l < n_levels; ++l) { lv.h[l] = shapes_hw[2 * l]; lv.w[l] = shapes_hw[2 * l + 1]; if (lv.h[l] <= 0 || lv.w[l] <= 0) return MOY_EINVAL; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned blocks = (unsigned)(((long)rows * n_heads + 255) / 256);
+  if (dtype == MOY_F32)
+    hipLaunchKernelGGL((msda_prep_kernel<float>), dim3(blocks), dim3(256), 0, st, offaw, ld, col_off, col_aw, ref, refdim, rows, n_heads,
+                       n_levels, n_points, lv, sigmoid_attn, static_cast<float*>(loc), static_cast<float*>(aw));
+  else
+    hipLaunchKernelGGL((msda_prep_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, offaw, ld, col_off, col_aw, ref, refdim, rows, n_heads,
+                       n_levels, n_points, lv, sigmoid_attn, static_cast<bf16_t*>(loc), static_cast<bf16_t*>(aw));
+  return launch_status();
+}
+
+extern "C" int moy_mask_rows(void* x, int64_t ld, int M, int N, const uint8_t* mask, int dtype, void* stream) {
+  if (!x || !mask || M <= 0 || N <= 0 || !aligned16(x)) return MOY_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MOY_DISPATCH_T(dtype, {
+    constexpr int KPB = DT<T>::KPB;
+    if ((N % KPB) || (ld % KPB)) return MOY_EINVAL;
+    hipLaunchKernelGGL((mask_rows_kernel<T>), dim3(nblk((long)M * (N / KPB))), dim3(256), 0, st, static_cast<T*>(x), ld, M, N / KPB, mask);
+    return launch_status();
+  })
+}
+

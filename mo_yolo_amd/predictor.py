@@ -98,10 +98,14 @@ class TrackPredictor:
         eng = self._engine(fmt, orig_hw)
         results: List[TrackResults] = []
         n = x.shape[0]
+        if self.temporal and n % self.batch:
+            # batch element b is SEQUENCE b with persistent query memory: padding a short chunk with another sequence's frame
+            # would advance the memory, id counter and miss counters of the padded sequences
+            raise ValueError(f"temporal mode: the source must hold whole time steps ({self.batch} sequences per step), got {n} frames")
         for s in range(0, n, self.batch):
             chunk = x[s:s + self.batch]
             k = chunk.shape[0]
-            if k < self.batch:                                     # ragged tail: pad with the last frame
+            if k < self.batch:                                     # ragged tail (per-frame mode only): pad with the last frame
                 chunk = torch.cat([chunk, chunk[-1:].expand(self.batch - k, *chunk.shape[1:])], 0)
             if fmt == "u8" and orig_hw != self.imgsz:
                 ops.resize_linear_u8(chunk.contiguous(), self.imgsz, out=eng.input)

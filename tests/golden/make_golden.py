@@ -658,6 +658,59 @@ def dump_state():
     np.savez_compressed(os.path.join(HERE, "state.npz"), **out)
 
 
+def dump_encoder():
+    """SURVEY §8(f) rank 4, second half: the upstream deformable ENCODER (MOTR/models/deformable_transformer_plus.py:347-415)
+    evaluated by the reference itself with its torch formulation of the native op (`ms_deform_attn_core_pytorch`,
+    ops/functions/ms_deform_attn_func.py:44-64, in place of the un-built CUDA extension)."""
+    ref_shim.install()
+    import MOTR.models.deformable_transformer_plus as dtp
+    import MOTR.models.ops.modules.ms_deform_attn as msmod
+    from MOTR.models.ops.functions.ms_deform_attn_func import ms_deform_attn_core_pytorch
+
+    class _TorchOp:
+        @staticmethod
+        def apply(value, shapes, lsi, loc, aw, step):
+            return ms_deform_attn_core_pytorch(value, shapes, loc, aw)
+    msmod.MSDeformAttnFunction = _TorchOp
+    out = {}
+    for case, (nl, nh, npnt, nlayers, sig, masked, N, shapes) in {
+            "enc3": (3, 8, 4, 2, False, False, 2, [(12, 20), (6, 10), (3, 5)]),
+            "enc4_mask_sigmoid": (4, 8, 4, 1, True, True, 1, [(9, 7), (5, 4), (3, 2), (2, 1)])}.items():
+        g = torch.Generator().manual_seed(40 + nl)
+        layer = dtp.MOTRDeformableTransformerEncoderLayer(256, 1024, 0.1, "relu", nl, nh, npnt, sigmoid_attn=sig)
+        enc = dtp.DeformableTransformerEncoder(layer, nlayers).eval()
+        with torch.no_grad():                    # de-degenerate the zero-initialised offset / attention weights (SURVEY App. G)
+            for k, v in enc.state_dict().items():
+                if "sampling_offsets.weight" in k:
+                    v.copy_((torch.rand(v.shape, generator=g) - 0.5) * 0.1)
+                elif "attention_weights" in k:
+                    v.copy_((torch.rand(v.shape, generator=g) - 0.5) * 1.0)
+                elif k.endswith("bias") and "sampling_offsets" not in k:
+                    v.copy_((torch.rand(v.shape, generator=g) - 0.5) * 0.1)
+                elif "norm" in k and k.endswith("weight"):
+                    v.copy_(0.8 + 0.4 * torch.rand(v.shape, generator=g))
+        shp = torch.tensor(shapes, dtype=torch.long)
+        lsi = torch.cat((shp.new_zeros((1,)), shp.prod(1).cumsum(0)[:-1]))
+        S = int(shp.prod(1).sum())
+        src = torch.randn(N, S, 256, generator=g)
+        pos = torch.randn(N, S, 256, generator=g) * 0.5
+        vr = 0.7 + 0.3 * torch.rand(N, nl, 2, generator=g)
+        mask = (torch.rand(N, S, generator=g) < 0.15) if masked else None
+        with torch.no_grad():
+            y = enc(src, shp, lsi, vr, pos, mask)
+            y1 = enc.layers[0](src, pos, enc.get_reference_points(shp, vr, device=src.device), shp, lsi, mask)
+        for k, v in enc.state_dict().items():
+            out[f"{case}.sd.{k}"] = v.numpy().copy()
+        out[f"{case}.cfg"] = np.array([nl, nh, npnt, nlayers, int(sig)])
+        out[f"{case}.shapes"] = shp.numpy(); out[f"{case}.src"] = src.numpy(); out[f"{case}.pos"] = pos.numpy()
+        out[f"{case}.valid_ratios"] = vr.numpy()
+        if mask is not None:
+            out[f"{case}.mask"] = mask.numpy()
+        out[f"{case}.out"] = y.numpy(); out[f"{case}.layer0_out"] = y1.numpy()
+        print(f"[encoder {case}] S {S}, out std {float(y.std()):.3f}")
+    np.savez_compressed(os.path.join(HERE, "encoder.npz"), **out)
+
+
 def dump_hota():
     """HOTA of the reference evaluator (utils/hota.py:24-164) on synthetic GT vs jittered tracks."""
     ref_shim.install()
@@ -701,7 +754,7 @@ def dump_hota():
 
 
 def main():
-    which = sys.argv[1:] or ["tiny", "tiny3", "c2", "c4", "c1", "msda", "qim", "hota", "state"]
+    which = sys.argv[1:] or ["tiny", "tiny3", "c2", "c4", "c1", "msda", "qim", "hota", "state", "encoder"]
     cal = {}
     for name in which:
         if name in CONFIGS:
@@ -719,6 +772,8 @@ def main():
         dump_hota()
     if "state" in which:
         dump_state()
+    if "encoder" in which:
+        dump_encoder()
 
 
 if __name__ == "__main__":

@@ -238,6 +238,37 @@ def test_native_op_module_name_and_autograd_function_as_the_reference_binds_it()
         MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, aw, 64)
 
 
+@pytest.mark.parametrize("case", ["enc3", "enc4_mask_sigmoid"])
+def test_upstream_deformable_encoder_vs_reference_golden(case):
+    """DeformableTransformerEncoder / MOTRDeformableTransformerEncoderLayer / upstream MSDeformAttn
+    (MOTR/models/deformable_transformer_plus.py:347-415, ops/modules/ms_deform_attn.py:30-121) under the reference's class
+    names and state_dict keys, against the reference's own outputs (torch formulation of the op; tests/golden/encoder.npz):
+    2-d reference points with valid ratios, position embedding, padding mask, softmax and sigmoid attention."""
+    from mo_yolo_amd import motr_upstream as U
+    g = golden("encoder")
+    nl, nh, npnt, nlayers, sig = (int(v) for v in g[f"{case}.cfg"])
+    layer = U.MOTRDeformableTransformerEncoderLayer(256, 1024, 0.1, "relu", nl, nh, npnt, sigmoid_attn=bool(sig))
+    enc = U.DeformableTransformerEncoder(layer, nlayers)
+    sd = {k[len(case) + 4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(case + ".sd.")}
+    enc.load_state_dict(sd, strict=True)                                   # the reference's keys, strictly
+    enc = enc.to(DEV)
+    shp = torch.from_numpy(g[f"{case}.shapes"])
+    lsi = torch.cat((shp.new_zeros((1,)), shp.prod(1).cumsum(0)[:-1]))
+    src, pos = torch.from_numpy(g[f"{case}.src"]).to(DEV), torch.from_numpy(g[f"{case}.pos"]).to(DEV)
+    vr = torch.from_numpy(g[f"{case}.valid_ratios"]).to(DEV)
+    mask = torch.from_numpy(g[f"{case}.mask"]).to(DEV) if f"{case}.mask" in g else None
+    y = enc(src, shp.to(DEV), lsi.to(DEV), vr, pos, mask)
+    ref_pts = enc.get_reference_points(shp, vr, device=DEV)
+    y1 = enc.layers[0](src, pos, ref_pts, shp.to(DEV), lsi.to(DEV), mask)
+    torch.cuda.synchronize()
+    assert torch.allclose(y1.cpu(), torch.from_numpy(g[f"{case}.layer0_out"]), atol=2e-4, rtol=1e-4)
+    assert torch.allclose(y.cpu(), torch.from_numpy(g[f"{case}.out"]), atol=5e-4, rtol=1e-4)
+    yb = enc(src.bfloat16(), shp.to(DEV), lsi.to(DEV), vr, pos.bfloat16(), mask)             # 16-bit path: stated bar
+    assert float((yb.float().cpu() - torch.from_numpy(g[f"{case}.out"])).abs().max()) < 0.15
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        enc.layers[0].self_attn(src.cpu(), ref_pts.cpu(), src.cpu(), shp, lsi)
+
+
 def test_qim_update_track_embedding_vs_golden():
     """QueryInteractionModule._update_track_embedding (qim.py:251-301), isolated, vs reference output."""
     _, arch, sd = fixture("tiny")
