@@ -672,12 +672,13 @@ def dump_encoder():
         def apply(value, shapes, lsi, loc, aw, step):
             return ms_deform_attn_core_pytorch(value, shapes, loc, aw)
     msmod.MSDeformAttnFunction = _TorchOp
-    out = {}
+    D_FFN = 256                                  # (keeps the stored reference weights small)
+    out = {"d_ffn": np.array(D_FFN)}
     for case, (nl, nh, npnt, nlayers, sig, masked, N, shapes) in {
             "enc3": (3, 8, 4, 2, False, False, 2, [(12, 20), (6, 10), (3, 5)]),
             "enc4_mask_sigmoid": (4, 8, 4, 1, True, True, 1, [(9, 7), (5, 4), (3, 2), (2, 1)])}.items():
         g = torch.Generator().manual_seed(40 + nl)
-        layer = dtp.MOTRDeformableTransformerEncoderLayer(256, 1024, 0.1, "relu", nl, nh, npnt, sigmoid_attn=sig)
+        layer = dtp.MOTRDeformableTransformerEncoderLayer(256, D_FFN, 0.1, "relu", nl, nh, npnt, sigmoid_attn=sig)
         enc = dtp.DeformableTransformerEncoder(layer, nlayers).eval()
         with torch.no_grad():                    # de-degenerate the zero-initialised offset / attention weights
             for k, v in enc.state_dict().items():

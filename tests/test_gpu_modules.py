@@ -247,7 +247,7 @@ def test_upstream_deformable_encoder_vs_reference_golden(case):
     from mo_yolo_amd import motr_upstream as U
     g = golden("encoder")
     nl, nh, npnt, nlayers, sig = (int(v) for v in g[f"{case}.cfg"])
-    layer = U.MOTRDeformableTransformerEncoderLayer(256, 1024, 0.1, "relu", nl, nh, npnt, sigmoid_attn=bool(sig))
+    layer = U.MOTRDeformableTransformerEncoderLayer(256, int(g["d_ffn"]), 0.1, "relu", nl, nh, npnt, sigmoid_attn=bool(sig))
     enc = U.DeformableTransformerEncoder(layer, nlayers)
     sd = {k[len(case) + 4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(case + ".sd.")}
     enc.load_state_dict(sd, strict=True)                                   # the reference's keys, strictly
