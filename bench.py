@@ -354,11 +354,13 @@ def main(argv=None):
             torch.cuda.synchronize()
             parity = {"bench_engine_vs_fp32_engine": engine_pair_stats(got, want, arch.nq),
                       "frames": NP, "bench_engine": f"{dtype_name} B={Bs}", "reference_engine": f"f32 B={NP}"}
-            bars = {"f32": (1e-3, 1e-3, 0.0), "f16": (0.02, 0.05, 0.1), "bf16": (0.08, 0.3, 0.35)}[dtype_name]
+            # bars = the 2 x 600-frame measurements of profiles/parity_r02.json (tools/parity_stream.py) with ~2x margin
+            bars = {"f32": (1e-4, 1e-3, 1e-3, 0.0), "f16": (3e-4, 0.03, 0.06, 0.03), "bf16": (1.5e-3, 0.1, 0.4, 0.12)}[dtype_name]
             st_ = parity["bench_engine_vs_fp32_engine"]
-            parity["bars"] = {"box_matched": bars[0], "score_matched": bars[1], "birth_flip_frac_of_active": bars[2]}
-            parity["ok"] = bool(st_["box_max_err_matched"] <= bars[0] and st_["score_max_err_matched"] <= bars[1]
-                                and st_["birth_flip_frac_of_active"] <= bars[2] and n_masked == 0)
+            parity["bars"] = {"box_matched": bars[0], "hs_matched": bars[1], "score_matched": bars[2], "birth_flip_frac_of_active": bars[3]}
+            parity["ok"] = bool(st_["box_max_err_matched"] <= bars[0] and st_["hs_max_err_matched"] <= bars[1]
+                                and st_["score_max_err_matched"] <= bars[2]
+                                and (st_["birth_flip_frac_of_active"] <= bars[3] or st_["births_flipped"] <= 2) and n_masked == 0)
 
             def engine_check(keep):
                 """fp32 engine vs the CPU oracle on the oracle's own frames: logits <= 1e-3, ids exact (given the same selection)."""

@@ -208,32 +208,31 @@ def test_engine_fp16_c5_batched_sequences_graph():
     assert float(db) < 0.02 and float(ds) < 0.1
 
 
-@pytest.mark.parametrize("name", ["tiny", "c2"])
-def test_engine_bf16_close_to_oracle(name):
-    """bf16 activations/weights with fp32 accumulation: not a parity path; stated bars on boxes and
-    scores with the oracle's query order injected, plus the id flip count (reported, bounded)."""
+@pytest.mark.parametrize("name,dt", [("tiny", torch.bfloat16), ("c2", torch.bfloat16), ("c2", torch.float16)])
+def test_engine_16bit_close_to_oracle(name, dt):
+    """16-bit activations/weights with fp32 accumulation, FREE RUNNING (own top-k), against the free-running oracle on the
+    fixture frames.  Bars = the measurements of the 2 x 600-frame study (tools/parity_stream.py -> profiles/parity_r02.json:
+    bf16 box 4.7e-4 / decoder output 0.049 / score 0.20 / births flipped 4.0 % of the active rows / top-k overlap 0.975;
+    fp16 8.6e-5 / 0.012 / 0.025 / 0.6 % / 0.997) with a margin of about 2x.  The score bar is loose by construction: the fixture's
+    last score head amplifies the decoder output ~100x, the decoder output itself is the tight check."""
+    from mo_yolo_amd.parity import engine_pair_stats
     cfg, arch, sd = fixture(name)
-    B = 2
-    eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=torch.bfloat16)
+    B = min(4, cfg["frames"])
+    eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt)
     fr = torch.from_numpy(frames_u8(cfg, 0, B)).to(DEV)
     with torch.no_grad():
         r = O.forward(net_input(cfg, 0, B), sd, arch)
-    out = eng.forward_with_topk(fr, r["topk_ind"])
+    out = eng.forward(fr)
     torch.cuda.synchronize()
-    assert torch.isfinite(out["y"]).all()
-    db = float((out["boxes"].cpu() - r["dec_bboxes"]).abs().max())
-    ds = float((out["scores"].cpu() - r["dec_scores"].sigmoid().max(-1).values).abs().max())
-    ids = O.assign_ids(r["dec_scores"].sigmoid().max(-1).values)
-    flips = int(((out["obj_idxes"].cpu() >= 0) != (ids >= 0)).sum())
-    print(f"[bf16 {name}] max box err {db:.4f} max score err {ds:.4f} birth flips {flips}/{ids.numel()}")
-    assert db < 0.05 and ds < 0.25 and flips <= max(2, ids.numel() // 50)
-    # the free-running bf16 engine (its own top-k) must select mostly the same tokens
-    out2 = eng.forward(fr)
-    torch.cuda.synchronize()
-    same = np.mean([len(set(a.tolist()) & set(b.tolist())) / arch.nq
-                    for a, b in zip(out2["topk_ind"].cpu().numpy(), r["topk_ind"].numpy())])
-    print(f"[bf16 {name}] top-k overlap {same:.3f}")
-    assert same > 0.8
+    assert torch.isfinite(out["y"]).all() and int(out["n_masked"].sum()) == 0
+    sc = r["dec_scores"].sigmoid().max(-1).values
+    st = engine_pair_stats({k: v.clone() for k, v in out.items() if hasattr(v, "shape") and v.shape[:1] == (B,)},
+                           dict(topk_ind=r["topk_ind"], boxes=r["dec_bboxes"], scores=sc, obj_idxes=O.assign_ids(sc), hs=r["hs"]), arch.nq)
+    print(f"[{dt} {name}] {st}")
+    bars = {torch.bfloat16: (1.5e-3, 0.1, 0.4, 0.10, 0.94), torch.float16: (3e-4, 0.03, 0.06, 0.02, 0.99)}[dt]
+    assert st["box_max_err_matched"] < bars[0] and st["hs_max_err_matched"] < bars[1] and st["score_max_err_matched"] < bars[2], st
+    assert st["birth_flip_frac_of_active"] <= bars[3] or st["births_flipped"] <= 2, st
+    assert st["topk_overlap"] > bars[4], st
 
 
 def test_engine_graph_replay_matches_eager():
@@ -271,11 +270,11 @@ def test_streamed_engines_equal_single_engine():
 
 def test_hota_parity_on_synthetic_stream():
     """BASELINE metric, HOTA half: HOTA of the build's tracks vs HOTA of the oracle's tracks on the
-    same synthetic ground truth, with the reference evaluator's algorithm.  fp32: identical;
-    bf16: reported, bounded (stated bar: 2 HOTA points on the 0-100 scale)."""
+    same synthetic ground truth, with the reference evaluator's algorithm, on the fixture frames (the 2 x 600-frame figures are in
+    profiles/parity_r02.json)."""
     from tests._util import hota_of_tracks
     cfg, arch, sd = fixture("c2")
-    T = 6
+    T = 8
     fr = torch.from_numpy(frames_u8(cfg, 0, T)).to(DEV)
 
     def tracks(out):
@@ -305,7 +304,9 @@ def test_hota_parity_on_synthetic_stream():
     d32 = abs(float(np.mean(res[torch.float32]["HOTA"])) - float(np.mean(h_ref["HOTA"]))) * 100
     d16 = abs(float(np.mean(res[torch.bfloat16]["HOTA"])) - float(np.mean(h_ref["HOTA"]))) * 100
     print(f"HOTA ref {100 * np.mean(h_ref['HOTA']):.3f}  fp32 delta {d32:.4f}  bf16 delta {d16:.4f}")
-    assert d32 <= 0.1 and d16 <= 2.0
+    # north-star bar: HOTA within 0.1 of the reference path.  fp32: identical.  bf16 over 2 x 600 frames: <= 0.02 points
+    # (profiles/parity_r02.json); on these 8 frames one flipped birth already moves HOTA by ~0.1, hence the wider small-sample bar
+    assert d32 <= 0.1 and d16 <= 0.3
 
 
 def test_side_state_copy_filter_and_fsqm_vs_oracle():
