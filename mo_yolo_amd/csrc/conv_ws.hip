@@ -22,6 +22,7 @@
 #include "common.hpp"
 
 #include <type_traits>
+#include <utility>
 
 namespace moy {
 
@@ -347,6 +348,470 @@ static int cws_num_cus() {
   return n;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined form of the kernel above.  Measured on the lock-step kernel (s_memtime stamps, MOY_CWS_ABL=5): per tile
+// the matrix pipe is busy ~9 200 cycles, but every wave also spends ~2 000 cycles in the BN + SiLU epilogue, ~1 900 issuing the
+// next tile's DMA pieces and ~900 in the store pass and barriers while the pipe idles -- 13 700 cycles per tile at C = 128.
+// Here a wave's work is cut into half-tiles (RG output rows): the epilogue of half h-1 (VALU, LDS) and the DMA pieces of the
+// next tile are interleaved, fragment by fragment, between the MFMA groups of half h, in ONE instruction stream (an MFMA
+// holds the vector issue for 8 of its 16 cycles, the epilogue fits in the rest); the two accumulator halves alternate, so no
+// extra registers are needed.  Staging is double buffered by tile parity (it lives in the buffer set, beside the patch), the
+// store pass of tile t-1 sits between the two halves of tile t.  Per tile: barrier A (staging of t-1 complete / residual of
+// t landed), barrier B (patch of t+1 landed, patch of t free).
+template <typename T, int C, int N, int TH, int WN, bool RES, int OCC, int STAG = 0>
+__global__ __launch_bounds__(512, 2 * OCC) void conv_ws_pipe_kernel(const ConvWsParams p) {
+  constexpr int PW = 18, PH = TH + 2, NPIX = PH * PW, CPP = C / 8, NCP = N / 8, TPX = TH * 16;
+  constexpr int PATCH_PIECES = (NPIX * CPP + 63) / 64, RES_PIECES = RES ? TPX * NCP / 64 : 0;
+  constexpr int IPW0 = (PATCH_PIECES + 7) / 8, IPW1 = RES_PIECES / 8;
+  constexpr int STGB = TPX * N * 2, SETB = PATCH_PIECES * 1024 + STGB;
+  constexpr int NPASS = TPX * NCP / 512;
+  constexpr int WM = 8 / WN, MT = TH / WM, NT = N / 16 / WN, KC = C / 32;
+  constexpr int RG = MT / 2, NG = 3 * KC;                  // rows per half, MFMA groups per half
+  constexpr uint32_t OOB = 0x80000000u;
+  static_assert(MT % 2 == 0 && TH % WM == 0 && (N / 16) % WN == 0 && TPX * NCP % 512 == 0 && RES_PIECES % 8 == 0, "tile vs waves");
+  static_assert(RG * NT <= NG && IPW0 <= NG, "the epilogue fragments / DMA pieces of a half must fit between its MFMA groups");
+  static_assert((2 * SETB + 1024) * OCC <= 160 * 1024, "LDS budget");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int wn = wave % WN, wm = wave / WN;
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int t_first = xcd * p.per_xcd + slot;
+  const int t_limit = min((xcd + 1) * p.per_xcd, p.ntiles);
+  if (t_first >= t_limit) return;
+  const int n_mine = (t_limit - t_first + p.bpx - 1) / p.bpx;
+
+  const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+  const uint32_t scratch = lds_base + 2 * SETB;
+  const T* __restrict__ Ag = static_cast<const T*>(p.A);
+  const T* __restrict__ Rg = static_cast<const T*>(p.R);
+  T* __restrict__ Cg = static_cast<T*>(p.C);
+  const int64_t img_a = (int64_t)p.H * p.Wd * p.lda, img_r = (int64_t)p.H * p.Wd * p.ldr, img_c = (int64_t)p.H * p.Wd * p.ldc;
+
+  struct Tile { int b, y0, x0; bool live; };
+  auto tile_of = [&](int it) {
+    Tile t;
+    t.live = it < n_mine;
+    const int id = min(t_first + it * p.bpx, p.ntiles - 1);
+    t.b = (int)fdiv((uint32_t)id, p.fd_timg);
+    const int rem = id - t.b * p.tiles_img;
+    const int ty = (int)fdiv((uint32_t)rem, p.fd_tx);
+    t.y0 = ty * TH;
+    t.x0 = (rem - ty * p.tiles_x) * 16;
+    return t;
+  };
+  // piece k of the patch of tile t -> LDS set `set` (pieces beyond the patch image: zeros into the scratch KiB, keeps the counts uniform)
+  auto patch_piece = [&](const Tile& t, int set, int k) {
+    const int pc = wave + 8 * k;
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    const int X = pc * 64 + lv, pix = X / CPP, sl = X % CPP;
+    const int py = pix / PW, px = pix - py * PW;
+    const int yy = t.y0 + py - 1, xx = t.x0 + px - 1;
+    const bool ok = t.live && pc < PATCH_PIECES && pix < NPIX && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.Wd;
+    const uint32_t voff = ok ? (uint32_t)(((yy * p.Wd + xx) * (int)p.lda + ((sl ^ cws_swz<C>(pix)) * 8)) * 2) : OOB;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Ag + (int64_t)t.b * img_a), 0, (uint32_t)(img_a * 2), 0x00020000);
+    cws_dma16(voff, rs, pc < PATCH_PIECES ? lds_base + set * SETB + pc * 1024 : scratch);
+  };
+  auto res_piece = [&](const Tile& t, int set, int k) {
+    const int pc = wave + 8 * k;
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    const int X = pc * 64 + lv, opx = X / NCP, sl = X % NCP;
+    const int yy = t.y0 + (opx >> 4), xx = t.x0 + (opx & 15);
+    const bool ok = t.live && yy < p.H && xx < p.Wd;
+    const uint32_t voff = ok ? (uint32_t)(((yy * p.Wd + xx) * (int)p.ldr + ((sl ^ (opx & (NCP - 1))) * 8)) * 2) : OOB;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>((RES ? Rg : Ag) + (int64_t)t.b * (RES ? img_r : img_a)), 0,
+                                                      (uint32_t)((RES ? img_r : img_a) * 2), 0x00020000);
+    cws_dma16(voff, rs, lds_base + set * SETB + PATCH_PIECES * 1024 + pc * 1024);
+  };
+
+  // weights / BN of this wave -> registers
+  u32x4 wf[NT][9][KC];
+  f32x4 sc[NT], sh[NT];
+  {
+    const T* Wg = static_cast<const T*>(p.W);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = (wn * NT + j) * 16;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int cc = 0; cc < KC; ++cc)
+          wf[j][tap][cc] = *reinterpret_cast<const u32x4*>(Wg + (int64_t)(n + r) * p.Kpad + tap * C + cc * 32 + q * 8);
+      sc[j] = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n + q * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+      sh[j] = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const int s_px = tid / NCP, s_c = tid % NCP;
+  const int s_ty = s_px >> 4, s_tx = s_px & 15;
+  const int s_lds = s_px * (N * 2) + ((s_c ^ (s_px & (NCP - 1))) * 16);
+  const int s_rel = ((s_ty * p.Wd + s_tx) * (int)p.ldc + s_c * 8) * 2;
+  constexpr int PASS_ROWS = 512 / NCP / 16, PASS_LDS = (512 / NCP) * N * 2;
+  const int s_pass_rel = PASS_ROWS * p.Wd * (int)p.ldc * 2;
+
+  // one fragment (4 channels x 16 pixels per lane group) of a finished half -> staging image of its tile
+  auto epi_frag = [&](const f32x4& a, int half, int y, int j, unsigned char* stg) {
+    const int ch = (wn * NT + j) * 16 + q * 4;
+    f32x4 v = a * sc[j] + sh[j];
+    v.x = siluf_(v.x); v.y = siluf_(v.y); v.z = siluf_(v.z); v.w = siluf_(v.w);
+    const int opx = (wm * MT + half * RG + y) * 16 + r;
+    unsigned char* cell = stg + opx * (N * 2) + ((((ch >> 3) ^ (opx & (NCP - 1))) * 16) + ((ch >> 2) & 1) * 8);
+    if (RES) {
+      const u32x2 res = *reinterpret_cast<const u32x2*>(cell);
+      v += f32x4{DT<T>::lo(res.x), DT<T>::hi(res.x), DT<T>::lo(res.y), DT<T>::hi(res.y)};
+    }
+    *reinterpret_cast<u32x2*>(cell) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+  };
+  // the MFMA groups of one half; between(gi) runs before group gi (compile-time gi)
+  const int pix0 = wm * MT * PW + r;
+  auto half_mfma = [&](auto half_c, const unsigned char* patch, f32x4 (&acc)[RG][NT], auto&& between) {
+    constexpr int half = decltype(half_c)::value;
+    int pixv = pix0 + half * RG * PW;
+    asm volatile("" : "+v"(pixv));
+#pragma unroll
+    for (int y = 0; y < RG; ++y)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    [&]<int... GI>(std::integer_sequence<int, GI...>) {
+      ([&] {
+        constexpr int kx = GI / KC, cc = GI % KC;
+        between(std::integral_constant<int, GI>{});
+        u32x4 a[RG + 2];
+#pragma unroll
+        for (int y = 0; y < RG + 2; ++y) {
+          const int pix = pixv + y * PW + kx;
+          a[y] = *reinterpret_cast<const u32x4*>(patch + pix * (C * 2) + (((cc * 4 + q) ^ cws_swz<C>(pix)) * 16));
+        }
+#pragma unroll
+        for (int y = 0; y < RG; ++y)
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[y][j] = cws_mfma<T>(acc[y][j], wf[j][ky * 3 + kx][cc], a[y + ky]);
+      }(), ...);
+    }(std::make_integer_sequence<int, NG>{});
+  };
+  auto store_pass = [&](const Tile& t, const unsigned char* stg, bool valid) {
+    const auto rsC = __builtin_amdgcn_make_buffer_rsrc(Cg + (int64_t)t.b * img_c, 0, (uint32_t)(img_c * 2), 0x00020000);
+    const int off_c = (t.y0 * p.Wd + t.x0) * (int)p.ldc * 2 + s_rel;
+    const bool xok = valid && t.x0 + s_tx < p.Wd;
+    u32x4 vv[NPASS];
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) vv[k] = *reinterpret_cast<const u32x4*>(stg + s_lds + k * PASS_LDS);
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {
+      const bool ok = xok && t.y0 + s_ty + k * PASS_ROWS < p.H;
+      __builtin_amdgcn_raw_buffer_store_b128(vv[k], rsC, ok ? (uint32_t)(off_c + k * s_pass_rel) : OOB, 0, 0);
+    }
+  };
+
+  // The two waves of a SIMD (w and w + 4) run the same stream: without an offset both sit in an epilogue block (VALU) at the same
+  // time and the matrix pipe idles, then both want it.  Waves 4-7 start every barrier interval STAG x 64 cycles late, so one
+  // wave's VALU block lies beside its partner's MFMA group (MI355X_MICROARCH.md, "two waves that run the same program: try a stagger").
+  auto stagger = [&]() {
+    if constexpr (STAG > 0) {
+      if (wave >= 4) __builtin_amdgcn_s_sleep(STAG);
+    }
+  };
+  // prologue: the first patch
+  {
+    const Tile t0 = tile_of(0);
+#pragma unroll
+    for (int k = 0; k < IPW0; ++k) patch_piece(t0, 0, k);
+    cws_wait_vmcnt<0>();
+    __syncthreads();
+  }
+  f32x4 accA[RG][NT], accB[RG][NT];
+#pragma unroll
+  for (int y = 0; y < RG; ++y)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) accB[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  Tile prev = tile_of(0);
+  for (int it = 0; it < n_mine; ++it) {
+    const int set = it & 1, pset = set ^ 1;
+    const Tile cur = tile_of(it), nxt = tile_of(it + 1);
+    unsigned char* patch = smem + set * SETB;
+    unsigned char* stg_cur = patch + PATCH_PIECES * 1024;
+    unsigned char* stg_prev = smem + pset * SETB + PATCH_PIECES * 1024;
+    if constexpr (RES) {
+#pragma unroll
+      for (int k = 0; k < IPW1; ++k) res_piece(cur, set, k);      // needed by the epilogue of this tile's first half (second half-time)
+    }
+    // ---- first half of tile `it`; between its groups: the epilogue of the previous tile's second half, the next tile's patch
+    half_mfma(std::integral_constant<int, 0>{}, patch, accA, [&](auto gi_c) {
+      constexpr int gi = decltype(gi_c)::value;
+      if constexpr (gi < IPW0) patch_piece(nxt, pset, gi);
+      if constexpr (gi < RG * NT) {
+        if (it > 0) epi_frag(accB[gi / NT][gi % NT], 1, gi / NT, gi % NT, stg_prev);
+      }
+    });
+    if constexpr (RES) cws_wait_vmcnt<IPW0>();                    // this tile's residual pieces (older than the IPW0 patch pieces)
+    __syncthreads();                                               // A: staging of tile it-1 complete, residual of tile it visible
+    stagger();
+    store_pass(prev, stg_prev, it > 0);
+    // ---- second half; between its groups: the epilogue of the first half
+    half_mfma(std::integral_constant<int, 1>{}, patch, accB, [&](auto gi_c) {
+      constexpr int gi = decltype(gi_c)::value;
+      if constexpr (gi < RG * NT) epi_frag(accA[gi / NT][gi % NT], 0, gi / NT, gi % NT, stg_cur);
+    });
+    cws_wait_vmcnt<NPASS>();                                       // the next patch has landed; the stores stay in flight
+    __syncthreads();                                               // B
+    stagger();
+    prev = cur;
+  }
+  // drain: the last tile's second half
+  {
+    unsigned char* stg_last = smem + ((n_mine - 1) & 1) * SETB + PATCH_PIECES * 1024;
+#pragma unroll
+    for (int f = 0; f < RG * NT; ++f) epi_frag(accB[f / NT][f % NT], 1, f / NT, f % NT, stg_last);
+    __syncthreads();
+    store_pass(prev, stg_last, true);
+  }
+  cws_wait_vmcnt<0>();
+}
+
+template <typename T, int C, int N, int TH, int WN, bool RES, int OCC = 1, int STAG = 0>
+static int launch_conv_ws_pipe(ConvWsParams& p, int B, hipStream_t st) {
+  constexpr int PATCH_PIECES = ((TH + 2) * 18 * (C / 8) + 63) / 64;
+  constexpr int LDS = 2 * (PATCH_PIECES * 1024 + TH * 16 * N * 2) + 1024;
+  if constexpr (STAG == 0 && OCC == 1) {
+    static int stag = -1;                  // MOY_CWS_STAG: A/B knob, delay of waves 4-7 after every barrier in units of 64 cycles
+    if (stag < 0) { const char* e = getenv("MOY_CWS_STAG"); stag = e ? atoi(e) : 0; }
+    if (stag == 2) return launch_conv_ws_pipe<T, C, N, TH, WN, RES, OCC, 2>(p, B, st);
+    if (stag == 4) return launch_conv_ws_pipe<T, C, N, TH, WN, RES, OCC, 4>(p, B, st);
+    if (stag == 8) return launch_conv_ws_pipe<T, C, N, TH, WN, RES, OCC, 8>(p, B, st);
+  }
+  auto kern = conv_ws_pipe_kernel<T, C, N, TH, WN, RES, OCC, STAG>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (LDS > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return MOY_ELAUNCH;
+    attr_set = true;
+  }
+  p.tiles_x = (p.Wd + 15) / 16;
+  const int tiles_y = (p.H + TH - 1) / TH;
+  p.tiles_img = p.tiles_x * tiles_y;
+  p.ntiles = B * p.tiles_img;
+  p.fd_timg = make_fastdiv((uint32_t)p.tiles_img);
+  p.fd_tx = make_fastdiv((uint32_t)p.tiles_x);
+  p.per_xcd = (p.ntiles + 7) / 8;
+  p.bpx = cws_num_cus() / 8 * OCC;
+  if (p.bpx < 1) p.bpx = 1;
+  if (p.bpx > p.per_xcd) p.bpx = p.per_xcd;
+  hipLaunchKernelGGL(kern, dim3(8 * p.bpx), dim3(512), LDS, st, p);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stride-2 member of the family (the down-sampling convs of the backbone / neck, yolo_track.yaml:18-24,35,41: Cin -> Cout, 3x3,
+// stride 2, pad 1).  Same structure as conv_ws_kernel; what changes is the patch:
+//   * an output tile of TH x 16 pixels needs (2 TH + 1) x 33 input pixels; a patch row is stored PARITY-DE-INTERLEAVED --
+//     the 17 even columns first, then the 16 odd ones -- so that the 16 input pixels a fragment needs for tap column kx
+//     (columns 2 ox + kx) are 16 CONSECUTIVE patch pixels (even plane from 0, odd plane from 0, even plane from 1) and the
+//     conflict-free XOR maps of the stride-1 kernels apply unchanged (the implicit-GEMM path it replaces spent 12 VALU
+//     operations per MFMA on addressing and 2 bank-conflict cycles per LDS instruction, profiles/r01_e_pmc_gemm_conv_wreg.txt);
+//   * input row 2 y + 2 serves tap row 2 of output row y and tap row 0 of output row y + 1: 2 RG + 1 fragment reads per 3 RG MFMAs.
+struct ConvS2Params {
+  const void* A; int64_t lda;
+  const void* W; int Kpad;
+  const float* scale; const float* shift;
+  void* C; int64_t ldc;
+  int Hin, Win, Hout, Wout;
+  int tiles_x, tiles_img, ntiles, per_xcd, bpx;
+  FastDiv fd_timg, fd_tx;
+};
+
+template <typename T, int C, int N, int TH, int WN, int NBUF>
+__global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvS2Params p) {
+  constexpr int PW = 33, PH = 2 * TH + 1, NPIX = PH * PW, CPP = C / 8, NCP = N / 8, TPX = TH * 16;
+  constexpr int PIECES = (NPIX * CPP + 63) / 64, IPW = (PIECES + 7) / 8;
+  constexpr int SETB = PIECES * 1024, STGB = TPX * N * 2;
+  constexpr int NPASS = TPX * NCP / 512;
+  constexpr int WM = 8 / WN, MT = TH / WM, NT = N / 16 / WN, KC = C / 32;
+  constexpr int DIST = NBUF - 1;
+  constexpr int RG = MT < 4 ? MT : 4;
+  constexpr uint32_t OOB = 0x80000000u;
+  static_assert(TH % WM == 0 && (N / 16) % WN == 0 && TPX * NCP % 512 == 0 && MT % RG == 0, "tile vs waves");
+  static_assert(NBUF * SETB + STGB + 1024 <= 160 * 1024, "LDS budget");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int wn = wave % WN, wm = wave / WN;
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int t_first = xcd * p.per_xcd + slot;
+  const int t_limit = min((xcd + 1) * p.per_xcd, p.ntiles);
+  if (t_first >= t_limit) return;
+  const int n_mine = (t_limit - t_first + p.bpx - 1) / p.bpx;
+
+  const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+  const uint32_t scratch = lds_base + NBUF * SETB + STGB;
+  const T* __restrict__ Ag = static_cast<const T*>(p.A);
+  T* __restrict__ Cg = static_cast<T*>(p.C);
+  const int64_t img_a = (int64_t)p.Hin * p.Win * p.lda, img_c = (int64_t)p.Hout * p.Wout * p.ldc;
+
+  struct Tile { int b, y0, x0; bool live; };
+  auto tile_of = [&](int it) {
+    Tile t;
+    t.live = it < n_mine;
+    const int id = min(t_first + it * p.bpx, p.ntiles - 1);
+    t.b = (int)fdiv((uint32_t)id, p.fd_timg);
+    const int rem = id - t.b * p.tiles_img;
+    const int ty = (int)fdiv((uint32_t)rem, p.fd_tx);
+    t.y0 = ty * TH;                        // output coordinates
+    t.x0 = (rem - ty * p.tiles_x) * 16;
+    return t;
+  };
+  auto issue_tile = [&](int it, int set) {
+    const Tile t = tile_of(it);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Ag + (int64_t)t.b * img_a), 0, (uint32_t)(img_a * 2), 0x00020000);
+#pragma unroll
+    for (int k = 0; k < IPW; ++k) {
+      const int pc = wave + 8 * k;
+      int lv = lane;
+      asm volatile("" : "+v"(lv));
+      const int X = pc * 64 + lv, pix = X / CPP, sl = X % CPP;
+      const int row = pix / PW, s33 = pix - row * PW;
+      const int col = s33 < 17 ? 2 * s33 : 2 * (s33 - 17) + 1;      // patch column of this de-interleaved slot
+      const int yy = 2 * t.y0 - 1 + row, xx = 2 * t.x0 - 1 + col;
+      const bool ok = t.live && pc < PIECES && pix < NPIX && (unsigned)yy < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win;
+      const uint32_t voff = ok ? (uint32_t)(((yy * p.Win + xx) * (int)p.lda + ((sl ^ cws_swz<C>(pix)) * 8)) * 2) : OOB;
+      cws_dma16(voff, rs, pc < PIECES ? lds_base + set * SETB + pc * 1024 : scratch);
+    }
+  };
+
+  u32x4 wf[NT][9][KC];
+  f32x4 sc[NT], sh[NT];
+  {
+    const T* Wg = static_cast<const T*>(p.W);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = (wn * NT + j) * 16;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int cc = 0; cc < KC; ++cc)
+          wf[j][tap][cc] = *reinterpret_cast<const u32x4*>(Wg + (int64_t)(n + r) * p.Kpad + tap * C + cc * 32 + q * 8);
+      sc[j] = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n + q * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+      sh[j] = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const int s_px = tid / NCP, s_c = tid % NCP;
+  const int s_ty = s_px >> 4, s_tx = s_px & 15;
+  const int s_lds = s_px * (N * 2) + ((s_c ^ (s_px & (NCP - 1))) * 16);
+  const int s_rel = ((s_ty * p.Wout + s_tx) * (int)p.ldc + s_c * 8) * 2;
+  constexpr int PASS_ROWS = 512 / NCP / 16, PASS_LDS = (512 / NCP) * N * 2;
+  const int s_pass_rel = PASS_ROWS * p.Wout * (int)p.ldc * 2;
+
+#pragma unroll
+  for (int d = 0; d < DIST; ++d) issue_tile(d, d);
+  cws_wait_vmcnt<(DIST - 1) * IPW>();
+  __syncthreads();
+
+  const int pix0 = 2 * wm * MT * PW + r;   // patch pixel of this lane: input row of output row 0 of the wave, even plane, tap column 0
+  int set = 0;
+  for (int it = 0; it < n_mine; ++it) {
+    {
+      int nset = set + DIST; if (nset >= NBUF) nset -= NBUF;
+      issue_tile(it + DIST, nset);
+    }
+    const unsigned char* patch = smem + set * SETB;
+    int pixv = pix0;
+    asm volatile("" : "+v"(pixv));
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      constexpr int KOFF[3] = {0, 17, 1};                 // even plane, odd plane, even plane shifted by one
+#pragma unroll
+      for (int cc = 0; cc < KC; ++cc) {
+#pragma unroll
+        for (int g = 0; g < MT / RG; ++g) {
+          u32x4 a[2 * RG + 1];
+#pragma unroll
+          for (int y = 0; y < 2 * RG + 1; ++y) {
+            const int pix = pixv + (2 * g * RG + y) * PW + KOFF[kx];
+            a[y] = *reinterpret_cast<const u32x4*>(patch + pix * (C * 2) + (((cc * 4 + q) ^ cws_swz<C>(pix)) * 16));
+          }
+#pragma unroll
+          for (int y = 0; y < RG; ++y)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+              for (int j = 0; j < NT; ++j)
+                acc[g * RG + y][j] = cws_mfma<T>(acc[g * RG + y][j], wf[j][ky * 3 + kx][cc], a[2 * y + ky]);
+        }
+      }
+    }
+    unsigned char* stg = smem + NBUF * SETB;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int ch = (wn * NT + j) * 16 + q * 4;
+#pragma unroll
+      for (int y = 0; y < MT; ++y) {
+        f32x4 v = acc[y][j] * sc[j] + sh[j];
+        v.x = siluf_(v.x); v.y = siluf_(v.y); v.z = siluf_(v.z); v.w = siluf_(v.w);
+        const int opx = (wm * MT + y) * 16 + r;
+        unsigned char* cell = stg + opx * (N * 2) + ((((ch >> 3) ^ (opx & (NCP - 1))) * 16) + ((ch >> 2) & 1) * 8);
+        *reinterpret_cast<u32x2*>(cell) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+      }
+    }
+    __syncthreads();
+    {
+      const Tile t = tile_of(it);
+      const auto rsC = __builtin_amdgcn_make_buffer_rsrc(Cg + (int64_t)t.b * img_c, 0, (uint32_t)(img_c * 2), 0x00020000);
+      const int off_c = (t.y0 * p.Wout + t.x0) * (int)p.ldc * 2 + s_rel;
+      const bool xok = t.x0 + s_tx < p.Wout;
+      u32x4 vv[NPASS];
+#pragma unroll
+      for (int k = 0; k < NPASS; ++k) vv[k] = *reinterpret_cast<const u32x4*>(stg + s_lds + k * PASS_LDS);
+#pragma unroll
+      for (int k = 0; k < NPASS; ++k) {
+        const bool ok = xok && t.y0 + s_ty + k * PASS_ROWS < p.Hout;
+        __builtin_amdgcn_raw_buffer_store_b128(vv[k], rsC, ok ? (uint32_t)(off_c + k * s_pass_rel) : OOB, 0, 0);
+      }
+    }
+    cws_wait_vmcnt<(DIST - 1) * (IPW + NPASS) + NPASS>();
+    __syncthreads();
+    if (++set == NBUF) set = 0;
+  }
+  cws_wait_vmcnt<0>();
+}
+
+template <typename T, int C, int N, int TH, int WN, int NBUF>
+static int launch_conv_s2(ConvS2Params& p, int B, hipStream_t st) {
+  constexpr int PIECES = ((2 * TH + 1) * 33 * (C / 8) + 63) / 64;
+  constexpr int LDS = NBUF * PIECES * 1024 + TH * 16 * N * 2 + 1024;
+  auto kern = conv_s2_kernel<T, C, N, TH, WN, NBUF>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (LDS > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return MOY_ELAUNCH;
+    attr_set = true;
+  }
+  p.tiles_x = (p.Wout + 15) / 16;
+  const int tiles_y = (p.Hout + TH - 1) / TH;
+  p.tiles_img = p.tiles_x * tiles_y;
+  p.ntiles = B * p.tiles_img;
+  p.fd_timg = make_fastdiv((uint32_t)p.tiles_img);
+  p.fd_tx = make_fastdiv((uint32_t)p.tiles_x);
+  p.per_xcd = (p.ntiles + 7) / 8;
+  p.bpx = cws_num_cus() / 8;
+  if (p.bpx < 1) p.bpx = 1;
+  if (p.bpx > p.per_xcd) p.bpx = p.per_xcd;
+  hipLaunchKernelGGL(kern, dim3(8 * p.bpx), dim3(512), LDS, st, p);
+  return launch_status();
+}
+
 template <typename T, int C, int N, int TH, int WN, int NBUF, bool RES, int OCC = 1, bool SPREAD = false, int ABL = 0>
 static int launch_conv_ws(ConvWsParams& p, int B, hipStream_t st) {
   using G = CwsGeom<C, N, TH, NBUF, RES>;
@@ -391,6 +856,14 @@ template <typename T>
 static int conv_ws_dispatch(ConvWsParams& p, int B, int C, bool res, hipStream_t st) {
   const int v = cws_variant();
   const bool sp = v & 1, occ2 = v & 2;
+  if (v & 4) {                             // software-pipelined form
+    if (C == 32) {
+      if (occ2) return res ? launch_conv_ws_pipe<T, 32, 32, 16, 2, true, 2>(p, B, st) : launch_conv_ws_pipe<T, 32, 32, 16, 2, false, 2>(p, B, st);
+      return res ? launch_conv_ws_pipe<T, 32, 32, 16, 2, true>(p, B, st) : launch_conv_ws_pipe<T, 32, 32, 16, 2, false>(p, B, st);
+    }
+    if (C == 64) return res ? launch_conv_ws_pipe<T, 64, 64, 16, 4, true>(p, B, st) : launch_conv_ws_pipe<T, 64, 64, 16, 4, false>(p, B, st);
+    if (C == 128) return res ? launch_conv_ws_pipe<T, 128, 128, 8, 8, true>(p, B, st) : launch_conv_ws_pipe<T, 128, 128, 8, 8, false>(p, B, st);
+  }
   if (C == 32) {
     if (occ2) return res ? launch_conv_ws<T, 32, 32, 16, 2, 2, true, 2>(p, B, st) : launch_conv_ws<T, 32, 32, 16, 2, 2, false, 2>(p, B, st);
     if (sp) return res ? launch_conv_ws<T, 32, 32, 16, 2, 3, true, 1, true>(p, B, st) : launch_conv_ws<T, 32, 32, 16, 2, 3, false, 1, true>(p, B, st);
@@ -413,7 +886,28 @@ int conv_ws_try(const moy_gemm_args* a, hipStream_t st) {
   if (mode < 0) { const char* e = getenv("MOY_CONV_WS"); mode = e ? atoi(e) : 1; }
   if (!mode) return MOY_ENOSYS;
   if (a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_ENOSYS;
-  if (a->ksize != 3 || a->stride != 1 || a->act != MOY_ACT_SILU) return MOY_ENOSYS;
+  if (a->ksize != 3 || a->act != MOY_ACT_SILU) return MOY_ENOSYS;
+  if (a->stride == 2) {
+    static int s2 = -1;                    // MOY_CONV_S2=0 switches the stride-2 kernel off (A/B runs)
+    if (s2 < 0) { const char* e = getenv("MOY_CONV_S2"); s2 = e ? atoi(e) : 1; }
+    const int C = a->Cin, N = a->N;
+    const bool l1 = C == 32 && N == 64, l3 = C == 64 && N == 128;
+    if (!s2 || !(l1 || l3) || a->K != 9 * C || a->R) return MOY_ENOSYS;
+    if (a->ln_g || a->out_f32 || a->c_rows_per_batch || a->pre || a->plane_cols || a->dot_n || !a->C) return MOY_ENOSYS;
+    if ((a->lda % 8) || (a->ldc % 8) || !aligned16(a->A) || !aligned16(a->C) || !aligned16(a->W)) return MOY_ENOSYS;
+    if ((a->scale && !aligned16(a->scale)) || (a->shift && !aligned16(a->shift))) return MOY_ENOSYS;
+    if ((int64_t)a->Hin * a->Win * a->lda * 2 > 0x3fffffffLL || (int64_t)a->Hout * a->Wout * a->ldc * 2 > 0x3fffffffLL) return MOY_ENOSYS;
+    const int TH = l1 ? 8 : 4;
+    const long tiles = (long)a->B * ((a->Hout + TH - 1) / TH) * ((a->Wout + 15) / 16);
+    const double util = (double)a->Hout * a->Wout * a->B / (double)(tiles * TH * 16);
+    if (mode == 1 && (tiles < 2 * cws_num_cus() || util < 0.7)) return MOY_ENOSYS;
+    ConvS2Params q{};
+    q.A = a->A; q.lda = a->lda; q.W = a->W; q.Kpad = (a->K + 63) / 64 * 64; q.scale = a->scale; q.shift = a->shift;
+    q.C = a->C; q.ldc = a->ldc; q.Hin = a->Hin; q.Win = a->Win; q.Hout = a->Hout; q.Wout = a->Wout;
+    if (a->dtype == MOY_BF16) return l1 ? launch_conv_s2<bf16_t, 32, 64, 8, 4, 3>(q, a->B, st) : launch_conv_s2<bf16_t, 64, 128, 4, 8, 2>(q, a->B, st);
+    return l1 ? launch_conv_s2<f16_t, 32, 64, 8, 4, 3>(q, a->B, st) : launch_conv_s2<f16_t, 64, 128, 4, 8, 2>(q, a->B, st);
+  }
+  if (a->stride != 1) return MOY_ENOSYS;
   const int C = a->Cin;
   if ((C != 32 && C != 64 && C != 128) || a->N != C || a->K != 9 * C) return MOY_ENOSYS;
   if (a->ln_g || a->out_f32 || a->c_rows_per_batch || a->pre || a->plane_cols || a->dot_n || !a->C) return MOY_ENOSYS;

@@ -277,6 +277,28 @@ def test_conv3x3_weight_stationary_kernel(dt, C, B, H, W, res):
     assert torch.equal(buf[:, :C].float().cpu(), x.permute(0, 2, 3, 1).reshape(M, C))   # input untouched
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Cin,Cout,B,H,W", [(32, 64, 16, 121, 135), (64, 128, 16, 60, 136), (32, 64, 12, 152, 272)])
+def test_conv3x3_stride2_weight_stationary_kernel(dt, Cin, Cout, B, H, W):
+    """The down-sampling convs (yolo_track.yaml:18-19,35: 3x3, stride 2, pad 1) at launch sizes that take the persistent
+    stride-2 kernel (csrc/conv_ws.hip: parity-de-interleaved patch): odd input sizes, tiles cut by both image edges, input and
+    output as channel slices of wider buffers."""
+    x = q(rnd(B, Cin, H, W, seed=1), dt)
+    w = q(rnd(Cout, Cin, 3, 3, seed=2, scale=1 / math.sqrt(9 * Cin)), dt)
+    sc, sh = rnd(Cout, seed=3) * 0.2 + 1, rnd(Cout, seed=4, scale=0.1)
+    ref = F.silu(F.conv2d(x, w, None, 2, 1) * sc[None, :, None, None] + sh[None, :, None, None])
+    Ho, Wo = ref.shape[2:]
+    xin = torch.zeros(B * H * W, Cin + 8, device=DEV, dtype=dt)
+    xin[:, :Cin] = x.permute(0, 2, 3, 1).reshape(B * H * W, Cin).to(DEV, dt)
+    out = torch.zeros(B * Ho * Wo, Cout + 16, device=DEV, dtype=dt)
+    wp = ops.pad_weight(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).to(DEV), dt)
+    ops.gemm(xin[:, :Cin], wp, Cout, 9 * Cin, ksize=3, stride=2, geom=(B, H, W, Ho, Wo, Cin), scale=sc.to(DEV), shift=sh.to(DEV),
+             act=L.ACT_SILU, out=out[:, 8:8 + Cout])
+    got = out[:, 8:8 + Cout].float().cpu().view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    assert torch.allclose(got, ref, atol=tol(dt, 2e-5, 3e-2), rtol=1e-5)
+    assert float(out[:, :8].abs().max()) == 0 and float(out[:, 8 + Cout:].abs().max()) == 0
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_channel_slice_views(dt):
     """A / R / C as channel slices of wider concat buffers (C2f / Concat without copies)."""
