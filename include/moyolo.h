@@ -148,6 +148,17 @@ int moy_stem_conv(const void* in, int in_fmt, int B, int H, int W, const float* 
 int moy_stem_conv_mfma(const void* in_u8, int B, int H, int W, const void* wpad, const float* scale, const float* shift,
                        int Cout, void* out, int64_t ldc, void* stream);
 
+/* Stem AND the first down-sampling conv in one launch (16-bit engines): uint8 BGR frames -> layer 0 (3x3 s2, 3 -> 32) -> layer 1
+ * (3x3 s2, 32 -> 64), each Conv + BN + SiLU (predictor.py:117-134; yolo_track.yaml:17-18; conv.py:36-38).  The 32-channel
+ * half-resolution tensor never reaches HBM (csrc/stem_l1.hip).
+ *   in_u8 [B, H, W, 3] BGR (H, W multiples of 4, pointer 4-byte aligned)
+ *   w0: T [32][32], stem weights in the kernel's k order: k = q*8 + e; q < 3: (ky = q, kx = e / 3, c_bgr = e % 3), e = 0..7;
+ *       q = 3: e = 0..2: (ky = e, kx = 2, c_bgr = 2), e >= 3: zero  (c_rgb = 2 - c_bgr; mo_yolo_amd.ops.stem_weights_fused)
+ *   scale0 / shift0 fp32 [32] (BN folded; the preprocess' 1/255 is applied inside); w1: T [64][320], k = (ky*3+kx)*32 + c;
+ *   scale1 / shift1 fp32 [64]; out: T [B, H/4, W/4, 64] with pixel stride ldc.   T = bf16 / fp16 (fp32: MOY_ENOSYS). */
+int moy_stem_l1_fused(const void* in_u8, int B, int H, int W, const void* w0, const float* scale0, const float* shift0, const void* w1,
+                      const float* scale1, const float* shift1, void* out, int64_t ldc, int dtype, void* stream);
+
 /* SPPF pooling: y1 = maxpool5(x), y2 = maxpool5(y1), y3 = maxpool5(y2) (stride 1, pad 2, -inf
  * padding) == windows 5/9/13 of x.  Replaces the three nn.MaxPool2d calls of SPPF.forward
  * (nn/modules/block.py:129-134).  x: T [B,H,W,C] stride ldx; y1..y3: stride ldy. C % 8 == 0. */

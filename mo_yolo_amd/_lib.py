@@ -51,6 +51,7 @@ SIGNATURES = {
     "moy_gemm": (C.c_int, [C.POINTER(GemmArgs), vp]),
     "moy_stem_conv": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, i64, C.c_int, vp]),
     "moy_stem_conv_mfma": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, i64, vp]),
+    "moy_stem_l1_fused": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64, C.c_int, vp]),
     "moy_sppf_pool": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, i64, C.c_int, vp]),
     "moy_upsample2x": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
     "moy_rowdot": (C.c_int, [vp, i64, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]),

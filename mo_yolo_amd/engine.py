@@ -212,6 +212,15 @@ class TrackEngine:
             w, b = w[rows], b[rows]
         return self._weight(w), self._dev(b)
 
+    def _fuse_stem_l1(self, consumers):
+        """Layers 0 and 1 as one launch: uint8 frames, 16-bit engine, Conv(3->32, s2) feeding ONLY Conv(32->64, 3x3, s2)."""
+        a = self.arch.layers
+        if os.environ.get("MOY_FUSE_STEM", "1") == "0" or self.dtype == torch.float32 or self.input_format != "u8" or len(a) < 2:
+            return False
+        return (a[0].kind == "Conv" and a[0].k == 3 and a[0].s == 2 and a[0].c1 == 3 and a[0].c2 == 32 and a[1].kind == "Conv"
+                and a[1].k == 3 and a[1].s == 2 and a[1].c1 == 32 and a[1].c2 == 64 and list(a[1].src) in ([-1], [0])
+                and consumers.get(0, []) == [1] and self.H % 4 == 0 and self.W % 4 == 0)
+
     # ------------------------------------------------------------------ plan
     def _build(self):
         arch, B, H, W, sd, lib, code = self.arch, self.B, self.H, self.W, self.sd, self.lib, self.code
@@ -285,7 +294,26 @@ class TrackEngine:
                 p = f"model.{Ls.i}"
                 x = outv[Ls.src[0]] if Ls.src[0] >= 0 else None
                 hin = hw[Ls.src[0]] if Ls.src[0] >= 0 else (H, W)
-                if Ls.kind == "Conv" and Ls.i == 0:
+                if Ls.kind == "Conv" and Ls.i == 0 and self._fuse_stem_l1(consumers):
+                    # layers 0 + 1 in one launch (csrc/stem_l1.hip): the 32-channel half-resolution tensor never reaches HBM
+                    from .ops import stem_weights_fused
+                    L1 = arch.layers[1]
+                    o1 = out_view(1, L1.c2)
+                    s0, h0 = self._bn("model.0.bn")
+                    s1, h1 = self._bn("model.1.bn")
+                    w0 = self._dev(stem_weights_fused(sd["model.0.conv.weight"], self.dtype))
+                    w1 = self._weight(sd["model.1.conv.weight"].permute(0, 2, 3, 1).reshape(L1.c2, 9 * L1.c1))
+                    ho, wo = H // 4, W // 4
+                    self._add(lib.moy_stem_l1_fused, self.input.data_ptr(), B, H, W, w0.data_ptr(), s0.data_ptr(), h0.data_ptr(), w1.data_ptr(),
+                              s1.data_ptr(), h1.data_ptr(), o1.ptr, o1.ld, code,
+                              meta=dict(name=f"stem+conv1 fused M{B * ho * wo} N{L1.c2}", bytes=B * H * W * 3 + B * ho * wo * L1.c2 * 2,
+                                        flops=2 * B * (H // 2) * (W // 2) * 32 * 27 + 2 * B * ho * wo * L1.c2 * 288))
+                    self._stem_step = len(self._steps) - 1
+                    outv[0], outv[1] = None, o1
+                    self._fused_l1 = True
+                elif Ls.kind == "Conv" and Ls.i == 1 and getattr(self, "_fused_l1", False):
+                    pass                                   # produced by the fused launch above
+                elif Ls.kind == "Conv" and Ls.i == 0:
                     assert Ls.k == 3 and Ls.s == 2 and Ls.c1 == 3
                     o = out_view(0, Ls.c2)
                     scale, shift = self._bn(p + ".bn")

@@ -126,6 +126,31 @@ def stem_weights_mfma(w):
     return out.to(torch.bfloat16).contiguous()
 
 
+def stem_weights_fused(w, dtype):
+    """[32, 3, 3, 3] fp32 stem weight (c_rgb) -> T [32, 32] in moy_stem_l1_fused's k order: slice q < 3 = tap row ky = q over the
+    8 bytes (kx, c_bgr) of a window row, slice 3 = the ninth byte (kx 2, c_bgr 2 = red) of the three rows."""
+    assert tuple(w.shape) == (32, 3, 3, 3)
+    out = torch.zeros(32, 32, device=w.device, dtype=torch.float32)
+    for qq in range(3):
+        for e in range(8):
+            out[:, qq * 8 + e] = w[:, 2 - e % 3, qq, e // 3]
+    for e in range(3):
+        out[:, 24 + e] = w[:, 0, e, 2]
+    return out.to(dtype).contiguous()
+
+
+def stem_l1_fused(x_u8, w0, scale0, shift0, w1pad, scale1, shift1, dtype, out=None):
+    """Layers 0 + 1 (both 3x3 stride 2 + BN + SiLU) of the backbone from uint8 BGR frames in one launch; out [B*(H/4)*(W/4), 64]."""
+    _need_gpu(x_u8)
+    B, H, W, _ = x_u8.shape
+    if out is None:
+        out = torch.empty(B * (H // 4) * (W // 4), 64, device=x_u8.device, dtype=dtype)
+    L.check(L.lib().moy_stem_l1_fused(x_u8.data_ptr(), B, H, W, w0.data_ptr(), scale0.data_ptr(), shift0.data_ptr(), w1pad.data_ptr(),
+                                      scale1.data_ptr(), shift1.data_ptr(), out.data_ptr(), _ld(out), _code(out), _st()),
+            "moy_stem_l1_fused")
+    return out
+
+
 def stem_conv_mfma(x_u8, wpad, scale, shift):
     _need_gpu(x_u8)
     B, H, W, _ = x_u8.shape

@@ -299,6 +299,30 @@ def test_conv3x3_stride2_weight_stationary_kernel(dt, Cin, Cout, B, H, W):
     assert float(out[:, :8].abs().max()) == 0 and float(out[:, 8 + Cout:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (3, 100, 132), (1, 608, 1088)])
+def test_stem_and_first_downsample_fused(dt, B, H, W):
+    """moy_stem_l1_fused = preprocess (BGR->RGB, /255, predictor.py:125-133) + layer 0 + layer 1 (yolo_track.yaml:17-18, Conv + BN +
+    SiLU each) against the same chain in torch fp32 with the 16-bit weights; frame sizes that cut tiles at both edges (H/4, W/4
+    not multiples of the 8 x 16 tile) and the full C2 frame; output written into a channel slice."""
+    g = torch.Generator().manual_seed(0)
+    u8 = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    x = u8.flip(-1).permute(0, 3, 1, 2).float() / 255
+    w0 = q(rnd(32, 3, 3, 3, seed=2, scale=0.3), dt)
+    w1 = q(rnd(64, 32, 3, 3, seed=5, scale=1 / math.sqrt(288)), dt)
+    s0, h0 = rnd(32, seed=3) * 0.2 + 1, rnd(32, seed=4, scale=0.1)
+    s1, h1 = rnd(64, seed=6) * 0.2 + 1, rnd(64, seed=7, scale=0.1)
+    y0 = F.silu(F.conv2d(x, w0, None, 2, 1) * s0[None, :, None, None] + h0[None, :, None, None])
+    ref = F.silu(F.conv2d(q(y0, dt), w1, None, 2, 1) * s1[None, :, None, None] + h1[None, :, None, None])   # layer 0's output is stored in T
+    Ho, Wo = H // 4, W // 4
+    out = torch.zeros(B * Ho * Wo, 96, device=DEV, dtype=dt)
+    ops.stem_l1_fused(u8.to(DEV), ops.stem_weights_fused(w0.to(DEV), dt), s0.to(DEV), h0.to(DEV),
+                      ops.pad_weight(w1.permute(0, 2, 3, 1).reshape(64, 288).to(DEV), dt), s1.to(DEV), h1.to(DEV), dt, out=out[:, 16:80])
+    got = out[:, 16:80].float().cpu().view(B, Ho, Wo, 64).permute(0, 3, 1, 2)
+    assert torch.allclose(got, ref, atol=tol(dt, 1e-5, 4e-2), rtol=1e-5), float((got - ref).abs().max())
+    assert float(out[:, :16].abs().max()) == 0 and float(out[:, 80:].abs().max()) == 0
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_channel_slice_views(dt):
     """A / R / C as channel slices of wider concat buffers (C2f / Concat without copies)."""
