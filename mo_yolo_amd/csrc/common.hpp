@@ -23,8 +23,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float bf2f(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
 // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN preserving) on gfx950
 __device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+// two casts at once: ONE v_cvt_pk_bf16_f32 (two scalar casts cost cvt, cvt, shift, or -- in every bf16 epilogue)
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_{lo, hi}, bf16x2_));
 }
 __device__ __forceinline__ float bflo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }

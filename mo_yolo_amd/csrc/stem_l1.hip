@@ -57,7 +57,7 @@ __device__ __forceinline__ f32x4 sl1_mfma<f16_t>(f32x4 acc, u32x4 w, u32x4 a) {
 
 constexpr int SL1_TH = 8;
 
-template <typename T>
+template <typename T, int DIAG = 0>     // DIAG = 1: s_memtime stamps of wave 0 (diagnostic build, MOY_SL1_DIAG=1; output garbage at the head of `out`)
 __global__ __launch_bounds__(512, 4) void stem_l1_kernel(const StemL1Params p) {
   constexpr int TH = SL1_TH, C1 = 32, N1 = 64;
   constexpr int PW = 33, PH = 2 * TH + 1, NPIX = PH * PW;              // layer-1 patch of stem pixels
@@ -157,12 +157,25 @@ __global__ __launch_bounds__(512, 4) void stem_l1_kernel(const StemL1Params p) {
   const int s_pass_rel = PASS_ROWS * Wo * (int)p.ldc * 2;
   constexpr uint32_t OOB = 0x80000000u;
 
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+  auto stamp = [&](int i) {
+    if constexpr (DIAG) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long tt = __builtin_amdgcn_s_memtime();
+      ph[i] += tt - tprev;
+      tprev = tt;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   load_window(tile_of(0));
   const int pix0 = 2 * wm * MT * PW + r;
+  if constexpr (DIAG) tprev = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < n_mine; ++it) {
     const Tile t = tile_of(it);
     store_window();
+    stamp(0);
     __syncthreads();                                   // W: window of tile `it` visible (and the staging of tile it-1 read out)
+    stamp(1);
     if (it + 1 < n_mine) load_window(tile_of(it + 1)); // in flight under the whole tile
 
     // ---- stem: fragments of 16 consecutive patch pixels, K = 32 (27), 32 channels
@@ -172,12 +185,11 @@ __global__ __launch_bounds__(512, 4) void stem_l1_kernel(const StemL1Params p) {
       sc0[j] = *reinterpret_cast<const f32x4*>(p.sc0 + j * 16 + q * 4) * (1.0f / 255.0f);     // the preprocess' /255 (predictor.py:133)
       sh0[j] = *reinterpret_cast<const f32x4*>(p.sh0 + j * 16 + q * 4);
     }
+    int pix = wave * 16 + r, row = pix / PW, s33 = pix - row * PW;
 #pragma unroll 1
-    for (int k = 0; k < FPW; ++k) {                    // (rolled: the fragments' address arithmetic is not worth 5x the registers)
-      const int f = wave + 8 * k;                       // wave-uniform
-      if (f >= NFRAG) continue;
-      const int pix = f * 16 + r;
-      const int row = pix / PW, s33 = pix - row * PW;
+    for (int k = 0; k < FPW; ++k, pix += 128, row += 128 / PW, s33 += 128 % PW) {   // (rolled: not worth 5x the registers)
+      if (wave + 8 * k >= NFRAG) break;                 // wave-uniform
+      if (s33 >= PW) { s33 -= PW; ++row; }              // (row, s33) = divmod(pix, PW), carried
       const int col = s33 < 17 ? 2 * s33 : 2 * (s33 - 17) + 1;
       // window coordinates of the stem pixel's 3x3 input patch: rows 2 row .. +2, bytes 6 col .. +8 (+ the row phase)
       const int rsel = min(2 * row + min(q, 2), WR - 1);
@@ -201,13 +213,15 @@ __global__ __launch_bounds__(512, 4) void stem_l1_kernel(const StemL1Params p) {
       for (int j = 0; j < 2; ++j) {
         f32x4 v = sl1_mfma<T>(f32x4{0.f, 0.f, 0.f, 0.f}, w0f[j], af) * sc0[j] + sh0[j];
         v.x = siluf_(v.x); v.y = siluf_(v.y); v.z = siluf_(v.z); v.w = siluf_(v.w);
-        if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x2 o = {DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+        if (!inside) o = u32x2{0u, 0u};
         if (pix < NPIX)
-          *reinterpret_cast<u32x2*>(patch + pix * (C1 * 2) + (((2 * j + (q >> 1)) ^ ((pix >> 1) & 3)) * 16) + (q & 1) * 8) =
-              u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+          *reinterpret_cast<u32x2*>(patch + pix * (C1 * 2) + (((2 * j + (q >> 1)) ^ ((pix >> 1) & 3)) * 16) + (q & 1) * 8) = o;
       }
     }
+    stamp(2);
     __syncthreads();                                   // P: patch complete
+    stamp(3);
 
     // ---- layer 1 on the patch (conv_s2_kernel's core: C 32, N 64, rows 2y+ky of the de-interleaved image)
     f32x4 acc[MT];
@@ -244,7 +258,9 @@ __global__ __launch_bounds__(512, 4) void stem_l1_kernel(const StemL1Params p) {
             u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
       }
     }
+    stamp(4);
     __syncthreads();                                   // S: staging complete, patch free
+    stamp(5);
     {
       const auto rsC = __builtin_amdgcn_make_buffer_rsrc(Og + (int64_t)t.b * img_c, 0, (uint32_t)(img_c * 2), 0x00020000);
       const int off_c = (t.y0 * Wo + t.x0) * (int)p.ldc * 2 + s_rel;
@@ -257,6 +273,14 @@ __global__ __launch_bounds__(512, 4) void stem_l1_kernel(const StemL1Params p) {
         const bool ok = xok && t.y0 + s_ty + k * PASS_ROWS < Ho;
         __builtin_amdgcn_raw_buffer_store_b128(vv[k], rsC, ok ? (uint32_t)(off_c + k * s_pass_rel) : OOB, 0, 0);
       }
+    }
+    stamp(6);
+  }
+  if constexpr (DIAG) {
+    if (blockIdx.x == 0 && tid == 0) {
+      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.out);
+      for (int i = 0; i < 7; ++i) dbg[i] = ph[i];
+      dbg[7] = (unsigned long long)n_mine;
     }
   }
 }
@@ -277,10 +301,13 @@ static int launch_stem_l1(StemL1Params& p, hipStream_t st) {
   constexpr int TH = SL1_TH;
   constexpr int WIN_B = (((4 * TH + 3) * 52 * 4 + 15) / 16) * 16, PATCH_B = (((2 * TH + 1) * 33 * 64 + 1023) / 1024) * 1024, STG_B = TH * 16 * 128;
   constexpr int LDS = WIN_B + PATCH_B + STG_B;
-  auto kern = stem_l1_kernel<T>;
+  static int diag = -1;
+  if (diag < 0) { const char* e = getenv("MOY_SL1_DIAG"); diag = e ? atoi(e) : 0; }
+  auto kern = diag ? stem_l1_kernel<T, 1> : stem_l1_kernel<T, 0>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (LDS > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+    if (LDS > 65536 && (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_l1_kernel<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(stem_l1_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess))
       return MOY_ELAUNCH;
     attr_set = true;
   }
