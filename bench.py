@@ -323,6 +323,10 @@ def main(argv=None):
                     bytes_step *= 2
                 ach_s = bytes_step / (ms_step * 1e-3) / 1e9
                 roof_step.update(achieved=round(ach_s, 1), frac=round(ach_s / HBM_PEAK_GBS, 4), alg_bytes_per_step=bytes_step)
+                # SURVEY §8(d) as written charges the 25.7 MB of weights to EVERY frame (FPS x B_alg / peak: 11.6 k FPS = 0.60 at C2);
+                # `frac` above charges them once per launch (they are read once per sub-batch), the stricter figure
+                roof_step["frac_survey_8d_per_frame_weights"] = round(ALG_BYTES_FRAME[cfg_name] * (2 if dtype_name == "f32" else 1) * B
+                                                                      / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             # (c) measured HBM traffic of the plan (PMC passes committed under profiles/, tools/pmc_traffic.sh): bytes per frame
             tpf = prof.get("step_total", {}).get(f"{cfg_name}_{dtype_name}", {}).get("hbm_bytes_per_frame")
             if tpf:

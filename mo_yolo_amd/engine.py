@@ -523,7 +523,8 @@ class TrackEngine:
             t = self.trk
             self._add(lib.moy_temporal_assemble, t["embed"].data_ptr(), t["qpos"].data_ptr(), t["ref"].data_ptr(), t["n"].data_ptr(),
                       det_embed.ptr, det_embed.ld, det_qpos.ptr, det_qpos.ld, self.refer_logit.data_ptr(), B, n_max, nq,
-                      embed[0].ptr, embed[0].ld, qpos.ptr, qpos.ld, self.refer_all.data_ptr(), refs[0].data_ptr(), code)
+                      embed[0].ptr, embed[0].ld, qpos.ptr, qpos.ld, self.refer_all.data_ptr(), refs[0].data_ptr(), code,
+                      meta=dict(name=f"temporal_assemble B{B} L{nq + n_max}", bytes=Md * (4 * hd * self._esz + 32), flops=0))
         self.query_pos = qpos
 
         M = Md                           # from here on: decoder rows
@@ -630,7 +631,8 @@ class TrackEngine:
             self._add(lib.moy_track_state_update, self.scores.data_ptr(), self.boxes.data_ptr(), self.obj_idxes.data_ptr(),
                       self.hs.ptr, self.hs.ld, B, nq, self.copy_rows.data_ptr(), self.copy_ids.data_ptr(), self.n_copy.data_ptr(),
                       f["mem"].data_ptr(), f["conf"].data_ptr(), f["ids"].data_ptr(), f["boxes"].data_ptr(), f["low"].data_ptr(),
-                      f["pool"].data_ptr(), f["pool"].numel(), f["pool_hc"].data_ptr(), code)
+                      f["pool"].data_ptr(), f["pool"].numel(), f["pool_hc"].data_ptr(), code,
+                      meta=dict(name=f"track_state_update B{B} Q{nq}", bytes=B * nq * (28 + hd * self._esz) + 300 * (hd * 4 + 40), flops=0))
 
     def _build_temporal_update(self, qpos: View):
         """After the decoder of a frame (temporal mode): ID lifecycle + compaction (`moy_temporal_assign`), the learned
@@ -650,18 +652,22 @@ class TrackEngine:
                   C.c_float(self.filter_score_thresh), self.miss_tolerance, C.c_float(self.conf), C.c_float(self.img_wh[0]),
                   C.c_float(self.img_wh[1]), self.y.data_ptr(), self.scores.data_ptr(), self.obj_idxes.data_ptr(),
                   self.dis_out.data_ptr(), self.sel_rows.data_ptr(), self.n_new.data_ptr(), self.n_overflow.data_ptr(),
-                  self.rows.data_ptr(), self.track_id.data_ptr(), self.n_rows.data_ptr(), self.n_ids.data_ptr())
+                  self.rows.data_ptr(), self.track_id.data_ptr(), self.n_rows.data_ptr(), self.n_ids.data_ptr(),
+                  meta=dict(name=f"temporal_assign B{B} L{Lq}", bytes=B * Lq * (4 * nc + 16 + 24 + 12) + B * n_max * 16, flops=0))
         # the selected rows' decoder output (content embedding of the track from now on), the position embedding and the
         # reference box they were decoded with
         sel = self.sel_rows.data_ptr()
         out_embed = View(t["embed"])
         qp_prev = View(self._buf(Mq, hd))
         ref_in = self._buf(Mq, 4, torch.float32)
-        self._add(lib.moy_gather_rows, self.hs.ptr, self.hs.ld, sel, Mq, hd, out_embed.ptr, out_embed.ld, code)
-        self._add(lib.moy_gather_rows, qpos.ptr, qpos.ld, sel, Mq, hd, qp_prev.ptr, qp_prev.ld, code)
-        self._add(lib.moy_gather_rows, self.refer_all.data_ptr(), 4, sel, Mq, 4, ref_in.data_ptr(), 4, L.F32)
+        gm = dict(name=f"gather_rows M{Mq} C{hd}", bytes=Mq * (2 * hd * self._esz + 4), flops=0)
+        self._add(lib.moy_gather_rows, self.hs.ptr, self.hs.ld, sel, Mq, hd, out_embed.ptr, out_embed.ld, code, meta=gm)
+        self._add(lib.moy_gather_rows, qpos.ptr, qpos.ld, sel, Mq, hd, qp_prev.ptr, qp_prev.ld, code, meta=gm)
+        self._add(lib.moy_gather_rows, self.refer_all.data_ptr(), 4, sel, Mq, 4, ref_in.data_ptr(), 4, L.F32,
+                  meta=dict(name=f"gather_rows M{Mq} C4", bytes=Mq * 36, flops=0))
         pos = View(self._buf(Mq, hd))
-        self._add(lib.moy_pos2posemb, ref_in.data_ptr(), Mq, pos.ptr, pos.ld, code)
+        self._add(lib.moy_pos2posemb, ref_in.data_ptr(), Mq, pos.ptr, pos.ld, code,
+                  meta=dict(name=f"pos2posemb M{Mq}", bytes=Mq * (16 + hd * self._esz), flops=0))
         q = f"model.{len(arch.layers)}.track_embed"
         Wqk, bqk = self._linear_w_raw(sd[q + ".self_attn.in_proj_weight"][:2 * hd], sd[q + ".self_attn.in_proj_bias"][:2 * hd])
         Wvv, bvv = self._linear_w_raw(sd[q + ".self_attn.in_proj_weight"][2 * hd:], sd[q + ".self_attn.in_proj_bias"][2 * hd:])
@@ -670,7 +676,7 @@ class TrackEngine:
         self._gemm(out_embed, Wvv, hd, hd, qkv.slice(2 * hd, hd), Mq, shift=bvv)
         attn = View(self._buf(Mq, hd))
         self._add(lib.moy_mha_core_masked, qkv.ptr, qkv.ld, B, n_max, arch.nh, hd, self.n_new.data_ptr(), n_max, attn.ptr, attn.ld,
-                  code)
+                  code, meta=dict(name=f"mha_core B{B} L{n_max}", bytes=4 * Mq * hd * self._esz, flops=4 * B * n_max * n_max * hd))
         tgt1, tgt2 = View(self._buf(Mq, hd)), View(self._buf(Mq, hd))
         Wo, bo = self._linear_w(q + ".self_attn.out_proj")
         self._gemm(attn, Wo, hd, hd, tgt1, Mq, shift=bo, R=out_embed, ln=self._ln(q + ".norm1"))
@@ -686,7 +692,8 @@ class TrackEngine:
         self._gemm(tgt2, Wf1, dff, hd, g1, Mq, shift=bf1, act=L.ACT_RELU)
         self._gemm(g1, Wf2, hd, dff, View(t["qpos"]), Mq, shift=bf2, R=qp_prev, ln=self._ln(q + ".norm_feat"))
         self._add(lib.moy_temporal_commit, sel, self.n_new.data_ptr(), self.obj_idxes.data_ptr(), self.dis_out.data_ptr(),
-                  self.boxes.data_ptr(), B, n_max, t["id"].data_ptr(), t["dis"].data_ptr(), t["ref"].data_ptr(), t["n"].data_ptr())
+                  self.boxes.data_ptr(), B, n_max, t["id"].data_ptr(), t["dis"].data_ptr(), t["ref"].data_ptr(), t["n"].data_ptr(),
+                  meta=dict(name=f"temporal_commit B{B} N{n_max}", bytes=Mq * (4 + 8 + 4 + 16 + 28), flops=0))
 
     def _build_detect_head(self, head_src):
         """Detect head of config C1 (nn/modules/head.py:27-78) + NMS / scale_boxes
@@ -712,7 +719,8 @@ class TrackEngine:
                 outs[name] = o
             stride = float(self.H // hh)
             self._add(lib.moy_detect_decode, outs["cv2"].ptr, outs["cv2"].ld, outs["cv3"].ptr, outs["cv3"].ld, B, hh, ww, nc,
-                      C.c_float(stride), a_off, A, self.y.data_ptr(), code)
+                      C.c_float(stride), a_off, A, self.y.data_ptr(), code,
+                      meta=dict(name=f"detect_decode M{M}", bytes=M * ((64 + nc) * self._esz + (4 + nc) * 4), flops=0))
             a_off += hh * ww
         self.rows = torch.zeros(B, self.max_det, 6, device=self.dev)
         self.n_rows = torch.zeros(B, device=self.dev, dtype=torch.int32)
@@ -724,7 +732,8 @@ class TrackEngine:
             cw, ch_ = float(ow), float(oh)
         self._add(lib.moy_nms, self.y.data_ptr(), B, nc, A, C.c_float(self.conf), C.c_float(self.iou), self.max_det,
                   C.c_float(7680.0), C.c_float(gain), C.c_float(padx), C.c_float(pady), C.c_float(cw), C.c_float(ch_),
-                  self.rows.data_ptr(), self.n_rows.data_ptr())
+                  self.rows.data_ptr(), self.n_rows.data_ptr(),
+                  meta=dict(name=f"nms B{B} A{A}", bytes=B * (A * (4 + nc) * 4 + self.max_det * 24), flops=0))
 
     def reset_sequence(self, which=None):
         """Start of a new video sequence.  Temporal mode: empties the query memory and restarts the id counter of the

@@ -249,6 +249,23 @@ def test_engine_graph_replay_matches_eager():
         assert torch.equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("mode", ["per_frame", "temporal", "side_state", "detect"])
+def test_every_launch_has_byte_accounting(mode):
+    """bench.py's plan_bytes sums `meta["bytes"]` over the launches: no launch kind may be left at zero."""
+    if mode == "detect":
+        from mo_yolo_amd.config import build_detect_arch
+        from mo_yolo_amd.weights import make_fixture_state_dict
+        arch = build_detect_arch()
+        sd, cfg, kw = make_fixture_state_dict(arch, 5), dict(H=640, W=640), {}
+    else:
+        cfg, arch, sd = fixture("tiny")
+        kw = dict(temporal=8) if mode == "temporal" else dict(side_state=True) if mode == "side_state" else {}
+    eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=2, dtype=torch.bfloat16, **kw)
+    assert len(eng.meta) == eng.num_launches
+    missing = [m["name"] for m in eng.meta if not m["bytes"] > 0]
+    assert not missing, missing
+
+
 def test_streamed_engines_equal_single_engine():
     """Sub-batches on separate HIP streams + graphs (engine.StreamedEngines) give the frames' own results."""
     from mo_yolo_amd.engine import StreamedEngines

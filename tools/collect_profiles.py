@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries of one tools/profile_round.sh run from gpurun_out/ (scratch) into profiles/ (tracked).
+usage: collect_profiles.py gpurun_out/<dir> <tag>      e.g.  collect_profiles.py gpurun_out/r02p r02_a
+Also refreshes profiles/traffic_by_launch.json (read by bench.py for roofline.traffic / roofline_step.traffic_frac)."""
+import glob, json, os, shutil, sys
+src, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(ROOT, "profiles")
+
+
+def cp(a, b):
+    if os.path.exists(a):
+        shutil.copyfile(a, os.path.join(dst, b))
+        print("  ", b)
+
+
+for f in sorted(glob.glob(f"{src}/bench_*.json")):
+    cp(f, f"{tag}_{os.path.basename(f)}")
+for f in sorted(glob.glob(f"{src}/launches_*.json")):
+    cp(f, f"{tag}_launch_table_{os.path.basename(f)[9:]}")
+for sub, name in (("trace_default", "default_2streams"), ("trace_1stream", "b288_1stream")):
+    for f in glob.glob(f"{src}/{sub}/**/*kernel_stats.csv", recursive=True):
+        cp(f, f"{tag}_kernel_stats_{name}.csv")
+cp(f"{src}/trace_1stream_by_launch_shape.csv", f"{tag}_b288_1stream_by_launch_shape.csv")
+cp(f"{src}/traffic.json", f"{tag}_b288_hbm_traffic_pmc.json")
+cp(f"{src}/traffic_step.json", f"{tag}_b288_hbm_traffic_step.json")
+
+tp = os.path.join(dst, "traffic_by_launch.json")
+doc = json.load(open(tp)) if os.path.exists(tp) else {}
+if "launches" not in doc:
+    doc = {"launches": doc, "step_total": {}}
+if os.path.exists(f"{src}/traffic_step.json") and os.path.exists(f"{src}/traffic.json"):
+    st = json.load(open(f"{src}/traffic_step.json"))
+    doc["step_total"]["c2_bf16"] = dict(hbm_bytes_per_frame=st["hbm_bytes_per_frame"], dispatches_per_pass=st["dispatches_per_step"],
+                                        source=f"profiles/{tag}_b288_hbm_traffic_step.json: {st['formula']}; {st['steps']} passes of the "
+                                               f"plan at {st['frames_per_step']} frames, one engine, one stream, eager launches")
+    rows = json.load(open(f"{src}/traffic.json"))
+    for r in rows:          # the dominant launch: value projection = the 8-wave x 512-column weight-stationary GEMM, grid 122880
+        if "gemm_wreg_kernel" in r["kernel"] and "8, 64, 256" in r["kernel"] and r["grid"] == "122880":
+            doc["launches"]["gemm1x1 M3907008 N1536 K256"] = dict(
+                hbm_bytes=r["hbm_bytes"], source=f"profiles/{tag}_b288_hbm_traffic_pmc.json ({r['kernel'][:70]}, grid {r['grid']}, "
+                f"{r['dispatches']} dispatches): (2*FETCH_SIZE + WRITE_SIZE)*1024, fetch {r['fetch_kb_raw']:.0f} KB raw, write {r['write_kb']:.0f} KB")
+    json.dump(doc, open(tp, "w"), indent=1)
+    print("   traffic_by_launch.json: c2_bf16", round(st["hbm_bytes_per_frame"] / 1e6, 1), "MB/frame")
