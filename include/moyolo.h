@@ -159,6 +159,26 @@ int moy_stem_conv_mfma(const void* in_u8, int B, int H, int W, const void* wpad,
 int moy_stem_l1_fused(const void* in_u8, int B, int H, int W, const void* w0, const float* scale0, const float* shift0, const void* w1,
                       const float* scale1, const float* shift1, void* out, int64_t ldc, int dtype, void* stream);
 
+/* A whole C2f block in one launch (16-bit engines): the first C2f of the backbone, 64 -> [32 | 32] -> 64 channels, n = 1 with
+ * shortcut (yolo_track.yaml:19; ultralytics/nn/modules/block.py:219-240 C2f.forward, :271-283 Bottleneck; conv.py:36-38):
+ *   y0 | y1 = SiLU(BN(cv1 . x));  z = SiLU(BN(m.cv1 * y1));  y2 = y1 + SiLU(BN(m.cv2 * z));  out = SiLU(BN(cv2 . [y0 | y1 | y2])).
+ * y0, y1, z, y2 never reach HBM (csrc/c2f_fused.hip); each is rounded to T as the four-launch path (moy_gemm x 4) stores it.
+ *   x   T [B, H, W, 64] with pixel stride ldx;   out T [B, H, W, 64] with pixel stride ldo
+ *   w_cv1 T [64][kp_cv1] (k = input channel);  w_m1, w_m2 T [32][kp_m], k = (ky*3+kx)*32 + c;  w_cv2 T [64][kp_cv2], k over
+ *   [y0 | y1 | y2];  scale_* / shift_* fp32 (BN folded), [64], [32], [32], [64].   T = bf16 / fp16 (fp32: MOY_ENOSYS). */
+typedef struct moy_c2f_args {
+  const void* x; int64_t ldx;
+  int32_t B, H, W;
+  const void* w_cv1; int32_t kp_cv1; const float* scale_cv1; const float* shift_cv1;
+  const void* w_m1; const float* scale_m1; const float* shift_m1;
+  const void* w_m2; const float* scale_m2; const float* shift_m2; int32_t kp_m;
+  const void* w_cv2; int32_t kp_cv2; const float* scale_cv2; const float* shift_cv2;
+  void* out; int64_t ldo;
+  int32_t dtype;
+} moy_c2f_args;
+
+int moy_c2f_fused(const moy_c2f_args* args, void* stream);
+
 /* SPPF pooling: y1 = maxpool5(x), y2 = maxpool5(y1), y3 = maxpool5(y2) (stride 1, pad 2, -inf
  * padding) == windows 5/9/13 of x.  Replaces the three nn.MaxPool2d calls of SPPF.forward
  * (nn/modules/block.py:129-134).  x: T [B,H,W,C] stride ldx; y1..y3: stride ldy. C % 8 == 0. */

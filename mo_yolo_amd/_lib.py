@@ -44,6 +44,18 @@ class DecoderTailArgs(C.Structure):
     ]
 
 
+class C2fArgs(C.Structure):
+    """Mirror of `moy_c2f_args` (include/moyolo.h)."""
+    _fields_ = [
+        ("x", vp), ("ldx", i64), ("B", i32), ("H", i32), ("W", i32),
+        ("w_cv1", vp), ("kp_cv1", i32), ("scale_cv1", vp), ("shift_cv1", vp),
+        ("w_m1", vp), ("scale_m1", vp), ("shift_m1", vp),
+        ("w_m2", vp), ("scale_m2", vp), ("shift_m2", vp), ("kp_m", i32),
+        ("w_cv2", vp), ("kp_cv2", i32), ("scale_cv2", vp), ("shift_cv2", vp),
+        ("out", vp), ("ldo", i64), ("dtype", i32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol declared in include/moyolo.h
 SIGNATURES = {
     "moy_version": (C.c_int, []),
@@ -52,6 +64,7 @@ SIGNATURES = {
     "moy_stem_conv": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, i64, C.c_int, vp]),
     "moy_stem_conv_mfma": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, i64, vp]),
     "moy_stem_l1_fused": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64, C.c_int, vp]),
+    "moy_c2f_fused": (C.c_int, [C.POINTER(C2fArgs), vp]),
     "moy_sppf_pool": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, i64, C.c_int, vp]),
     "moy_upsample2x": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
     "moy_rowdot": (C.c_int, [vp, i64, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]),

@@ -338,6 +338,30 @@ class TrackEngine:
                     o = out_view(Ls.i, Ls.c2)
                     self._conv(p, x, hin, Ls.c1, Ls.c2, Ls.k, Ls.s, o)
                     outv[Ls.i] = o
+                elif (Ls.kind == "C2f" and Ls.c1 == 64 and Ls.c2 == 64 and Ls.n == 1 and Ls.shortcut and Ls.src[0] not in virt_cat
+                      and self.dtype != torch.float32 and os.environ.get("MOY_FUSE_C2F", "1") != "0"
+                      and hin[0] * hin[1] * 64 * 2 <= 0x3fffffff):
+                    # the whole block in one launch (csrc/c2f_fused.hip): y0 | y1, z and y2 never reach HBM
+                    c, (h_, w_) = 32, hin
+                    a = L.C2fArgs()
+                    o = out_view(Ls.i, Ls.c2)
+                    a.x, a.ldx, a.B, a.H, a.W = x.ptr, x.ld, B, h_, w_
+                    wt = {}
+                    for key, q_, kk in (("cv1", p + ".cv1", 1), ("m1", p + ".m.0.cv1", 3), ("m2", p + ".m.0.cv2", 3), ("cv2", p + ".cv2", 1)):
+                        w = sd[q_ + ".conv.weight"]
+                        w2 = w.reshape(w.shape[0], -1) if kk == 1 else w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+                        wt[key] = (self._weight(w2),) + self._bn(q_ + ".bn")
+                    a.w_cv1, a.kp_cv1, a.scale_cv1, a.shift_cv1 = wt["cv1"][0].data_ptr(), wt["cv1"][0].shape[1], wt["cv1"][1].data_ptr(), wt["cv1"][2].data_ptr()
+                    a.w_m1, a.scale_m1, a.shift_m1 = wt["m1"][0].data_ptr(), wt["m1"][1].data_ptr(), wt["m1"][2].data_ptr()
+                    a.w_m2, a.scale_m2, a.shift_m2, a.kp_m = wt["m2"][0].data_ptr(), wt["m2"][1].data_ptr(), wt["m2"][2].data_ptr(), wt["m1"][0].shape[1]
+                    a.w_cv2, a.kp_cv2, a.scale_cv2, a.shift_cv2 = wt["cv2"][0].data_ptr(), wt["cv2"][0].shape[1], wt["cv2"][1].data_ptr(), wt["cv2"][2].data_ptr()
+                    a.out, a.ldo, a.dtype = o.ptr, o.ld, code
+                    self._keep.append(a)
+                    M_ = B * h_ * w_
+                    self._add(lib.moy_c2f_fused, C.byref(a), meta=dict(
+                        name=f"c2f fused M{M_} 64->[32|32]->64", bytes=M_ * 128 * self._esz,
+                        flops=2 * M_ * (64 * 64 + 2 * 32 * 288 + 96 * 64)))
+                    outv[Ls.i] = o
                 elif Ls.kind == "C2f":
                     c = Ls.c2 // 2
                     h_, w_ = hin

@@ -151,6 +151,25 @@ def stem_l1_fused(x_u8, w0, scale0, shift0, w1pad, scale1, shift1, dtype, out=No
     return out
 
 
+def c2f_fused(x, B, H, W, cv1, m1, m2, cv2, out=None):
+    """C2f block 64 -> [32 | 32] -> 64, n = 1, shortcut, in one launch (csrc/c2f_fused.hip).  x [B*H*W, 64] (a channel slice of a
+    wider buffer is fine); cv1 / m1 / m2 / cv2 = (padded weight [N, Kpad], scale fp32 [N], shift fp32 [N]) with the weights of the
+    3x3 convs as [32, (ky*3+kx)*32 + c]; out [B*H*W, 64]."""
+    _need_gpu(x)
+    if out is None:
+        out = torch.empty(B * H * W, 64, device=x.device, dtype=x.dtype)
+    a = L.C2fArgs()
+    a.x, a.ldx, a.B, a.H, a.W = x.data_ptr(), _ld(x), B, H, W
+    a.w_cv1, a.kp_cv1, a.scale_cv1, a.shift_cv1 = cv1[0].data_ptr(), cv1[0].shape[1], cv1[1].data_ptr(), cv1[2].data_ptr()
+    a.w_m1, a.scale_m1, a.shift_m1 = m1[0].data_ptr(), m1[1].data_ptr(), m1[2].data_ptr()
+    a.w_m2, a.scale_m2, a.shift_m2, a.kp_m = m2[0].data_ptr(), m2[1].data_ptr(), m2[2].data_ptr(), m1[0].shape[1]
+    assert m1[0].shape[1] == m2[0].shape[1]
+    a.w_cv2, a.kp_cv2, a.scale_cv2, a.shift_cv2 = cv2[0].data_ptr(), cv2[0].shape[1], cv2[1].data_ptr(), cv2[2].data_ptr()
+    a.out, a.ldo, a.dtype = out.data_ptr(), _ld(out), _code(out)
+    L.check(L.lib().moy_c2f_fused(C.byref(a), _st()), "moy_c2f_fused")
+    return out
+
+
 def stem_conv_mfma(x_u8, wpad, scale, shift):
     _need_gpu(x_u8)
     B, H, W, _ = x_u8.shape

@@ -323,6 +323,55 @@ def test_stem_and_first_downsample_fused(dt, B, H, W):
     assert float(out[:, :16].abs().max()) == 0 and float(out[:, 80:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,W", [(2, 19, 45), (1, 152, 272), (3, 8, 30), (2, 9, 61)])
+def test_c2f_block_fused(dt, B, H, W):
+    """moy_c2f_fused (C2f 64 -> [32 | 32] -> 64, n = 1, shortcut: block.py:219-240, :271-283; conv.py:36-38) against (i) the same
+    block as four moy_gemm launches -- equal up to the fp32 summation order inside an MFMA, i.e. an ulp of T on a few values --
+    and (ii) torch fp32 with every intermediate rounded to T where the launches store it.  Sizes: tiles cut by both image edges
+    (W = 45 -> two tiles of 23; H = 19, 9 -> a last row group of 3 / 1 rows), the C2 layer-2 geometry (152 x 272 -> 10 tiles of
+    28), exactly one tile; input / output as channel slices of wider buffers."""
+    c = 32
+    x = q(rnd(B, 64, H, W, seed=1), dt)
+    ws = dict(cv1=q(rnd(64, 64, seed=2, scale=1 / 8), dt), m1=q(rnd(c, c, 3, 3, seed=3, scale=1 / 17), dt),
+              m2=q(rnd(c, c, 3, 3, seed=4, scale=1 / 17), dt), cv2=q(rnd(64, 96, seed=5, scale=1 / 10), dt))
+    bn = {k: (rnd(n, seed=10 + i) * 0.2 + 1, rnd(n, seed=20 + i, scale=0.1)) for i, (k, n) in enumerate((("cv1", 64), ("m1", c), ("m2", c), ("cv2", 64)))}
+
+    def act(v, k):
+        return F.silu(v * bn[k][0][None, :, None, None] + bn[k][1][None, :, None, None])
+    y01 = q(act(F.conv2d(x, ws["cv1"][:, :, None, None]), "cv1"), dt)
+    y1 = y01[:, c:]
+    z = q(act(F.conv2d(y1, ws["m1"], None, 1, 1), "m1"), dt)
+    y2 = q(y1 + act(F.conv2d(z, ws["m2"], None, 1, 1), "m2"), dt)
+    ref = act(F.conv2d(torch.cat([y01, y2], 1), ws["cv2"][:, :, None, None]), "cv2")
+
+    M = B * H * W
+    xin = torch.zeros(M, 80, device=DEV, dtype=dt)
+    xin[:, 8:72] = x.permute(0, 2, 3, 1).reshape(M, 64).to(DEV, dt)
+    d = lambda t: t.to(DEV)
+    wp = dict(cv1=ops.pad_weight(d(ws["cv1"]), dt), m1=ops.pad_weight(d(ws["m1"].permute(0, 2, 3, 1).reshape(c, 9 * c)), dt),
+              m2=ops.pad_weight(d(ws["m2"].permute(0, 2, 3, 1).reshape(c, 9 * c)), dt), cv2=ops.pad_weight(d(ws["cv2"]), dt))
+    arg = {k: (wp[k], d(bn[k][0]), d(bn[k][1])) for k in wp}
+    out = torch.zeros(M, 96, device=DEV, dtype=dt)
+    ops.c2f_fused(xin[:, 8:72], B, H, W, arg["cv1"], arg["m1"], arg["m2"], arg["cv2"], out=out[:, 16:80])
+    got = out[:, 16:80].float().cpu()
+    assert float(out[:, :16].abs().max()) == 0 and float(out[:, 80:].abs().max()) == 0
+    assert torch.allclose(got.view(B, H, W, 64).permute(0, 3, 1, 2), ref, atol=tol(dt, 1e-5, 4e-2), rtol=1e-5)
+
+    # the four-launch path on the same buffers
+    cat = torch.zeros(M, 96, device=DEV, dtype=dt)
+    tmp = torch.zeros(M, c, device=DEV, dtype=dt)
+    kw = lambda k: dict(scale=arg[k][1], shift=arg[k][2], act=L.ACT_SILU)
+    ops.gemm(xin[:, 8:72], wp["cv1"], 64, 64, out=cat[:, :64], **kw("cv1"))
+    ops.gemm(cat[:, c:2 * c], wp["m1"], c, 9 * c, ksize=3, stride=1, geom=(B, H, W, H, W, c), out=tmp, **kw("m1"))
+    ops.gemm(tmp, wp["m2"], c, 9 * c, ksize=3, stride=1, geom=(B, H, W, H, W, c), R=cat[:, c:2 * c], out=cat[:, 2 * c:], **kw("m2"))
+    four = ops.gemm(cat, wp["cv2"], 64, 96, **kw("cv2")).float().cpu()
+    diff = (got - four).abs()
+    ulp = 2.0 ** (-8 if dt == torch.bfloat16 else -11)
+    assert float((diff / four.abs().clamp_min(0.25)).max()) <= 2 * ulp, float(diff.max())
+    assert float((diff > 0).float().mean()) < 0.02                       # all but a few values are bit-identical
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_channel_slice_views(dt):
     """A / R / C as channel slices of wider concat buffers (C2f / Concat without copies)."""
