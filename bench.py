@@ -329,7 +329,7 @@ def main(argv=None):
                                                                       / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             # (c) measured HBM traffic of the plan (PMC passes committed under profiles/, tools/pmc_traffic.sh): bytes per frame
             tpf = prof.get("step_total", {}).get(f"{cfg_name}_{dtype_name}", {}).get("hbm_bytes_per_frame")
-            if tpf:
+            if tpf and not a.temporal:                           # (measured on the per-frame plan)
                 tb = tpf * B
                 roof_step.update(traffic_bytes_per_step=tb, traffic_frac=round(tb / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                  traffic_source=prof["step_total"][f"{cfg_name}_{dtype_name}"].get("source"))
