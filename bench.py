@@ -278,7 +278,8 @@ def main(argv=None):
         Bs = eng.B
         n_masked = int(out["n_masked"].sum())
         active = float((out["obj_idxes"] >= 0).sum()) / Bs
-        line_extra.update(mean_active_tracks=round(active, 1), masked_tokens_selected=n_masked)
+        line_extra.update(mean_active_tracks=round(active, 1), masked_tokens_selected=n_masked,
+                          hbm_allocated_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1))
 
         # ---- per-launch timing with HIP events on the launch stream (eager replay of the same plan, one sub-batch engine)
         if not a.no_launch_table:
