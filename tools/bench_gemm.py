@@ -19,6 +19,7 @@ SHAPES = [
     ("L1 3x3s2 32->64", 3, 2, 304, 544, 32, 64, False),
     ("L2m 3x3 32->32", 3, 1, 152, 272, 32, 32, False),
     ("L2cv2 1x1 96->64", 1, 1, 152, 272, 96, 64, False),
+    ("L3 3x3s2 64->128", 3, 2, 152, 272, 64, 128, False),
     ("L4m 3x3 64->64", 3, 1, 76, 136, 64, 64, False),
     ("L4cv2 1x1 256->128", 1, 1, 76, 136, 256, 128, False),
     ("L6m 3x3 128->128", 3, 1, 38, 68, 128, 128, False),
