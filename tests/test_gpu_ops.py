@@ -324,13 +324,13 @@ def test_stem_and_first_downsample_fused(dt, B, H, W):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("B,H,W", [(2, 19, 45), (1, 152, 272), (3, 8, 30), (2, 9, 61)])
+@pytest.mark.parametrize("B,H,W", [(2, 19, 45), (1, 152, 272), (3, 8, 30), (2, 9, 61), (1, 272, 480)])
 def test_c2f_block_fused(dt, B, H, W):
     """moy_c2f_fused (C2f 64 -> [32 | 32] -> 64, n = 1, shortcut: block.py:219-240, :271-283; conv.py:36-38) against (i) the same
     block as four moy_gemm launches -- equal up to the fp32 summation order inside an MFMA, i.e. an ulp of T on a few values --
     and (ii) torch fp32 with every intermediate rounded to T where the launches store it.  Sizes: tiles cut by both image edges
-    (W = 45 -> two tiles of 23; H = 19, 9 -> a last row group of 3 / 1 rows), the C2 layer-2 geometry (152 x 272 -> 10 tiles of
-    28), exactly one tile; input / output as channel slices of wider buffers."""
+    (W = 45 -> two tiles of 23; H = 19, 9 -> a last row group of 3 / 1 rows), the C2 and C4 layer-2 geometries (152 x 272 -> 10
+    tiles of 28; 272 x 480 -> 16 of 30), exactly one tile; input / output as channel slices of wider buffers."""
     c = 32
     x = q(rnd(B, 64, H, W, seed=1), dt)
     ws = dict(cv1=q(rnd(64, 64, seed=2, scale=1 / 8), dt), m1=q(rnd(c, c, 3, 3, seed=3, scale=1 / 17), dt),
