@@ -64,7 +64,8 @@ struct DT<f16_t> {
   // kernels (seen: SiLU epilogue, tiled vs weight-stationary GEMM).
   static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
     asm volatile("" : "+v"(lo), "+v"(hi));
-    return (uint32_t)f2h(lo) | ((uint32_t)f2h(hi) << 16);
+    typedef _Float16 h2_ __attribute__((ext_vector_type(2)));      // both casts at once: ONE v_cvt_pk_f16_f32 (RNE), not cvt, cvt, pack
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_{lo, hi}, h2_));
   }
   static __device__ __forceinline__ float lo(uint32_t w) { return h2f((uint16_t)(w & 0xffffu)); }
   static __device__ __forceinline__ float hi(uint32_t w) { return h2f((uint16_t)(w >> 16)); }
