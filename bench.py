@@ -45,6 +45,8 @@ def parse(argv=None):
     ap.add_argument("--backend", default="auto", choices=["auto", "gloo", "nccl"],
                     help="torch.distributed backend of the timing barrier / MAX reduce (the data path has no collective)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: synthetic step time, exercises the N > 1 control flow")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N > 1 ranks all on GPU 0 of a one-GPU box: runs the real multi-rank code path end to end; its FPS means nothing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=20)
     ap.add_argument("--no-parity", action="store_true")
@@ -54,13 +56,15 @@ def parse(argv=None):
 
 
 def pin_device(local_rank: int):
-    """One process per GPU: make the rank's GPU the only visible one BEFORE anything touches HIP."""
-    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
-    if vis:
-        ids = [v for v in vis.split(",") if v != ""]
-        if len(ids) > 1 and local_rank < len(ids):
-            os.environ["HIP_VISIBLE_DEVICES"] = ids[local_rank]
-        # a single id is already this rank's device
+    """One process per GPU: make the rank's GPU the only visible one BEFORE anything touches HIP.
+    HIP_VISIBLE_DEVICES indexes the devices the ROCr layer exposes (ROCR_VISIBLE_DEVICES narrows that set and renumbers it from
+    0), so: a HIP list handed down by the launcher -> this rank takes its local_rank-th entry; otherwise -> the local rank itself,
+    whatever ROCR_VISIBLE_DEVICES says."""
+    ids = [v for v in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if v != ""]
+    if len(ids) > 1 and local_rank < len(ids):
+        os.environ["HIP_VISIBLE_DEVICES"] = ids[local_rank]
+    elif len(ids) == 1:
+        pass                                              # a single id is already this rank's device
     else:
         os.environ["HIP_VISIBLE_DEVICES"] = str(local_rank)
     return os.environ["HIP_VISIBLE_DEVICES"]
@@ -166,7 +170,7 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", 0))
     visible = None
     if not a.dry_run:
-        visible = pin_device(local)
+        visible = pin_device(0 if a.rehearse_one_gpu else local)
 
     import torch
     from mo_yolo_amd import shard

@@ -127,6 +127,9 @@ def test_bench_pins_one_device_per_local_rank(monkeypatch):
     assert bench.pin_device(2) == "6"
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "5")               # already pinned by the launcher
     assert bench.pin_device(0) == "5"
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "4,5,6,7")        # ROCr renumbers its subset from 0: HIP index = local rank
+    assert bench.pin_device(2) == "2"
 
 
 def _hota_case(g, case):
