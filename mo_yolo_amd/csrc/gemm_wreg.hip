@@ -448,13 +448,26 @@ static int launch_wreg_k(WregParams& p, int K, hipStream_t st) {
   }
 }
 
+// 4 waves x 32 columns = 128 columns per block, two blocks per CU: the 1x1 convs with 128 outputs (C2f cv1 / cv2 at the P3 level)
+template <typename T>
+static int launch_wreg_n128(WregParams& p, int K, hipStream_t st) {
+  switch (K) {
+    case 128: return launch_wreg<T, 32, 3, 2, false, 4, 32, 128>(p, st);
+    case 256: return launch_wreg<T, 32, 3, 2, false, 4, 32, 256>(p, st);
+    default: return MOY_ENOSYS;
+  }
+}
+
 // Eligibility + dispatch; MOY_ENOSYS = not this kernel's shape (moy_gemm falls through to the tiled kernel).
 int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   static int mode = -1;                    // MOY_GEMM_WREG=0 switches the kernel off (A/B runs, bit-identity test)
   if (mode < 0) { const char* e = getenv("MOY_GEMM_WREG"); mode = e ? atoi(e) : 1; }
   if (!mode) return MOY_ENOSYS;
   if (a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_ENOSYS;
-  if (a->ksize != 1 || a->N % 256 || a->N / 256 > 16) return MOY_ENOSYS;
+  static int n128 = -1;                    // MOY_WREG_N128=0: N = 128 stays on the tiled kernel (A/B runs)
+  if (n128 < 0) { const char* e = getenv("MOY_WREG_N128"); n128 = e ? atoi(e) : 1; }
+  const bool is128 = a->N == 128 && n128 && (a->K == 128 || a->K == 256);
+  if (a->ksize != 1 || (!is128 && (a->N % 256 || a->N / 256 > 16))) return MOY_ENOSYS;
   if (a->K != 128 && a->K != 256 && a->K != 384 && a->K != 512) return MOY_ENOSYS;
   if (a->A2 || a->a_rows || a->R || a->out_f32 || a->pre) return MOY_ENOSYS;
   // score mode: LayerNorm + narrow head with NO feature output (C == NULL; moy_gemm documents it); the normalised rows
@@ -468,7 +481,7 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   }
   static int kgen = -1;                    // MOY_WREG_KGEN=0: only the K = 256 forms (A/B runs)
   if (kgen < 0) { const char* e = getenv("MOY_WREG_KGEN"); kgen = e ? atoi(e) : 1; }
-  const bool general = a->K != 256 || a->c_rows_per_batch;       // the 8 x 32-column form
+  const bool general = a->K != 256 || a->c_rows_per_batch || is128;       // the 32-columns-per-wave forms
   if (general && (!kgen || a->plane_cols)) return MOY_ENOSYS;
   if (a->c_rows_per_batch) {               // per-lane 32-bit byte offsets into the remapped C
     const int64_t rows = ((int64_t)a->M / a->c_rows_per_batch + 1) * a->c_batch_stride;
@@ -484,6 +497,7 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   p.C = a->C; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.ngroups = a->N / 256;
   p.plane_cols = a->plane_cols; p.plane_stride = a->plane_stride;
   p.c_rpb = a->c_rows_per_batch; p.c_bstride = a->c_batch_stride; p.fd_rpb = make_fastdiv(p.c_rpb > 0 ? p.c_rpb : 1);
+  if (is128) return a->dtype == MOY_BF16 ? launch_wreg_n128<bf16_t>(p, a->K, st) : launch_wreg_n128<f16_t>(p, a->K, st);
   if (general) return a->dtype == MOY_BF16 ? launch_wreg_k<bf16_t>(p, a->K, st) : launch_wreg_k<f16_t>(p, a->K, st);
   if (score) {
     p.ln_g = a->ln_g; p.ln_b = a->ln_b; p.dot_w = a->dot_w; p.dot_b = a->dot_b; p.dot_out = a->dot_out; p.dot_n = a->dot_n;
