@@ -683,6 +683,101 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const T* __restrict__ v
   DT<T>::store4(out + (long)row * ldo + m * 32 + sub * 4, acc);
 }
 
+// Head-plane form of the kernel above for 16-bit values (value[(b*S + s)*32 + m*head_stride + d]: the 32 channels of a head are
+// 64 contiguous bytes and the tokens x0, x0 + 1 of a bilinear sample are 128 CONTIGUOUS bytes).  The gather is bound by the number
+// of random accesses, not by bytes, so the two x-corners of a sample row are fetched by ONE instruction:
+// lane = head*8 + sub, sub = corner_x*4 + channel octet -- 16 bytes per lane, 128 contiguous bytes per head: 24 loads of 16 bytes
+// per lane instead of 48 of 8, half as many requests.  Every lane accumulates its own corner's share of its 8 channels (the
+// sum over corners is linear); the two corner lanes are added once at the end (one xor-4 shuffle per channel).  Addresses are
+// 32-bit offsets into a per-frame buffer descriptor (head_stride * 8 * 2 bytes < 2 GiB, checked by the host); a corner outside
+// the level is an out-of-range offset (the hardware returns zeros): no branch around any load, all 24 in flight at once.
+template <typename T>
+__global__ __launch_bounds__(256) void msda_planes_kernel(const T* __restrict__ value, int64_t head_stride, int S, LevelInfo lv, int L,
+                                                          const float* __restrict__ offaw, int64_t ld_oa,
+                                                          const float* __restrict__ ref, int Lq, int nrows,
+                                                          T* __restrict__ out, int64_t ldo) {
+  static_assert(sizeof(T) == 2, "16-bit values");
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int b = __builtin_amdgcn_readfirstlane(row / Lq);
+  const int m = lane >> 3, sub = lane & 7, cx = sub >> 2, oct = sub & 3;
+  const int LP = L * 4;
+  const float* oa = offaw + (long)row * ld_oa;
+  const float* offp = oa + m * LP * 2;
+  const float* awp = oa + 8 * LP * 2 + m * LP;
+  float logit[16], offx[16], offy[16];
+#pragma unroll
+  for (int i = 0; i < 16; i += 4)
+    if (i < LP) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(awp + i);
+      logit[i] = a.x; logit[i + 1] = a.y; logit[i + 2] = a.z; logit[i + 3] = a.w;
+      const f32x4 o0 = *reinterpret_cast<const f32x4*>(offp + 2 * i), o1 = *reinterpret_cast<const f32x4*>(offp + 2 * i + 4);
+      offx[i] = o0.x; offy[i] = o0.y; offx[i + 1] = o0.z; offy[i + 1] = o0.w;
+      offx[i + 2] = o1.x; offy[i + 2] = o1.y; offx[i + 3] = o1.z; offy[i + 3] = o1.w;
+    }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (i < LP) mx = fmaxf(mx, logit[i]);
+  float den = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (i < LP) { logit[i] = expf(logit[i] - mx); den += logit[i]; }
+  const float inv_den = 1.0f / den;
+  const f32x4 rb = *reinterpret_cast<const f32x4*>(ref + (long)row * 4);
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(value + (int64_t)b * S * 32), 0, 0x80000000u, 0x00020000);
+  const uint32_t lane_off = (uint32_t)((m * head_stride + oct * 8) * 2);
+  constexpr uint32_t OOB = 0x80000000u;
+  u32x4 tap[16][2];
+  float wgt[16][2];
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+    if (l < L) {
+      const int H = lv.H[l], W = lv.W[l];
+#pragma unroll
+      for (int pnt = 0; pnt < 4; ++pnt) {
+        const int i = l * 4 + pnt;
+        // loc = ref_xy + off / n_points * ref_wh * 0.5   (transformer.py:280-282)
+        const float lx = rb.x + offx[i] / 4.0f * rb.z * 0.5f;
+        const float ly = rb.y + offy[i] / 4.0f * rb.w * 0.5f;
+        const float x = lx * W - 0.5f, y = ly * H - 0.5f;
+        const float aw = logit[i] * inv_den;
+        const float xf = floorf(x), yf = floorf(y);
+        const float fx = x - xf, fy = y - yf;
+        const int xi = (int)xf + cx, y0 = (int)yf;
+        const float wx = (cx ? fx : 1.f - fx) * aw;
+        const bool xin = (unsigned)xi < (unsigned)W;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int yi = y0 + t;
+          const bool ok = xin && (unsigned)yi < (unsigned)H;
+          const uint32_t off = lane_off + (uint32_t)((lv.start[l] + yi * W + xi) * 64);
+          tap[i][t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0));
+          wgt[i][t] = wx * (t ? fy : 1.f - fy);
+        }
+      }
+    }
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+    if (l < L)
+#pragma unroll
+      for (int pnt = 0; pnt < 4; ++pnt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {                    // same order of the four corners per sample as the kernel above: (x0,y0) (x1,y0) (x0,y1) (x1,y1)
+          const u32x4 w = tap[l * 4 + pnt][t];
+          const float g = wgt[l * 4 + pnt][t];
+          acc[0] += DT<T>::lo(w.x) * g; acc[1] += DT<T>::hi(w.x) * g; acc[2] += DT<T>::lo(w.y) * g; acc[3] += DT<T>::hi(w.y) * g;
+          acc[4] += DT<T>::lo(w.z) * g; acc[5] += DT<T>::hi(w.z) * g; acc[6] += DT<T>::lo(w.w) * g; acc[7] += DT<T>::hi(w.w) * g;
+        }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], 4);
+  if (cx == 0)
+    *reinterpret_cast<u32x4*>(out + (long)row * ldo + m * 32 + oct * 8) =
+        u32x4{DT<T>::pack2(acc[0], acc[1]), DT<T>::pack2(acc[2], acc[3]), DT<T>::pack2(acc[4], acc[5]), DT<T>::pack2(acc[6], acc[7])};
+}
+
 // ------------------------------------------------------------------------------------------------
 // Stretch resize of uint8 HWC frames = cv2.resize(img, (Wd, Hd), interpolation=cv2.INTER_LINEAR), the only thing
 // LetterBox does on the tracking path (scaleFill branch, data/augment.py:573-576, called from
@@ -1629,6 +1724,23 @@ extern "C" int moy_mha_core(const void* qkv, int64_t ld_qkv, int B, int L, int n
   return mha_host(qkv, ld_qkv, B, L, nh, E, nullptr, L, out, ldo, dtype, stream);
 }
 
+// The paired-corner kernel when the layout allows it (16-bit head planes); MOY_ENOSYS = use msda_fused_kernel.
+template <typename T>
+static int try_msda_planes(const void* value, int64_t ldv, int64_t head_stride, int S, const LevelInfo& lv, int L, const float* offaw, int64_t ld_oa,
+                           const float* ref, int Lq, int nrows, void* out, int64_t ldo, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    static int planes = -1;                  // MOY_MSDA_PLANES=0: the one-corner-per-load kernel on every layout (A/B runs)
+    if (planes < 0) { const char* e = getenv("MOY_MSDA_PLANES"); planes = e ? atoi(e) : 1; }
+    if (planes && ldv == 32 && head_stride * 8 * 2 <= 0x7fffffffLL && (int64_t)S * 64 <= 0x0fffffffLL && aligned16(value) && aligned16(out) &&
+        (ldo % 8) == 0 && (head_stride % 8) == 0) {
+      hipLaunchKernelGGL((msda_planes_kernel<T>), dim3((nrows + 3) / 4), dim3(256), 0, st, static_cast<const T*>(value), head_stride, S, lv, L,
+                         offaw, ld_oa, ref, Lq, nrows, static_cast<T*>(out), ldo);
+      return launch_status();
+    }
+  }
+  return MOY_ENOSYS;
+}
+
 extern "C" int moy_msda_fused(const void* value, int64_t ldv, int64_t head_stride, int B, int S, const int32_t* shapes_hw, int L, const float* offaw,
                               int64_t ld_oa, const float* ref, int Lq, void* out, int64_t ldo, int dtype, void* stream) {
   if (!value || !shapes_hw || !offaw || !ref || !out || B <= 0 || S <= 0 || L <= 0 || L > 4 || Lq <= 0) return MOY_EINVAL;
@@ -1647,6 +1759,10 @@ extern "C" int moy_msda_fused(const void* value, int64_t ldv, int64_t head_strid
     if (reinterpret_cast<uintptr_t>(value) % (4 * sizeof(T)) || !aligned16(offaw) ||
         reinterpret_cast<uintptr_t>(out) % (4 * sizeof(T)))
       return MOY_EINVAL;
+    {
+      const int rc = try_msda_planes<T>(value, ldv, head_stride, S, lv, L, offaw, ld_oa, ref, Lq, nrows, out, ldo, st);
+      if (rc != MOY_ENOSYS) return rc;
+    }
     hipLaunchKernelGGL((msda_fused_kernel<T>), dim3((nrows + 3) / 4), dim3(256), 0, st, static_cast<const T*>(value), ldv, head_stride, S, lv, L,
                        offaw, ld_oa, ref, Lq, nrows, static_cast<T*>(out), ldo);
     return launch_status();
