@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const T* __restrict__ v
 // sum over corners is linear); the two corner lanes are added once at the end (one xor-4 shuffle per channel).  Addresses are
 // 32-bit offsets into a per-frame buffer descriptor (head_stride * 8 * 2 bytes < 2 GiB, checked by the host); a corner outside
 // the level is an out-of-range offset (the hardware returns zeros): no branch around any load, all 24 in flight at once.
-template <typename T>
+template <typename T, int MODE = 1>     // taps in flight per wave: 0 all levels (209 VGPRs, 2 waves/SIMD), 1 one level (114, 4 waves/SIMD: the default), 2 two levels; MOY_MSDA_PLANES=2 / 1 / 3
 __global__ __launch_bounds__(256) void msda_planes_kernel(const T* __restrict__ value, int64_t head_stride, int S, LevelInfo lv, int L,
                                                           const float* __restrict__ offaw, int64_t ld_oa,
                                                           const float* __restrict__ ref, int Lq, int nrows,
@@ -729,48 +729,72 @@ __global__ __launch_bounds__(256) void msda_planes_kernel(const T* __restrict__ 
   const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(value + (int64_t)b * S * 32), 0, 0x80000000u, 0x00020000);
   const uint32_t lane_off = (uint32_t)((m * head_stride + oct * 8) * 2);
   constexpr uint32_t OOB = 0x80000000u;
-  u32x4 tap[16][2];
-  float wgt[16][2];
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto level_taps = [&](int l, u32x4 (&tap)[4][2], float (&wgt)[4][2]) {
+    const int H = lv.H[l], W = lv.W[l];
 #pragma unroll
-  for (int l = 0; l < 4; ++l)
-    if (l < L) {
-      const int H = lv.H[l], W = lv.W[l];
+    for (int pnt = 0; pnt < 4; ++pnt) {
+      const int i = l * 4 + pnt;
+      // loc = ref_xy + off / n_points * ref_wh * 0.5   (transformer.py:280-282)
+      const float lx = rb.x + offx[i] / 4.0f * rb.z * 0.5f;
+      const float ly = rb.y + offy[i] / 4.0f * rb.w * 0.5f;
+      const float x = lx * W - 0.5f, y = ly * H - 0.5f;
+      const float aw = logit[i] * inv_den;
+      const float xf = floorf(x), yf = floorf(y);
+      const float fx = x - xf, fy = y - yf;
+      const int xi = (int)xf + cx, y0 = (int)yf;
+      const float wx = (cx ? fx : 1.f - fx) * aw;
+      const bool xin = (unsigned)xi < (unsigned)W;
 #pragma unroll
-      for (int pnt = 0; pnt < 4; ++pnt) {
-        const int i = l * 4 + pnt;
-        // loc = ref_xy + off / n_points * ref_wh * 0.5   (transformer.py:280-282)
-        const float lx = rb.x + offx[i] / 4.0f * rb.z * 0.5f;
-        const float ly = rb.y + offy[i] / 4.0f * rb.w * 0.5f;
-        const float x = lx * W - 0.5f, y = ly * H - 0.5f;
-        const float aw = logit[i] * inv_den;
-        const float xf = floorf(x), yf = floorf(y);
-        const float fx = x - xf, fy = y - yf;
-        const int xi = (int)xf + cx, y0 = (int)yf;
-        const float wx = (cx ? fx : 1.f - fx) * aw;
-        const bool xin = (unsigned)xi < (unsigned)W;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int yi = y0 + t;
-          const bool ok = xin && (unsigned)yi < (unsigned)H;
-          const uint32_t off = lane_off + (uint32_t)((lv.start[l] + yi * W + xi) * 64);
-          tap[i][t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0));
-          wgt[i][t] = wx * (t ? fy : 1.f - fy);
-        }
+      for (int t = 0; t < 2; ++t) {
+        const int yi = y0 + t;
+        const bool ok = xin && (unsigned)yi < (unsigned)H;
+        const uint32_t off = lane_off + (uint32_t)((lv.start[l] + yi * W + xi) * 64);
+        tap[pnt][t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0));
+        wgt[pnt][t] = wx * (t ? fy : 1.f - fy);
       }
     }
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  };
+  auto level_acc = [&](const u32x4 (&tap)[4][2], const float (&wgt)[4][2]) {
 #pragma unroll
-  for (int l = 0; l < 4; ++l)
-    if (l < L)
+    for (int pnt = 0; pnt < 4; ++pnt)
 #pragma unroll
-      for (int pnt = 0; pnt < 4; ++pnt)
+      for (int t = 0; t < 2; ++t) {                      // same order of the four corners per sample as the kernel above
+        const u32x4 w = tap[pnt][t];
+        const float g = wgt[pnt][t];
+        acc[0] += DT<T>::lo(w.x) * g; acc[1] += DT<T>::hi(w.x) * g; acc[2] += DT<T>::lo(w.y) * g; acc[3] += DT<T>::hi(w.y) * g;
+        acc[4] += DT<T>::lo(w.z) * g; acc[5] += DT<T>::hi(w.z) * g; acc[6] += DT<T>::lo(w.w) * g; acc[7] += DT<T>::hi(w.w) * g;
+      }
+  };
+  if constexpr (MODE == 0) {                              // all levels' taps in flight at once
+    u32x4 tap[4][4][2];
+    float wgt[4][4][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {                    // same order of the four corners per sample as the kernel above: (x0,y0) (x1,y0) (x0,y1) (x1,y1)
-          const u32x4 w = tap[l * 4 + pnt][t];
-          const float g = wgt[l * 4 + pnt][t];
-          acc[0] += DT<T>::lo(w.x) * g; acc[1] += DT<T>::hi(w.x) * g; acc[2] += DT<T>::lo(w.y) * g; acc[3] += DT<T>::hi(w.y) * g;
-          acc[4] += DT<T>::lo(w.z) * g; acc[5] += DT<T>::hi(w.z) * g; acc[6] += DT<T>::lo(w.w) * g; acc[7] += DT<T>::hi(w.w) * g;
-        }
+    for (int l = 0; l < 4; ++l)
+      if (l < L) level_taps(l, tap[l], wgt[l]);
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+      if (l < L) level_acc(tap[l], wgt[l]);
+  } else if constexpr (MODE == 1) {                       // level by level
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+      if (l < L) {
+        u32x4 tap[4][2];
+        float wgt[4][2];
+        level_taps(l, tap, wgt);
+        level_acc(tap, wgt);
+      }
+  } else {                                                // two levels in flight: level l+1's taps issued before level l is summed
+    u32x4 tap[2][4][2];
+    float wgt[2][4][2];
+    level_taps(0, tap[0], wgt[0]);
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+      if (l < L) {
+        if (l + 1 < L) level_taps(l + 1, tap[(l + 1) & 1], wgt[(l + 1) & 1]);
+        level_acc(tap[l & 1], wgt[l & 1]);
+      }
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], 4);
   if (cx == 0)
@@ -1733,8 +1757,15 @@ static int try_msda_planes(const void* value, int64_t ldv, int64_t head_stride, 
     if (planes < 0) { const char* e = getenv("MOY_MSDA_PLANES"); planes = e ? atoi(e) : 1; }
     if (planes && ldv == 32 && head_stride * 8 * 2 <= 0x7fffffffLL && (int64_t)S * 64 <= 0x0fffffffLL && aligned16(value) && aligned16(out) &&
         (ldo % 8) == 0 && (head_stride % 8) == 0) {
-      hipLaunchKernelGGL((msda_planes_kernel<T>), dim3((nrows + 3) / 4), dim3(256), 0, st, static_cast<const T*>(value), head_stride, S, lv, L,
-                         offaw, ld_oa, ref, Lq, nrows, static_cast<T*>(out), ldo);
+      if (planes == 3)
+        hipLaunchKernelGGL((msda_planes_kernel<T, 2>), dim3((nrows + 3) / 4), dim3(256), 0, st, static_cast<const T*>(value), head_stride, S, lv, L,
+                           offaw, ld_oa, ref, Lq, nrows, static_cast<T*>(out), ldo);
+      else if (planes == 2)
+        hipLaunchKernelGGL((msda_planes_kernel<T, 0>), dim3((nrows + 3) / 4), dim3(256), 0, st, static_cast<const T*>(value), head_stride, S, lv, L,
+                           offaw, ld_oa, ref, Lq, nrows, static_cast<T*>(out), ldo);
+      else
+        hipLaunchKernelGGL((msda_planes_kernel<T, 1>), dim3((nrows + 3) / 4), dim3(256), 0, st, static_cast<const T*>(value), head_stride, S, lv, L,
+                           offaw, ld_oa, ref, Lq, nrows, static_cast<T*>(out), ldo);
       return launch_status();
     }
   }
