@@ -513,6 +513,9 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   if (a->dtype == MOY_BF16) {
     if (variant == 1) return launch_wreg<bf16_t, 64, 3, 1>(p, st);
     if (variant == 2 || a->N % 512) return launch_wreg<bf16_t, 32, 3, 2>(p, st);
+    if (variant == 3) return launch_wreg<bf16_t, 32, 4, 1, false, 8>(p, st);      // 8 waves, ring of 4 (three tiles ahead)
+    if (variant == 4) return launch_wreg<bf16_t, 64, 2, 1, false, 8>(p, st);      // 8 waves, 64-row tiles, ring of 2
+    if (variant == 5) return launch_wreg<bf16_t, 16, 4, 1, false, 8>(p, st);      // 8 waves, 16-row tiles, ring of 4
     return launch_wreg<bf16_t, 32, 3, 1, false, 8>(p, st);
   }
   if (a->N % 512) return launch_wreg<f16_t, 32, 3, 2>(p, st);
