@@ -6,7 +6,7 @@
 //     y2      = y1 + SiLU(BN(m.cv2 * z))               3x3, 32 -> 32
 //     out     = SiLU(BN(cv2 . [y0 | y1 | y2]))         1x1, 96 -> 64
 //
-// Why: as four launches this block was 2.66 ms of a 25.7 ms pass (profiles/r02_a_launch_table_c2_bf16.json, launches 1-4), every one
+// Why: as four launches this block was 2.66 ms of a 25.7 ms pass (per-launch table of the plan before this kernel), every one
 // of them bound by HBM at the largest pixel count of the network (11.9 M pixels per 288 frames): 448 channel-values moved per pixel
 // where the block's input and output are 128.  Fused, y0, y1, z and y2 only exist as the tile images of one block in LDS:
 //   * a block owns TH x TW (8 x <= 30) output pixels; z is needed on (TH+2) x 32 pixels, y1 on (TH+4) x 34 (conv halos, recomputed
