@@ -6,13 +6,18 @@
 //     y2      = y1 + SiLU(BN(m.cv2 * z))               3x3, 32 -> 32
 //     out     = SiLU(BN(cv2 . [y0 | y1 | y2]))         1x1, 96 -> 64
 //
-// Why: as four launches this block was 2.66 ms of a 25.7 ms pass (per-launch table of the plan before this kernel), every one
-// of them bound by HBM at the largest pixel count of the network (11.9 M pixels per 288 frames): 448 channel-values moved per pixel
-// where the block's input and output are 128.  Fused, y0, y1, z and y2 only exist as the tile images of one block in LDS:
-//   * a block owns TH x TW (8 x <= 30) output pixels; z is needed on (TH+2) x 32 pixels, y1 on (TH+4) x 34 (conv halos, recomputed
-//     by the neighbours: 1.7x on cv1, 1.33x on the first 3x3 -- cheap next to the traffic they replace);
+// Why: as four launches this block was 2.66 ms of a 25.7 ms pass (per-launch table of the plan before this kernel),
+// every one of them bound by HBM at the largest pixel count of the network (11.9 M pixels per 288 frames): 448 channel-values moved
+// per pixel where the block's input and output are 128.  Fused, y0, y1, z and y2 only exist as images of one block in LDS:
+//   * a block walks a STRIP -- a column of 8 x (<= 30)-pixel tiles of one image -- from top to bottom and keeps y0, y1 and z in ROW
+//     RINGS (image row a in slot a & 15): the rows two neighbouring tiles share (4 of y1's 12, 2 of z's 10) are computed once, so a
+//     tile adds 8 new rows to each ring; a pseudo tile above the first one fills the rings.  Column halos (y1 on 34, z on 32 columns)
+//     are recomputed by the horizontal neighbours.  SiLU work per output pixel 224 values instead of 272 with independent tiles --
+//     the kernel is bound by its SiLU epilogues (2 transcendentals per value), not by bytes or the matrix pipe;
+//   * work units: every block gets the same number of whole strips, the strips left over are cut into row ranges (one per block);
 //   * cv1 reads its B operands STRAIGHT from global memory (a lane's fragment slice is 16 contiguous bytes of one pixel), one
-//     tile ahead, into registers; everything else is LDS -> MFMA -> LDS;
+//     tile ahead, into registers (17 fragments per tile: two per wave, the 17th split over four waves); everything else is
+//     LDS -> MFMA -> LDS;
 //   * all four weight sets stay in registers for the whole launch (116 VGPRs per wave), the BN tables in LDS;
 //   * pixels outside the image are ZERO in y1 and z (the zero padding of the two 3x3 convs), not SiLU(BN(0));
 //   * every intermediate is rounded to T exactly where the separate launches store it, the taps accumulate in the same order
@@ -20,9 +25,9 @@
 // LDS images of the 32-channel tensors are CHUNK-PLANAR: plane c (channels 8c .. 8c+7) holds 16 bytes per pixel, pixels in patch
 // order.  An MFMA B-fragment read (lane (r, q): chunk q of pixel P + r) is then 256 contiguous bytes per 16-lane group -- conflict
 // free without an XOR swizzle -- and its address is ONE per-lane base register plus an immediate for every (row, column fragment,
-// tap column): the XOR-swizzled pixel-major images of the first version spent 5 VALU operations per fragment address, more than
-// the SiLU epilogues.  The output tile is pixel-major [pixel][64 ch] with chunk ^= pixel & 7 (whole-line 16-byte stores).
-// 126 KB of LDS, one block of 8 waves per CU.
+// tap column) (+ one addition per ring row): the XOR-swizzled pixel-major images of the first version spent 5 VALU operations per
+// fragment address, more than the SiLU epilogues.  The output tile is pixel-major [pixel][64 ch] with chunk ^= pixel & 7 (whole-line
+// 16-byte stores).  156 KB of LDS, one block of 8 waves per CU.
 #include "common.hpp"
 
 #include <type_traits>
@@ -37,8 +42,9 @@ struct C2fParams {
   const void* W2; int kp2; const float* sc2; const float* sh2;  // cv2   T [64][kp2], k = [y0 | y1 | y2]
   void* Out; int64_t ldo;
   int B, H, Wd, TW;
-  int tiles_x, tiles_img, ntiles, per_xcd, bpx;
-  FastDiv fd_timg, fd_tx;
+  int tiles_x, nstrips, bpx;        // bpx: blocks per XCD
+  int nfull, rem, parts;            // whole strips per block; strips left over; row ranges each of those is cut into
+  FastDiv fd_tx;
 };
 
 template <typename T>
@@ -52,26 +58,28 @@ __device__ __forceinline__ f32x4 c2f_mfma<f16_t>(f32x4 acc, u32x4 w, u32x4 a) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
 }
 
-constexpr int C2F_TH = 8, C2F_PW = 34, C2F_TWMAX = 30;
-constexpr int C2F_PL1 = (C2F_TH + 4) * C2F_PW * 16, C2F_PLZ = (C2F_TH + 2) * C2F_PW * 16, C2F_PL2 = C2F_TH * C2F_PW * 16;   // plane sizes
+constexpr int C2F_TH = 8, C2F_PW = 34, C2F_TWMAX = 30, C2F_RING = 16;
+constexpr int C2F_PLR = C2F_RING * C2F_PW * 16, C2F_PL2 = C2F_TH * C2F_PW * 16;   // plane sizes: row-ring images, tile-local image
 constexpr int C2F_SGB = C2F_TH * 32 * 128;
-constexpr int C2F_LDS = 8 * C2F_PL1 + 4 * C2F_PLZ + 4 * C2F_PL2 + C2F_SGB + 384 * 4;
+constexpr int C2F_LDS = 12 * C2F_PLR + 4 * C2F_PL2 + C2F_SGB + 384 * 4;
 
 __device__ __forceinline__ f32x4 silu4(f32x4 v) { return f32x4{siluf_(v.x), siluf_(v.y), siluf_(v.z), siluf_(v.w)}; }
 
 template <typename T, int DIAG = 0>     // DIAG = 1: s_memtime stamps of wave 0 (MOY_C2F_DIAG=1; garbage at the head of the output)
 __global__ __launch_bounds__(512, 2) void c2f_fused_kernel(const C2fParams p) {
-  constexpr int TH = C2F_TH, PW = C2F_PW, PH = TH + 4, NP1 = PH * PW;
-  constexpr int NF1 = (NP1 + 15) / 16, FPW1 = (NF1 + 7) / 8;           // cv1 fragments (16 patch pixels each), per wave
+  constexpr int TH = C2F_TH, PW = C2F_PW, RING = C2F_RING, ROWB = PW * 16;
+  constexpr int NPN = TH * PW;                                          // y0 / y1 pixels new per tile: 8 rows x 34
+  constexpr int NF1 = NPN / 16, FPW1 = 3;                               // 17 fragments: two per wave + the 17th split over four waves
+  static_assert(NF1 == 17, "cv1 fragment dealing");
   constexpr uint32_t OOB = 0x80000000u;
-  static_assert(sizeof(T) == 2, "16-bit types");
+  static_assert(sizeof(T) == 2 && NPN % 16 == 0, "16-bit types; whole fragments");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int PL1 = C2F_PL1, PLZ = C2F_PLZ, PL2 = C2F_PL2;
-  unsigned char* Y1 = smem;                         // 4 planes x [PH][PW] pixels: y1 with a halo of 2
-  unsigned char* Y0 = Y1 + 4 * PL1;                 // same pixel indexing; only the tile pixels are written / read
-  unsigned char* Zs = Y0 + 4 * PL1;                 // 4 planes x [TH+2][PW] pixels: z with a halo of 1 (columns 32, 33: never written)
-  unsigned char* Y2 = Zs + 4 * PLZ;                 // 4 planes x [TH][PW] pixels
+  constexpr int PLR = C2F_PLR, PL2 = C2F_PL2;
+  unsigned char* Y1 = smem;                         // 4 planes x [RING rows][PW]: y1, image row a in ring slot a & 15
+  unsigned char* Y0 = Y1 + 4 * PLR;                 // same indexing (columns >= 2 of image rows only)
+  unsigned char* Zs = Y0 + 4 * PLR;                 // same indexing, z column zc = image column x0 - 1 + zc (columns 32, 33: never written)
+  unsigned char* Y2 = Zs + 4 * PLR;                 // 4 planes x [TH][PW] pixels of the tile
   unsigned char* Sg = Y2 + 4 * PL2;                 // [TH][32] pixels x 64 ch: output tile
   float* bn = reinterpret_cast<float*>(Sg + C2F_SGB);      // sc1 sh1 [64] | sca sha [32] | scb shb [32] | sc2 sh2 [64]
 
@@ -79,11 +87,28 @@ __global__ __launch_bounds__(512, 2) void c2f_fused_kernel(const C2fParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
 
+  // ---- this block's work units.  A strip = one column of tiles of one image, walked top to bottom (a pseudo tile above its first
+  // tile fills the rings).  Every block takes `nfull` whole strips -- XCD x owns the strip range [x, x + 1) * nfull * bpx, its
+  // blocks consecutive strips: horizontal neighbours share halo columns through that L2 -- and the `rem` strips left over are cut
+  // into `parts` row ranges, one per block, so that no block walks a whole extra strip while the others idle.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int t_first = xcd * p.per_xcd + slot;
-  const int t_limit = min((xcd + 1) * p.per_xcd, p.ntiles);
-  if (t_first >= t_limit) return;
-  const int n_mine = (t_limit - t_first + p.bpx - 1) / p.bpx;
+  const int nty = (p.H + TH - 1) / TH;
+  const int lin = xcd * p.bpx + slot;
+  const bool has_part = lin < p.rem * p.parts;
+  const int n_units = p.nfull + (has_part ? 1 : 0);
+  if (n_units == 0) return;
+  struct Unit { int sid, kb, ke; };                 // strip, tiles [kb, ke)
+  auto unit_of = [&](int u) {
+    Unit un;
+    if (u < p.nfull) {
+      un.sid = xcd * (p.nfull * p.bpx) + u * p.bpx + slot; un.kb = 0; un.ke = nty;
+    } else {
+      const int sp = lin / p.parts, part = lin - sp * p.parts;
+      un.sid = p.nfull * 8 * p.bpx + sp;
+      un.kb = part * nty / p.parts; un.ke = (part + 1) * nty / p.parts;
+    }
+    return un;
+  };
 
   if (tid < 384) {
     float v;
@@ -98,15 +123,13 @@ __global__ __launch_bounds__(512, 2) void c2f_fused_kernel(const C2fParams p) {
     bn[tid] = v;
   }
 
-  struct Tile { int b, y0, x0; };
-  auto tile_of = [&](int it) {
+  struct Tile { int b, y0, x0; };                   // y0 = (kb - 1) * TH: the pseudo tile that starts a unit
+  auto tile_of = [&](int sid, int k) {
     Tile t;
-    const int id = min(t_first + it * p.bpx, p.ntiles - 1);
-    t.b = (int)fdiv((uint32_t)id, p.fd_timg);
-    const int rem = id - t.b * p.tiles_img;
-    const int ty = (int)fdiv((uint32_t)rem, p.fd_tx);
-    t.y0 = ty * TH;
-    t.x0 = (rem - ty * p.tiles_x) * p.TW;
+    const int id = min(sid, p.nstrips - 1);
+    t.b = (int)fdiv((uint32_t)id, p.fd_tx);
+    t.x0 = (id - t.b * p.tiles_x) * p.TW;
+    t.y0 = k * TH;
     return t;
   };
 
@@ -115,8 +138,8 @@ __global__ __launch_bounds__(512, 2) void c2f_fused_kernel(const C2fParams p) {
   const T* Wa = static_cast<const T*>(p.Wa);
   const T* Wb = static_cast<const T*>(p.Wb);
   const T* W2 = static_cast<const T*>(p.W2);
-  const int wn = wave & 1, wm = wave >> 1;          // the 3x3 convs: 16-channel half, row group
-  const int nf = wave & 3, gh = wave >> 2;          // cv2: 16-channel quarter, fragment parity
+  const int wn = wave & 1, wm = wave >> 1;          // the 3x3 convs: 16-channel half, row pair
+  const int nf = wave & 3, gh = wave >> 2;          // cv2: 16-channel quarter, column half
   u32x4 w1f[4][2], waf[9], wbf[9], w2f[3];
 #pragma unroll
   for (int n = 0; n < 4; ++n)
@@ -134,17 +157,19 @@ __global__ __launch_bounds__(512, 2) void c2f_fused_kernel(const C2fParams p) {
   T* __restrict__ Og = static_cast<T*>(p.Out);
   const int64_t img_x = (int64_t)p.H * p.Wd * p.ldx, img_o = (int64_t)p.H * p.Wd * p.ldo;
 
-  // cv1's B operands of a tile: fragment f = wave + 8 i covers patch pixels f*16 .. +15; lane (r, q): 16 bytes at channel q*8 of
-  // each 32-channel half.  Pixels outside the image: out-of-range offsets (zeros; the epilogue zeroes y1 there anyway).
+  // cv1's B operands of a tile = the 8 NEW y0 | y1 rows it adds to the ring (image rows y0 + 2 .. y0 + 9, 34 columns): fragment
+  // f = wave + 8 i covers pixels f*16 .. +15 of them; lane (r, q): 16 bytes at channel q*8 of each 32-channel half.  Pixels outside
+  // the image: out-of-range offsets (zeros; the epilogue zeroes y1 there anyway).
   u32x4 xr[FPW1][2];
   auto load_x = [&](const Tile& t) {
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Xg + (int64_t)t.b * img_x), 0, (uint32_t)(img_x * 2), 0x00020000);
 #pragma unroll
     for (int i = 0; i < FPW1; ++i) {
-      const int p1 = (wave + 8 * i) * 16 + r;
-      const int row = p1 / PW, col = p1 - row * PW;
-      const int iy = t.y0 - 2 + row, ix = t.x0 - 2 + col;
-      const bool ok = p1 < NP1 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
+      const int f = i < 2 ? wave + 8 * i : 16;          // the 17th fragment is shared by waves 0-3, one 16-channel quarter each
+      const int pp = f * 16 + r;
+      const int jj = pp / PW, col = pp - jj * PW;
+      const int iy = t.y0 + 2 + jj, ix = t.x0 - 2 + col;
+      const bool ok = (i < 2 || wave < 4) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
       const uint32_t off = (uint32_t)(((iy * p.Wd + ix) * (int)p.ldx + q * 8) * 2);
       xr[i][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0));
       xr[i][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 64 : OOB, 0, 0));
@@ -161,162 +186,184 @@ __global__ __launch_bounds__(512, 2) void c2f_fused_kernel(const C2fParams p) {
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  auto slot_of = [&](int a) { return (a + 4 * RING) & (RING - 1); };       // ring slot of image row a (a >= -4 RING)
 
-  // One 3x3 conv phase of this wave: NR output rows from row r0, both 16-pixel column fragments, 16 output channels (half wn).
-  // src: [rows][PW] pixel image; a fragment row read for tap column kx serves the three tap rows of up to NR output rows.
-  auto conv3 = [&](auto nr_tag, const unsigned char* src, int plane, const u32x4 (&wf)[9], int r0, f32x4 (&acc)[3][2]) {
-    constexpr int NR = decltype(nr_tag)::value;
-    const unsigned char* base = src + q * plane + (r0 * PW + r) * 16;       // every fragment address = base + immediate
+  // One 3x3 conv phase of this wave: two output rows, both 16-pixel column fragments, 16 output channels (half wn).  src: a ring
+  // image; the four source rows are image rows a0 .. a0 + 3; a fragment row read for tap column kx serves the three tap rows of
+  // both output rows.  Every address = (lane base + row slot offset: 4 additions per phase) + immediate.
+  auto conv3 = [&](const unsigned char* src, const u32x4 (&wf)[9], int a0, f32x4 (&acc)[2][2]) {
+    const int lb = q * PLR + r * 16;
+    const unsigned char* rowb[4];
+#pragma unroll
+    for (int y = 0; y < 4; ++y) rowb[y] = src + (lb + slot_of(a0 + y) * ROWB);
 #pragma unroll
     for (int cf = 0; cf < 2; ++cf) {
 #pragma unroll
-      for (int y = 0; y < NR; ++y) acc[y][cf] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int y = 0; y < 2; ++y) acc[y][cf] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        u32x4 a[NR + 2];
+        u32x4 a[4];
 #pragma unroll
-        for (int y = 0; y < NR + 2; ++y) a[y] = *reinterpret_cast<const u32x4*>(base + (y * PW + cf * 16 + kx) * 16);
+        for (int y = 0; y < 4; ++y) a[y] = *reinterpret_cast<const u32x4*>(rowb[y] + (cf * 16 + kx) * 16);
 #pragma unroll
-        for (int y = 0; y < NR; ++y)
+        for (int y = 0; y < 2; ++y)
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky) acc[y][cf] = c2f_mfma<T>(acc[y][cf], wf[ky * 3 + kx], a[y + ky]);
       }
     }
   };
-  // first 3x3: z = SiLU(BN(.)) on rows r0 .. r0+NR-1 of the z image, zero outside the frame
-  auto phase_z = [&](auto nr_tag, const Tile& t, int r0) {
-    constexpr int NR = decltype(nr_tag)::value;
-    f32x4 acc[3][2];
-    conv3(nr_tag, Y1, PL1, waf, r0, acc);
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(bn + 128 + wn * 16 + q * 4), sh = *reinterpret_cast<const f32x4*>(bn + 160 + wn * 16 + q * 4);
-    unsigned char* zb = Zs + (wn * 2 + (q >> 1)) * PLZ + (q & 1) * 8 + (r0 * PW + r) * 16;
-#pragma unroll
-    for (int cf = 0; cf < 2; ++cf) {
-      const bool xin = (unsigned)(t.x0 - 1 + cf * 16 + r) < (unsigned)p.Wd;
-#pragma unroll
-      for (int y = 0; y < NR; ++y) {
-        const bool inside = xin && (unsigned)(t.y0 - 1 + r0 + y) < (unsigned)p.H;
-        const f32x4 v = silu4(acc[y][cf] * sc + sh);
-        u32x2 o = {DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
-        if (!inside) o = u32x2{0u, 0u};
-        *reinterpret_cast<u32x2*>(zb + (y * PW + cf * 16) * 16) = o;
-      }
-    }
-  };
 
-  load_x(tile_of(0));
+  Unit un = unit_of(0);
+  int u = 0, k = un.kb - 1;
+  load_x(tile_of(un.sid, k));
   __syncthreads();                                   // BN tables
   if constexpr (DIAG) tprev = __builtin_amdgcn_s_memtime();
-  for (int it = 0; it < n_mine; ++it) {
-    const Tile t = tile_of(it);
+  int n_iter = 0;
+  for (;;) {
+    const Tile t = tile_of(un.sid, k);
+    const bool pseudo = k < un.kb;
+    Unit nun = un;
+    int nu = u, kn = k + 1;
+    if (kn == un.ke) {
+      ++nu;
+      if (nu < n_units) { nun = unit_of(nu); kn = nun.kb - 1; }
+    }
+    const bool last = nu >= n_units;
+    ++n_iter;
 
-    // ---- cv1 on the (TH+4) x PW patch: y1 (all pixels, zero outside the frame) and y0 (tile pixels only)
+    // ---- cv1 on the 8 new rows (image rows y0 + 2 .. y0 + 9): y1 (zero outside the frame) and y0 into their ring slots
     {
-      unsigned char* wb1 = Y1 + (q >> 1) * PL1 + (q & 1) * 8 + (wave * 16 + r) * 16;
-      unsigned char* wb0 = wb1 + 4 * PL1;
+      const int plane_off = (q >> 1) * PLR + (q & 1) * 8;
 #pragma unroll
       for (int i = 0; i < FPW1; ++i) {
-        if (wave + 8 * i >= NF1) continue;              // wave-uniform
-        const int p1 = (wave + 8 * i) * 16 + r;
-        const int row = p1 / PW, col = p1 - row * PW;
-        const bool inside = (unsigned)(t.y0 - 2 + row) < (unsigned)p.H && (unsigned)(t.x0 - 2 + col) < (unsigned)p.Wd;
-        const bool interior = (unsigned)(row - 2) < (unsigned)TH && col >= 2;
+        if (i == 2 && wave >= 4) continue;              // wave-uniform
+        const int pp = (i < 2 ? wave + 8 * i : 16) * 16 + r;
+        const int jj = pp / PW, col = pp - jj * PW;
+        const int arow = t.y0 + 2 + jj;
+        const bool inside = (unsigned)arow < (unsigned)p.H && (unsigned)(t.x0 - 2 + col) < (unsigned)p.Wd;
+        const bool interior = col >= 2 && (unsigned)arow < (unsigned)p.H;
+        unsigned char* w1p = Y1 + plane_off + (slot_of(arow) * PW + col) * 16;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
+          if (i == 2 && n != wave) continue;            // wave-uniform
           f32x4 acc = c2f_mfma<T>(f32x4{0.f, 0.f, 0.f, 0.f}, w1f[n][0], xr[i][0]);
           acc = c2f_mfma<T>(acc, w1f[n][1], xr[i][1]);
           const f32x4 sc = *reinterpret_cast<const f32x4*>(bn + n * 16 + q * 4), sh = *reinterpret_cast<const f32x4*>(bn + 64 + n * 16 + q * 4);
           const f32x4 v = silu4(acc * sc + sh);
           u32x2 o = {DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
           if (n < 2) {
-            if (interior) *reinterpret_cast<u32x2*>(wb0 + n * 2 * PL1 + i * 128 * 16) = o;
+            if (interior) *reinterpret_cast<u32x2*>(w1p + 4 * PLR + n * 2 * PLR) = o;
           } else {
             if (!inside) o = u32x2{0u, 0u};
-            if (p1 < NP1) *reinterpret_cast<u32x2*>(wb1 + (n - 2) * 2 * PL1 + i * 128 * 16) = o;
+            *reinterpret_cast<u32x2*>(w1p + (n - 2) * 2 * PLR) = o;
           }
         }
       }
     }
-    if (it + 1 < n_mine) load_x(tile_of(it + 1));     // in flight under the three phases below
+    if (!last) load_x(tile_of(nun.sid, kn));           // in flight under the phases below
     stamp(0);
-    __syncthreads();                                   // y0, y1 complete
+    __syncthreads();                                   // y0, y1 rows complete
     stamp(1);
 
-    // ---- m.cv1: z rows {0-2, 3-5, 6-7, 8-9} for row groups wm = 0..3
-    if (wm < 2) phase_z(std::integral_constant<int, 3>{}, t, 3 * wm);
-    else phase_z(std::integral_constant<int, 2>{}, t, 2 * wm + 2);
+    // ---- m.cv1: the 8 new z rows (image rows y0 + 1 .. y0 + 8; the first two of the tile's ten were made by the tile above)
+    {
+      f32x4 acc[2][2];
+      const int az = t.y0 + 1 + 2 * wm;              // first of this wave's two z rows; sources: y1 rows az - 1 .. az + 2
+      conv3(Y1, waf, az - 1, acc);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(bn + 128 + wn * 16 + q * 4), sh = *reinterpret_cast<const f32x4*>(bn + 160 + wn * 16 + q * 4);
+      const int zl = (wn * 2 + (q >> 1)) * PLR + (q & 1) * 8 + r * 16;
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        unsigned char* zb = Zs + (zl + slot_of(az + y) * ROWB);
+        const bool yin = (unsigned)(az + y) < (unsigned)p.H;
+#pragma unroll
+        for (int cf = 0; cf < 2; ++cf) {
+          const bool inside = yin && (unsigned)(t.x0 - 1 + cf * 16 + r) < (unsigned)p.Wd;
+          const f32x4 v = silu4(acc[y][cf] * sc + sh);
+          u32x2 o = {DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+          if (!inside) o = u32x2{0u, 0u};
+          *reinterpret_cast<u32x2*>(zb + cf * 256) = o;
+        }
+      }
+    }
     stamp(2);
     __syncthreads();                                   // z complete
     stamp(3);
 
-    // ---- m.cv2 + shortcut: y2 = y1 + SiLU(BN(.)), output rows 2 wm, 2 wm + 1
-    {
-      f32x4 acc[3][2];
-      conv3(std::integral_constant<int, 2>{}, Zs, PLZ, wbf, 2 * wm, acc);
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(bn + 192 + wn * 16 + q * 4), sh = *reinterpret_cast<const f32x4*>(bn + 224 + wn * 16 + q * 4);
-      const int cell = (wn * 2 + (q >> 1));
-      const unsigned char* rb = Y1 + cell * PL1 + (q & 1) * 8 + ((2 * wm + 2) * PW + r + 2) * 16;
-      unsigned char* ob = Y2 + cell * PL2 + (q & 1) * 8 + (2 * wm * PW + r) * 16;
-#pragma unroll
-      for (int cf = 0; cf < 2; ++cf)
+    if (!pseudo) {                                     // (the pseudo tile only feeds the rings)
+      // ---- m.cv2 + shortcut: y2 = y1 + SiLU(BN(.)), output rows 2 wm, 2 wm + 1 of the tile
+      {
+        f32x4 acc[2][2];
+        const int ao = t.y0 + 2 * wm;                // image row of the first output row; sources: z rows ao - 1 .. ao + 2
+        conv3(Zs, wbf, ao - 1, acc);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(bn + 192 + wn * 16 + q * 4), sh = *reinterpret_cast<const f32x4*>(bn + 224 + wn * 16 + q * 4);
+        const int cell = (wn * 2 + (q >> 1));
+        unsigned char* ob = Y2 + cell * PL2 + (q & 1) * 8 + (2 * wm * PW + r) * 16;
 #pragma unroll
         for (int y = 0; y < 2; ++y) {
-          f32x4 v = silu4(acc[y][cf] * sc + sh);
-          const u32x2 res = *reinterpret_cast<const u32x2*>(rb + (y * PW + cf * 16) * 16);
-          v += f32x4{DT<T>::lo(res.x), DT<T>::hi(res.x), DT<T>::lo(res.y), DT<T>::hi(res.y)};
-          *reinterpret_cast<u32x2*>(ob + (y * PW + cf * 16) * 16) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+          const unsigned char* rb = Y1 + cell * PLR + (q & 1) * 8 + (slot_of(ao + y) * PW + r + 2) * 16;
+#pragma unroll
+          for (int cf = 0; cf < 2; ++cf) {
+            f32x4 v = silu4(acc[y][cf] * sc + sh);
+            const u32x2 res = *reinterpret_cast<const u32x2*>(rb + cf * 256);
+            v += f32x4{DT<T>::lo(res.x), DT<T>::hi(res.x), DT<T>::lo(res.y), DT<T>::hi(res.y)};
+            *reinterpret_cast<u32x2*>(ob + (y * PW + cf * 16) * 16) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+          }
         }
-    }
-    stamp(4);
-    __syncthreads();                                   // y2 complete
-    stamp(5);
+      }
+      stamp(4);
+      __syncthreads();                                 // y2 complete
+      stamp(5);
 
-    // ---- cv2 over [y0 | y1 | y2] of the tile pixels: fragment (row i, column half gh); this wave: channel quarter nf
-    {
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(bn + 256 + nf * 16 + q * 4), sh = *reinterpret_cast<const f32x4*>(bn + 320 + nf * 16 + q * 4);
-      const unsigned char* b1 = Y1 + q * PL1 + (2 * PW + gh * 16 + r + 2) * 16;
-      const unsigned char* b0 = b1 + 4 * PL1;
-      const unsigned char* b2 = Y2 + q * PL2 + (gh * 16 + r) * 16;
-      const int pix0 = gh * 16 + r;
-      unsigned char* sb = Sg + pix0 * 128 + (((nf * 2 + (q >> 1)) ^ (pix0 & 7)) * 16) + (q & 1) * 8;
+      // ---- cv2 over [y0 | y1 | y2] of the tile pixels: fragment (row i, column half gh); this wave: channel quarter nf
+      {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(bn + 256 + nf * 16 + q * 4), sh = *reinterpret_cast<const f32x4*>(bn + 320 + nf * 16 + q * 4);
+        const int l1 = q * PLR + (gh * 16 + r + 2) * 16;
+        const unsigned char* b2 = Y2 + q * PL2 + (gh * 16 + r) * 16;
+        const int pix0 = gh * 16 + r;
+        unsigned char* sb = Sg + pix0 * 128 + (((nf * 2 + (q >> 1)) ^ (pix0 & 7)) * 16) + (q & 1) * 8;
 #pragma unroll
-      for (int i = 0; i < TH; ++i) {
-        const u32x4 a0 = *reinterpret_cast<const u32x4*>(b0 + i * PW * 16);
-        const u32x4 a1 = *reinterpret_cast<const u32x4*>(b1 + i * PW * 16);
-        const u32x4 a2 = *reinterpret_cast<const u32x4*>(b2 + i * PW * 16);
-        f32x4 acc = c2f_mfma<T>(f32x4{0.f, 0.f, 0.f, 0.f}, w2f[0], a0);
-        acc = c2f_mfma<T>(acc, w2f[1], a1);
-        acc = c2f_mfma<T>(acc, w2f[2], a2);
-        const f32x4 v = silu4(acc * sc + sh);
-        *reinterpret_cast<u32x2*>(sb + i * 32 * 128) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+        for (int i = 0; i < TH; ++i) {
+          const unsigned char* b1 = Y1 + (l1 + slot_of(t.y0 + i) * ROWB);
+          const u32x4 a0 = *reinterpret_cast<const u32x4*>(b1 + 4 * PLR);
+          const u32x4 a1 = *reinterpret_cast<const u32x4*>(b1);
+          const u32x4 a2 = *reinterpret_cast<const u32x4*>(b2 + i * ROWB);
+          f32x4 acc = c2f_mfma<T>(f32x4{0.f, 0.f, 0.f, 0.f}, w2f[0], a0);
+          acc = c2f_mfma<T>(acc, w2f[1], a1);
+          acc = c2f_mfma<T>(acc, w2f[2], a2);
+          const f32x4 v = silu4(acc * sc + sh);
+          *reinterpret_cast<u32x2*>(sb + i * 32 * 128) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+        }
       }
+      stamp(6);
+      __syncthreads();                                 // output tile complete
+      {
+        const auto rsO = __builtin_amdgcn_make_buffer_rsrc(Og + (int64_t)t.b * img_o, 0, (uint32_t)(img_o * 2), 0x00020000);
+        u32x4 vv[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int pix = kk * 64 + (tid >> 3), c = tid & 7;
+          vv[kk] = *reinterpret_cast<const u32x4*>(Sg + pix * 128 + ((c ^ (pix & 7)) * 16));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int pix = kk * 64 + (tid >> 3), c = tid & 7;
+          const int orow = pix >> 5, oc = pix & 31;
+          const bool ok = oc < p.TW && t.x0 + oc < p.Wd && t.y0 + orow < p.H;
+          const uint32_t off = (uint32_t)((((t.y0 + orow) * p.Wd + t.x0 + oc) * (int)p.ldo + c * 8) * 2);
+          __builtin_amdgcn_raw_buffer_store_b128(vv[kk], rsO, ok ? off : OOB, 0, 0);
+        }
+      }
+      stamp(7);
     }
-    stamp(6);
-    __syncthreads();                                   // output tile complete (and y0 / y1 / y2 free for the next tile's cv1)
-    {
-      const auto rsO = __builtin_amdgcn_make_buffer_rsrc(Og + (int64_t)t.b * img_o, 0, (uint32_t)(img_o * 2), 0x00020000);
-      u32x4 vv[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int pix = k * 64 + (tid >> 3), c = tid & 7;
-        vv[k] = *reinterpret_cast<const u32x4*>(Sg + pix * 128 + ((c ^ (pix & 7)) * 16));
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int pix = k * 64 + (tid >> 3), c = tid & 7;
-        const int orow = pix >> 5, oc = pix & 31;
-        const bool ok = oc < p.TW && t.x0 + oc < p.Wd && t.y0 + orow < p.H;
-        const uint32_t off = (uint32_t)((((t.y0 + orow) * p.Wd + t.x0 + oc) * (int)p.ldo + c * 8) * 2);
-        __builtin_amdgcn_raw_buffer_store_b128(vv[k], rsO, ok ? off : OOB, 0, 0);
-      }
-    }
-    stamp(7);
+    if (last) break;
+    un = nun; u = nu; k = kn;
   }
   if constexpr (DIAG) {
     if (blockIdx.x == 0 && tid == 0) {
       unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.Out);
       for (int i = 0; i < 8; ++i) dbg[i] = ph[i];
-      dbg[8] = (unsigned long long)n_mine;
+      dbg[8] = (unsigned long long)n_iter;
     }
   }
 }
@@ -347,14 +394,15 @@ static int launch_c2f(C2fParams& p, hipStream_t st) {
   const int nx = (p.Wd + C2F_TWMAX - 1) / C2F_TWMAX;
   p.TW = (p.Wd + nx - 1) / nx;                       // equal tile widths <= 30 (W = 272: 10 tiles of 28, not 9 of 30 + one of 2)
   p.tiles_x = (p.Wd + p.TW - 1) / p.TW;
-  p.tiles_img = p.tiles_x * ((p.H + C2F_TH - 1) / C2F_TH);
-  p.ntiles = p.B * p.tiles_img;
-  p.fd_timg = make_fastdiv((uint32_t)p.tiles_img);
+  p.nstrips = p.B * p.tiles_x;
   p.fd_tx = make_fastdiv((uint32_t)p.tiles_x);
-  p.per_xcd = (p.ntiles + 7) / 8;
   p.bpx = c2f_num_cus() / 8;
-  if (p.bpx > p.per_xcd) p.bpx = p.per_xcd;
   if (p.bpx < 1) p.bpx = 1;
+  const int nb = 8 * p.bpx, nty = (p.H + C2F_TH - 1) / C2F_TH;
+  p.nfull = p.nstrips / nb;
+  p.rem = p.nstrips - p.nfull * nb;
+  p.parts = p.rem ? nb / p.rem : 1;
+  if (p.parts > nty) p.parts = nty;                  // at least one tile per part
   hipLaunchKernelGGL(kern, dim3(8 * p.bpx), dim3(512), C2F_LDS, st, p);
   return launch_status();
 }
