@@ -152,7 +152,8 @@ int moy_stem_conv_mfma(const void* in_u8, int B, int H, int W, const void* wpad,
  * (3x3 s2, 32 -> 64), each Conv + BN + SiLU (predictor.py:117-134; yolo_track.yaml:17-18; conv.py:36-38).  The 32-channel
  * half-resolution tensor never reaches HBM (csrc/stem_l1.hip).
  *   in_u8 [B, H, W, 3] BGR (H, W multiples of 4, pointer 4-byte aligned)
- *   w0: T [32][32], stem weights in the kernel's k order: k = q*8 + e; q < 3: (ky = q, kx = e / 3, c_bgr = e % 3), e = 0..7;
+ *   w0: IEEE half [32][32] for BOTH types T (the frame bytes enter the matrix cores as the halfs 1024 + x, exact; the bias
+ *       1024 * sum_k w0[n][k] is removed inside), stem weights in the kernel's k order: k = q*8 + e; q < 3: (ky = q, kx = e / 3, c_bgr = e % 3), e = 0..7;
  *       q = 3: e = 0..2: (ky = e, kx = 2, c_bgr = 2), e >= 3: zero  (c_rgb = 2 - c_bgr; mo_yolo_amd.ops.stem_weights_fused)
  *   scale0 / shift0 fp32 [32] (BN folded; the preprocess' 1/255 is applied inside); w1: T [64][320], k = (ky*3+kx)*32 + c;
  *   scale1 / shift1 fp32 [64]; out: T [B, H/4, W/4, 64] with pixel stride ldc.   T = bf16 / fp16 (fp32: MOY_ENOSYS). */

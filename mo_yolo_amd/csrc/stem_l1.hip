@@ -8,9 +8,11 @@
 //     the frame: 7 KB of uint8, brought in by aligned dword loads one tile ahead (registers), borders by byte;
 //   * stem on the matrix cores: K = 27 padded to 32, with the k order chosen so that a lane's 8-element slice is 8 CONSECUTIVE
 //     BYTES of one window row (tap row ky = q, bytes (kx, c_bgr) 0..7; slice 3 = the ninth byte of the three rows):
-//     3 dword LDS reads + 2 v_alignbyte + 8 v_cvt_f32_ubyte per fragment instead of 8 byte gathers; uint8 is exact in
-//     bf16 / fp16, the 1/255 of the preprocess is folded into the fp32 BN scale (closer to the fp32 reference than
-//     bf16(u8/255));
+//     3 dword LDS reads + 2 v_alignbyte per fragment instead of 8 byte gathers.  The bytes enter the MFMA as the IEEE halfs
+//     1024 + x -- bit pattern 0x6400 | x, exact, made by ONE v_perm_b32 per pair of bytes (no integer -> float conversion at all);
+//     the stem's weights are halfs for both engine types and the constant 1024 * sum_k w[n][k] (summed once per block from the
+//     weight fragments) is taken out again in the fp32 BN shift; the 1/255 of the preprocess is folded into the fp32 BN scale
+//     (closer to the fp32 reference than bf16(u8/255));
 //   * BN + SiLU, zero outside the stem image (layer 1's padding), straight into layer 1's patch image: parity-de-interleaved
 //     rows, XOR-swizzled chunks, exactly the layout conv_s2_kernel DMA's from HBM;
 //   * layer 1 = conv_s2_kernel's core (weights in registers, row reuse), BN + SiLU, tile through LDS, whole-line stores.
@@ -24,7 +26,7 @@ namespace moy {
 struct StemL1Params {
   const uint8_t* in;           // [B, H, W, 3] BGR
   int B, H, W;                 // frame size; stem output Hs x Ws = H/2 x W/2, layer-1 output Ho x Wo = H/4 x W/4
-  const void* w0;              // T [32][32]: stem weights, k order of this kernel (host: ops.stem_weights_fused)
+  const void* w0;              // IEEE half [32][32] (both engine types): stem weights, k order of this kernel (host: ops.stem_weights_fused)
   const float* sc0; const float* sh0;
   const void* w1; int Kpad1;   // T [64][Kpad1], k = (ky*3+kx)*32 + c
   const float* sc1; const float* sh1;
@@ -32,17 +34,6 @@ struct StemL1Params {
   int tiles_x, tiles_img, ntiles, per_xcd, bpx;
   FastDiv fd_timg, fd_tx;
 };
-
-template <typename T>
-__device__ __forceinline__ uint32_t pack_u8pair(float lo, float hi);
-template <>
-__device__ __forceinline__ uint32_t pack_u8pair<bf16_t>(float lo, float hi) {   // exact: integers < 256 have <= 8 significant bits
-  return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x07060302u);
-}
-template <>
-__device__ __forceinline__ uint32_t pack_u8pair<f16_t>(float lo, float hi) {
-  return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lo, hi));   // exact: integers < 2048
-}
 
 template <typename T>
 __device__ __forceinline__ f32x4 sl1_mfma(f32x4 acc, u32x4 w, u32x4 a);
@@ -73,6 +64,7 @@ __global__ __launch_bounds__(512, 4) void stem_l1_kernel(const StemL1Params p) {
   unsigned char* win = smem;
   unsigned char* patch = smem + WIN_B;
   unsigned char* stg = patch + PATCH_B;
+  float* wsum = reinterpret_cast<float*>(stg + TH * 16 * N1 * 2);   // [32]: sum_k w0[n][k] (the bias the 1024 + x encoding adds per unit of weight)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
@@ -133,9 +125,18 @@ __global__ __launch_bounds__(512, 4) void stem_l1_kernel(const StemL1Params p) {
   // ---- weights -> registers
   u32x4 w0f[2];
   {
-    const T* W0 = static_cast<const T*>(p.w0);
+    const f16_t* W0 = static_cast<const f16_t*>(p.w0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) w0f[j] = *reinterpret_cast<const u32x4*>(W0 + (j * 16 + r) * 32 + q * 8);
+    for (int j = 0; j < 2; ++j) {
+      w0f[j] = *reinterpret_cast<const u32x4*>(W0 + (j * 16 + r) * 32 + q * 8);
+      float sm = 0.f;
+      const uint32_t ww[4] = {w0f[j].x, w0f[j].y, w0f[j].z, w0f[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sm += DT<f16_t>::lo(ww[e]) + DT<f16_t>::hi(ww[e]);
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      if (wave == 0 && q == 0) wsum[j * 16 + r] = sm;
+    }
   }
   u32x4 w1f[9];
   f32x4 sc1, sh1;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(512, 4) void stem_l1_kernel(const StemL1Params p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       sc0[j] = *reinterpret_cast<const f32x4*>(p.sc0 + j * 16 + q * 4) * (1.0f / 255.0f);     // the preprocess' /255 (predictor.py:133)
-      sh0[j] = *reinterpret_cast<const f32x4*>(p.sh0 + j * 16 + q * 4);
+      sh0[j] = *reinterpret_cast<const f32x4*>(p.sh0 + j * 16 + q * 4) - *reinterpret_cast<const f32x4*>(wsum + j * 16 + q * 4) * sc0[j] * 1024.0f;
     }
     int pix = wave * 16 + r, row = pix / PW, s33 = pix - row * PW;
 #pragma unroll 1
@@ -203,15 +204,14 @@ __global__ __launch_bounds__(512, 4) void stem_l1_kernel(const StemL1Params p) {
         lo = (uint32_t)win[pb] | ((uint32_t)win[pb + ROWB] << 8) | ((uint32_t)win[pb + 2 * ROWB] << 16);
         hi = 0;
       }
-      // (float)(byte k of a dword) is one v_cvt_f32_ubyteK
-      const float x0 = (float)(lo & 0xffu), x1 = (float)((lo >> 8) & 0xffu), x2 = (float)((lo >> 16) & 0xffu), x3 = (float)(lo >> 24);
-      const float x4 = (float)(hi & 0xffu), x5 = (float)((hi >> 8) & 0xffu), x6 = (float)((hi >> 16) & 0xffu), x7 = (float)(hi >> 24);
-      const u32x4 af = {pack_u8pair<T>(x0, x1), pack_u8pair<T>(x2, x3), pack_u8pair<T>(x4, x5), pack_u8pair<T>(x6, x7)};
+      // bytes -> the halfs 1024 + x: [b, 0x64] per 16-bit slot, one v_perm_b32 per pair (selector byte 4 = a byte of the constant)
+      const u32x4 af = {__builtin_amdgcn_perm(0x64646464u, lo, 0x04010400u), __builtin_amdgcn_perm(0x64646464u, lo, 0x04030402u),
+                        __builtin_amdgcn_perm(0x64646464u, hi, 0x04010400u), __builtin_amdgcn_perm(0x64646464u, hi, 0x04030402u)};
       const int sy = 2 * t.y0 - 1 + row, sx = 2 * t.x0 - 1 + col;
       const bool inside = pix < NPIX && (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws;   // outside: layer 1's zero padding
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        f32x4 v = sl1_mfma<T>(f32x4{0.f, 0.f, 0.f, 0.f}, w0f[j], af) * sc0[j] + sh0[j];
+        f32x4 v = sl1_mfma<f16_t>(f32x4{0.f, 0.f, 0.f, 0.f}, w0f[j], af) * sc0[j] + sh0[j];
         v.x = siluf_(v.x); v.y = siluf_(v.y); v.z = siluf_(v.z); v.w = siluf_(v.w);
         u32x2 o = {DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
         if (!inside) o = u32x2{0u, 0u};
@@ -300,7 +300,7 @@ template <typename T>
 static int launch_stem_l1(StemL1Params& p, hipStream_t st) {
   constexpr int TH = SL1_TH;
   constexpr int WIN_B = (((4 * TH + 3) * 52 * 4 + 15) / 16) * 16, PATCH_B = (((2 * TH + 1) * 33 * 64 + 1023) / 1024) * 1024, STG_B = TH * 16 * 128;
-  constexpr int LDS = WIN_B + PATCH_B + STG_B;
+  constexpr int LDS = WIN_B + PATCH_B + STG_B + 128;
   static int diag = -1;
   if (diag < 0) { const char* e = getenv("MOY_SL1_DIAG"); diag = e ? atoi(e) : 0; }
   auto kern = diag ? stem_l1_kernel<T, 1> : stem_l1_kernel<T, 0>;

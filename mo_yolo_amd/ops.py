@@ -126,9 +126,10 @@ def stem_weights_mfma(w):
     return out.to(torch.bfloat16).contiguous()
 
 
-def stem_weights_fused(w, dtype):
-    """[32, 3, 3, 3] fp32 stem weight (c_rgb) -> T [32, 32] in moy_stem_l1_fused's k order: slice q < 3 = tap row ky = q over the
-    8 bytes (kx, c_bgr) of a window row, slice 3 = the ninth byte (kx 2, c_bgr 2 = red) of the three rows."""
+def stem_weights_fused(w, dtype=None):
+    """[32, 3, 3, 3] fp32 stem weight (c_rgb) -> IEEE half [32, 32] in moy_stem_l1_fused's k order: slice q < 3 = tap row ky = q over
+    the 8 bytes (kx, c_bgr) of a window row, slice 3 = the ninth byte (kx 2, c_bgr 2 = red) of the three rows.  Halfs for BOTH engine
+    types: the kernel feeds the frame bytes to the matrix cores as the halfs 1024 + x (`dtype` is accepted for old call sites)."""
     assert tuple(w.shape) == (32, 3, 3, 3)
     out = torch.zeros(32, 32, device=w.device, dtype=torch.float32)
     for qq in range(3):
@@ -136,7 +137,7 @@ def stem_weights_fused(w, dtype):
             out[:, qq * 8 + e] = w[:, 2 - e % 3, qq, e // 3]
     for e in range(3):
         out[:, 24 + e] = w[:, 0, e, 2]
-    return out.to(dtype).contiguous()
+    return out.to(torch.float16).contiguous()
 
 
 def stem_l1_fused(x_u8, w0, scale0, shift0, w1pad, scale1, shift1, dtype, out=None):
