@@ -37,7 +37,7 @@ __device__ __forceinline__ float tail_inv_sigmoid(float x) {   // nn/modules/uti
 constexpr int TAIL_BM = 128, TAIL_NW = 8;
 constexpr int TAIL_LDS = 2 * TAIL_BM * 512 + TAIL_BM * TAIL_NW * 16;
 
-template <typename T>
+template <typename T, int ABL = 0>       // ABL 1: timing-only build that keeps the FIRST weight chunk for every product (MOY_TAIL_ABL=1; results garbage)
 __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_decoder_tail_args p) {
   constexpr int BM = TAIL_BM, NW = TAIL_NW, NTHR = 64 * NW, MT = BM / 16, NT = 2, WC = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -53,7 +53,9 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
   // this wave's 32 output rows of a [*, pitch] weight matrix, k columns koff .. koff+255.  (Requesting the next product's weights
   // half a product ahead -- panels 0-3 once consumed -- was tried: hipcc then keeps both generations of the registers apart and
   // spills 144 VGPRs; 132 us instead of 83.)
+  bool w_loaded = false;
   auto load_w = [&](const void* W, int row0, int pitch, int koff) {
+    if constexpr (ABL == 1) { if (w_loaded) return; w_loaded = true; }
     __builtin_amdgcn_sched_barrier(0);   // not above the MFMAs that still read the previous chunk (two chunks live = spills)
     const T* Wg = static_cast<const T*>(W) + (int64_t)(row0 + wave * WC) * pitch + koff;
 #pragma unroll
@@ -325,6 +327,14 @@ extern "C" int moy_decoder_tail(const moy_decoder_tail_args* a, void* stream) {
     attr_set = true;
   }
   const int blocks = (a->M + TAIL_BM - 1) / TAIL_BM;
+  static int abl = -1;
+  if (abl < 0) { const char* e = getenv("MOY_TAIL_ABL"); abl = e ? atoi(e) : 0; }
+  if (abl == 1 && a->dtype == MOY_BF16) {
+    auto k1 = decoder_tail_kernel<bf16_t, 1>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) != hipSuccess) return MOY_ELAUNCH;
+    hipLaunchKernelGGL(k1, dim3(blocks), dim3(64 * TAIL_NW), TAIL_LDS, st, *a);
+    return launch_status();
+  }
   if (a->dtype == MOY_BF16)
     hipLaunchKernelGGL((decoder_tail_kernel<bf16_t>), dim3(blocks), dim3(64 * TAIL_NW), TAIL_LDS, st, *a);
   else
