@@ -723,8 +723,8 @@ __global__ __launch_bounds__(256) void msda_planes_kernel(const T* __restrict__ 
   float den = 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i)
-    if (i < LP) { logit[i] = expf(logit[i] - mx); den += logit[i]; }
-  const float inv_den = 1.0f / den;
+    if (i < LP) { logit[i] = __builtin_amdgcn_exp2f((logit[i] - mx) * 1.4426950408889634f); den += logit[i]; }   // (v_exp_f32 / v_rcp_f32: an ulp
+  const float inv_den = __builtin_amdgcn_rcpf(den);                                                             // of fp32 on weights that multiply 16-bit values)
   const f32x4 rb = *reinterpret_cast<const f32x4*>(ref + (long)row * 4);
   const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(value + (int64_t)b * S * 32), 0, 0x80000000u, 0x00020000);
   const uint32_t lane_off = (uint32_t)((m * head_stride + oct * 8) * 2);
