@@ -328,7 +328,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restr
                                                             int32_t* __restrict__ idx_local, int32_t* __restrict__ idx_global,
                                                             int32_t* __restrict__ n_masked) {
   __shared__ uint32_t hist[256];
-  __shared__ uint32_t sh_prefix, sh_remaining, sh_cnt, sh_masked;
+  __shared__ uint32_t sh_prefix, sh_remaining, sh_cnt, sh_masked, wtot[4];
   __shared__ uint32_t scan[TOPK_THREADS];
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(dyn);   // [P2]
@@ -348,15 +348,28 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restr
       if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      uint32_t rem = sh_remaining, cum = 0;
-      int d = 255;
-      for (; d > 0; --d) {
-        if (cum + hist[d] >= rem) break;
-        cum += hist[d];
+    // bucket d = the highest one whose cumulative count (from bucket 255 down) reaches the number still needed: a 256-wide scan by
+    // four waves (one thread walking the buckets cost 256 dependent LDS reads per pass -- half of the kernel's time)
+    uint32_t cnt = 0, incl = 0;
+    const uint32_t rem = sh_remaining;
+    if (tid < 256) {
+      cnt = hist[255 - tid];                 // position tid <-> bucket 255 - tid
+      incl = cnt;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+        if ((tid & 63) >= off) incl += up;
       }
-      sh_remaining = rem - cum;         // still needed from bucket d
-      sh_prefix = prefix | ((uint32_t)d << shift);
+      if ((tid & 63) == 63) wtot[tid >> 6] = incl;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      for (int w = 0; w < (tid >> 6); ++w) incl += wtot[w];
+      const uint32_t excl = incl - cnt;
+      if (incl >= rem && excl < rem) {       // exactly one position: the counts of the matching elements sum to >= rem
+        sh_remaining = rem - excl;           // still needed from bucket d
+        sh_prefix = prefix | ((uint32_t)(255 - tid) << shift);
+      }
     }
     mask |= 255u << shift;
     __syncthreads();
