@@ -191,40 +191,62 @@ template <>
 __device__ __forceinline__ u32x4 max_chunk<float>(u32x4 a, u32x4 b) {
   return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(f32x4, a), __builtin_bit_cast(f32x4, b)));
 }
+// 16-bit planes are pooled as PACKED values, one VALU operation per pair: fp16 with v_pk_max_f16; bf16 (no packed bf16 maximum on
+// gfx950) as order-preserving int16 keys -- key = bits ^ 0x7fff for negative values (an involution) -- with v_pk_max_i16: encoded once
+// at the load, decoded once per store.  (Unpacking to fp32, fmaxf and repacking cost 28 operations per 16-byte chunk and tap: the
+// kernel was bound by them.)
+typedef short s16x2_ __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf16_key2(uint32_t w) { return w ^ (((w >> 15) & 0x00010001u) * 0x7fffu); }
 template <typename T>
-__device__ __forceinline__ u32x4 max_chunk16(u32x4 a, u32x4 b) {
-  using D = DT<T>;
-  u32x4 r;
-  r.x = D::pack2(fmaxf(D::lo(a.x), D::lo(b.x)), fmaxf(D::hi(a.x), D::hi(b.x)));
-  r.y = D::pack2(fmaxf(D::lo(a.y), D::lo(b.y)), fmaxf(D::hi(a.y), D::hi(b.y)));
-  r.z = D::pack2(fmaxf(D::lo(a.z), D::lo(b.z)), fmaxf(D::hi(a.z), D::hi(b.z)));
-  r.w = D::pack2(fmaxf(D::lo(a.w), D::lo(b.w)), fmaxf(D::hi(a.w), D::hi(b.w)));
-  return r;
+__device__ __forceinline__ u32x4 pool_encode(u32x4 v) { return v; }
+template <>
+__device__ __forceinline__ u32x4 pool_encode<bf16_t>(u32x4 v) { return u32x4{bf16_key2(v.x), bf16_key2(v.y), bf16_key2(v.z), bf16_key2(v.w)}; }
+template <typename T>
+__device__ __forceinline__ u32x4 pool_decode(u32x4 v) { return pool_encode<T>(v); }
+template <>
+__device__ __forceinline__ u32x4 max_chunk<bf16_t>(u32x4 a, u32x4 b) {     // on keys
+  auto mx = [](uint32_t x, uint32_t y) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_, x), __builtin_bit_cast(s16x2_, y)));
+  };
+  return u32x4{mx(a.x, b.x), mx(a.y, b.y), mx(a.z, b.z), mx(a.w, b.w)};
 }
 template <>
-__device__ __forceinline__ u32x4 max_chunk<bf16_t>(u32x4 a, u32x4 b) { return max_chunk16<bf16_t>(a, b); }
-template <>
-__device__ __forceinline__ u32x4 max_chunk<f16_t>(u32x4 a, u32x4 b) { return max_chunk16<f16_t>(a, b); }
+__device__ __forceinline__ u32x4 max_chunk<f16_t>(u32x4 a, u32x4 b) {
+  auto mx = [](uint32_t x, uint32_t y) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h16x2_, x), __builtin_bit_cast(h16x2_, y)));
+  };
+  return u32x4{mx(a.x, b.x), mx(a.y, b.y), mx(a.z, b.z), mx(a.w, b.w)};
+}
 
+// One block = one frame x G adjacent 16-byte channel chunks (G = 4 when the channel count allows): consecutive threads take the G
+// chunks of one pixel, so every global access of a wave is 16 runs of 64 contiguous bytes instead of 64 scattered 16-byte pieces --
+// with one chunk per block the kernel spent its time on 12 M separate 16-byte requests (the lesson of the deformable gather).
 template <typename T>
-__global__ __launch_bounds__(256) void sppf_pool_kernel(const T* __restrict__ x, int64_t ldx, int H, int W, int C,
+__global__ __launch_bounds__(512) void sppf_pool_kernel(const T* __restrict__ x, int64_t ldx, int H, int W, int C, int G,
                                                         T* __restrict__ y1, T* __restrict__ y2, T* __restrict__ y3,
                                                         int64_t ldy) {
   constexpr int KPB = DT<T>::KPB;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-  u32x4* P = reinterpret_cast<u32x4*>(dyn);            // [H*W] current plane
-  u32x4* Q = P + H * W;                                // [H*W] row-pass result
-  const int cpr = C / KPB;
-  const int b = blockIdx.x / cpr, cc = blockIdx.x % cpr;
-  const int npx = H * W, tid = threadIdx.x;
+  const int npx = H * W, nit = npx * G, tid = threadIdx.x;
+  u32x4* P = reinterpret_cast<u32x4*>(dyn);            // [G][H*W] current planes
+  u32x4* Q = P + nit;                                  // [G][H*W] row-pass result
+  const int gpr = C / (KPB * G);                       // chunk groups per pixel
+  const int b = blockIdx.x / gpr, cg = blockIdx.x % gpr;
+  const int gsh = G == 4 ? 2 : (G == 2 ? 1 : 0);
   const long pix0 = (long)b * npx;
-  for (int i = tid; i < npx; i += 256) P[i] = *reinterpret_cast<const u32x4*>(x + (pix0 + i) * ldx + cc * KPB);
+  const int c0 = cg * G * KPB;
+  for (int it = tid; it < nit; it += 512) {
+    const int px = it >> gsh, g = it & (G - 1);
+    P[g * npx + px] = pool_encode<T>(*reinterpret_cast<const u32x4*>(x + (pix0 + px) * ldx + c0 + g * KPB));
+  }
   __syncthreads();
   T* outs[3] = {y1, y2, y3};
 #pragma unroll 1
   for (int s = 0; s < 3; ++s) {
-    for (int i = tid; i < npx; i += 256) {             // row pass
-      const int yy = i / W, xx = i - yy * W;
+    for (int it = tid; it < nit; it += 512) {          // row pass
+      const int px = it >> gsh, i = (it & (G - 1)) * npx + px;
+      const int yy = px / W, xx = px - yy * W;
       u32x4 m = P[i];
 #pragma unroll
       for (int d = -2; d <= 2; ++d)
@@ -232,14 +254,15 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const T* __restrict__ x,
       Q[i] = m;
     }
     __syncthreads();
-    for (int i = tid; i < npx; i += 256) {             // column pass + store
-      const int yy = i / W;
+    for (int it = tid; it < nit; it += 512) {          // column pass + store
+      const int px = it >> gsh, g = it & (G - 1), i = g * npx + px;
+      const int yy = px / W;
       u32x4 m = Q[i];
 #pragma unroll
       for (int d = -2; d <= 2; ++d)
         if (d != 0 && (unsigned)(yy + d) < (unsigned)H) m = max_chunk<T>(m, Q[i + d * W]);
       P[i] = m;
-      *reinterpret_cast<u32x4*>(outs[s] + (pix0 + i) * ldy + cc * KPB) = m;
+      *reinterpret_cast<u32x4*>(outs[s] + (pix0 + px) * ldy + c0 + g * KPB) = pool_decode<T>(m);
     }
     __syncthreads();
   }
@@ -1650,10 +1673,15 @@ extern "C" int moy_sppf_pool(const void* x, int64_t ldx, int B, int H, int W, in
                              int64_t ldy, int dtype, void* stream) {
   if (!x || !y1 || !y2 || !y3 || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (ldy % 8)) return MOY_EINVAL;
   if (!aligned16(x) || !aligned16(y1) || !aligned16(y2) || !aligned16(y3)) return MOY_EINVAL;
-  const size_t lds = (size_t)H * W * 32;
-  if (lds > 160 * 1024) return MOY_ENOSYS;     // the plane of one channel chunk must fit in LDS (P5 level: 19x34 .. 34x60)
   hipStream_t st = static_cast<hipStream_t>(stream);
   MOY_DISPATCH_T(dtype, {
+    const int cpr = C / DT<T>::KPB;                      // 16-byte chunks per pixel
+    int G = (cpr % 4 == 0) ? 4 : ((cpr % 2 == 0) ? 2 : 1);
+    static int gmax = -1;                                // MOY_SPPF_G: cap of the group size (A/B runs)
+    if (gmax < 0) { const char* e = getenv("MOY_SPPF_G"); gmax = e ? atoi(e) : 4; }
+    while (G > 1 && (G > gmax || (size_t)H * W * 32 * G > 160 * 1024)) G >>= 1;
+    const size_t lds = (size_t)H * W * 32 * G;
+    if (lds > 160 * 1024) return MOY_ENOSYS;   // the planes of one chunk must fit in LDS (P5 level: 19x34 .. 34x60)
     auto kern = sppf_pool_kernel<T>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1661,7 +1689,7 @@ extern "C" int moy_sppf_pool(const void* x, int64_t ldx, int B, int H, int W, in
         return MOY_ELAUNCH;
       attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(B * (C / DT<T>::KPB)), dim3(256), lds, st, static_cast<const T*>(x), ldx, H, W, C,
+    hipLaunchKernelGGL(kern, dim3(B * (cpr / G)), dim3(512), lds, st, static_cast<const T*>(x), ldx, H, W, C, G,
                        static_cast<T*>(y1), static_cast<T*>(y2), static_cast<T*>(y3), ldy);
     return launch_status();
   })
