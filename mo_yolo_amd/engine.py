@@ -558,6 +558,7 @@ class TrackEngine:
         offaw = self._buf(M, 8 * nl * 4 * 3, torch.float32)
         samp = View(self._buf(M, hd))
         ffn = View(self._buf(M, arch.d_ffn))
+        self.debug_views = dict(qkv=qkv.tensor(), attn=attn.tensor(), e1=e1.tensor(), offaw=offaw, samp=samp.tensor())   # tools/probes
         shapes_c = (C.c_int32 * (2 * nl))(*[v for hw_ in self.shapes for v in hw_])
         self._keep.append(shapes_c)
         self.layer_out = []

@@ -54,3 +54,98 @@ def engine_pair_stats(got, want, nq: int):
         "birth_flip_frac_of_active": round(flips / max(1, active_w), 5),
         "ids_equal": bool(torch.equal(ig, iw)),
     }
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Agreement scores that can fail (round 3): the build's tracks scored AGAINST THE REFERENCE RUN'S TRACKS as ground truth.
+# HOTA against the synthetic scene is ~0 for every engine (a random-init decoder does not localise), so "HOTA within 0.1 of
+# the reference" was satisfied by construction; here 100 means identical tracks and every flipped birth, permuted id or moved
+# box costs points.  The evaluator is the path's own (mo_yolo_amd/evaluate.py = ultralytics/utils/hota.py:24-164).
+def _xyxy(boxes, W, H):
+    b = boxes.float()
+    return torch.stack([(b[:, 0] - b[:, 2] / 2) * W, (b[:, 1] - b[:, 3] / 2) * H, (b[:, 0] + b[:, 2] / 2) * W,
+                        (b[:, 1] + b[:, 3] / 2) * H], -1)
+
+
+def tracks_of(out, b, W, H):
+    """(pixel xyxy boxes [K, 4], ids [K]) of the rows of frame b that carry a track id (val.py:383-386)."""
+    act = out["obj_idxes"][b].cpu() >= 0
+    return (_xyxy(out["boxes"][b].cpu()[act], W, H).numpy().astype("float32"),
+            out["obj_idxes"][b].cpu()[act].numpy().astype("int64"))
+
+
+def agreement_hota(got_tracks, ref_tracks, device="cuda"):
+    """got_tracks / ref_tracks: per frame (boxes xyxy [K, 4], ids [K]).  HOTA / DetA / AssA (mean over the alpha grid, in
+    points of 100) of `got` scored against `ref` as ground truth, by the reference evaluator's algorithm (`compat`) and by the
+    published definition.  Identical inputs give 100 / 100 / 100."""
+    import numpy as np
+    from . import evaluate as E
+    gb, gi = [t[0] for t in ref_tracks], [t[1] for t in ref_tracks]
+    tb, ti = [t[0] for t in got_tracks], [t[1] for t in got_tracks]
+    sims = E.similarity_scores(gb, tb, device=device)
+    data = E.build_hota_data(gi, ti, sims)
+    out = {}
+    for name, metric in (("compat", E.HOTA(compat=True)), ("published", E.HOTA(compat=False))):
+        res = metric.eval_sequence({k: (list(v) if isinstance(v, list) else v) for k, v in data.items()})
+        out[name] = {m: round(100.0 * float(np.mean(res[m])), 3) for m in ("HOTA", "DetA", "AssA")}
+    out["frames"] = len(ref_tracks)
+    out["ref_tracks_per_frame"] = round(float(np.mean([len(i) for i in gi])), 2)
+    return out
+
+
+def _iou_matrix(a, b):
+    """IoU of cxcywh boxes a [n, 4] vs b [m, 4] (host, small)."""
+    ax = _xyxy(a, 1.0, 1.0)
+    bx = _xyxy(b, 1.0, 1.0)
+    lt = torch.maximum(ax[:, None, :2], bx[None, :, :2])
+    rb = torch.minimum(ax[:, None, 2:], bx[None, :, 2:])
+    inter = (rb - lt).clamp(min=0).prod(-1)
+    ua = (ax[:, 2] - ax[:, 0]) * (ax[:, 3] - ax[:, 1])
+    ub = (bx[:, 2] - bx[:, 0]) * (bx[:, 3] - bx[:, 1])
+    return inter / (ua[:, None] + ub[None, :] - inter).clamp(min=1e-12)
+
+
+def token_id_agreement(got, want, nq: int):
+    """Per-frame token -> id agreement of two runs on the same frames.
+
+    A query row is identified by the encoder token it was selected from.  Reported:
+      frames_ids_equal_by_token   frames in which EVERY token that carries an id in either run carries the SAME id in both
+                                  (the statement `north_star` asks for: same boxes get the same track ids)
+      frames_active_set_equal     frames in which the same tokens are active (ids may be permuted)
+      tokens_id_equal_frac        over tokens selected by both runs: share whose obj_idx is identical (incl. -1 == -1)
+      unmatched_frac              tokens of `got` that `want` did not select / all selected tokens
+      unmatched_active            ... of which carry an id in `got` (these rows exist in one run only)
+      unmatched_nearest_iou_mean / _min   for the unmatched rows: IoU of their box with the nearest row of `want`
+                                  (a near-duplicate neighbour token => close to 1; something else was detected => small)
+      active_missing              tokens active in `want` that are not active in `got` (not selected, or below the birth threshold)
+    """
+    tg, tw = got["topk_ind"].long().cpu(), want["topk_ind"].long().cpu()
+    ig, iw = got["obj_idxes"].cpu(), want["obj_idxes"].cpu()
+    bg, bw = got["boxes"].float().cpu(), want["boxes"].float().cpu()
+    B = tg.shape[0]
+    frames_ids, frames_set, common, id_eq, unmatched, unmatched_act, missing = 0, 0, 0, 0, 0, 0, 0
+    ious = []
+    for b in range(B):
+        mg = {int(t): int(i) for t, i in zip(tg[b].tolist(), ig[b].tolist())}
+        mw = {int(t): int(i) for t, i in zip(tw[b].tolist(), iw[b].tolist())}
+        act_g = {t: i for t, i in mg.items() if i >= 0}
+        act_w = {t: i for t, i in mw.items() if i >= 0}
+        frames_ids += int(act_g == act_w)
+        frames_set += int(set(act_g) == set(act_w))
+        missing += len(set(act_w) - set(act_g))
+        both = set(mg) & set(mw)
+        common += len(both)
+        id_eq += sum(1 for t in both if mg[t] == mw[t])
+        rows_un = [i for i, t in enumerate(tg[b].tolist()) if int(t) not in mw]
+        unmatched += len(rows_un)
+        unmatched_act += sum(1 for i in rows_un if int(ig[b, i]) >= 0)
+        if rows_un:
+            ious.append(_iou_matrix(bg[b, rows_un], bw[b]).max(1).values)
+    iou = torch.cat(ious) if ious else torch.ones(0)
+    return {
+        "frames": B, "frames_ids_equal_by_token": frames_ids, "frames_active_set_equal": frames_set,
+        "tokens_id_equal_frac": round(id_eq / max(1, common), 5), "unmatched_frac": round(unmatched / (B * nq), 5),
+        "unmatched_active": unmatched_act, "active_missing": missing,
+        "unmatched_nearest_iou_mean": round(float(iou.mean()), 4) if len(iou) else None,
+        "unmatched_nearest_iou_min": round(float(iou.min()), 4) if len(iou) else None,
+    }

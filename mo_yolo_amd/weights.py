@@ -69,6 +69,15 @@ def make_fixture_state_dict(arch: TrackArch, seed: int = 0) -> "OrderedDict[str,
             v = _u(rng, shp, math.sqrt(6.0 / fan_in))
             if (".cv2." in k or ".cv3." in k) and k.endswith(".2.weight"):
                 v = v * np.float32(20.0)                      # Detect output convs: spread the DFL / class logits
+        elif ".bn." in k and arch.head_kind == "track":
+            # Conv blocks of the tracking fixtures (round 3): gamma in [0.4, 0.6], beta in [0.3, 0.7].  With the BatchNorm
+            # statistics calibrated (tests/golden/make_golden.py:calibrate_bn) the pre-activation is z ~ N(beta, gamma^2); a
+            # RANDOM network then amplifies any relative perturbation by sqrt(E[silu'(z)^2] gamma^2 / Var silu(z)) per layer
+            # (Gaussian Poincare inequality: >= 1, equality only for a linear activation): 1.10 for gamma 1 / beta 0, i.e. the
+            # 0.3 % of one bf16 rounding grows to 8 % over the 46 convolutions of the longest path (measured:
+            # profiles/r03_seam_bias_c2_bf16_bn_gamma1.json) -- a property of random weights, not of 16-bit kernels and not of
+            # trained networks.  This range gives 1.02 per layer.  Same number of draws as before: every other weight is unchanged.
+            v = _ur(rng, shp, 0.4, 0.6) if leaf == "weight" else _ur(rng, shp, 0.3, 0.7)
         elif ".bn." in k or ".input_proj." in k or "norm" in k or k.endswith("enc_output.1.weight") \
                 or k.endswith("enc_output.1.bias"):
             v = _ur(rng, shp, 0.8, 1.2) if leaf == "weight" else _u(rng, shp, 0.17)

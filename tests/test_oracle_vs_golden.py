@@ -9,6 +9,7 @@ from oracle import track_oracle as O
 from tests._util import check_close, fixture, golden, net_input, frames_u8
 
 TOL = 2e-5   # fp32 CPU vs fp32 CPU, different op decomposition only
+RTOL = 2e-5  # ... relative part: with calibrated BatchNorm statistics (round 3) the activations are O(1-10), not O(0.1)
 
 
 @pytest.mark.parametrize("name", ["tiny", "tiny3", "c2"])
@@ -25,28 +26,28 @@ def test_seams_frame0(name):
     d = f"model.{len(arch.layers)}.decoder"
     assert [tuple(s) for s in g["shapes"]] == [tuple(s) for s in r["shapes"]]
     assert np.array_equal(g["valid_mask"], r["valid"][0, :, 0].numpy())
-    check_close(r["features"], g, "t0.enc_features", atol=TOL)
-    check_close(r["enc_scores_all"], g, "t0.enc_scores_all", atol=TOL)
+    check_close(r["features"], g, "t0.enc_features", atol=TOL, rtol=RTOL)
+    check_close(r["enc_scores_all"], g, "t0.enc_scores_all", atol=TOL, rtol=RTOL)
     fin = torch.isfinite(r["anchors"])
     assert torch.equal(r["anchors"][fin], torch.from_numpy(g["t0.anchors"])[fin]) if "t0.anchors" in g else True
     assert np.array_equal(r["topk_ind"].numpy().reshape(-1), g["t0.topk_ind"].reshape(-1)), "top-k order"
-    check_close(r["embed"], g, "t0.embed0", atol=TOL)
-    check_close(r["refer_bbox_logit"], g, "t0.refer_bbox_logit", atol=TOL)
+    check_close(r["embed"], g, "t0.embed0", atol=TOL, rtol=RTOL)
+    check_close(r["refer_bbox_logit"], g, "t0.refer_bbox_logit", atol=TOL, rtol=RTOL)
     check_close(r["query_pos"], g, "t0.query_pos", atol=5e-5)
-    check_close(r["enc_bboxes"], g, "t0.enc_bboxes", atol=TOL)
-    check_close(r["enc_scores"], g, "t0.enc_scores", atol=TOL)
+    check_close(r["enc_bboxes"], g, "t0.enc_bboxes", atol=TOL, rtol=RTOL)
+    check_close(r["enc_scores"], g, "t0.enc_scores", atol=TOL, rtol=RTOL)
     for li in range(arch.ndl):
         t = trace[li]
-        check_close(t["sa"].transpose(0, 1), g, f"t0.dec{li}.sa", atol=TOL)   # reference MHA is [L, B, E]
-        check_close(t["n1"], g, f"t0.dec{li}.n1", atol=TOL)
-        check_close(t["msda_loc"], g, f"t0.dec{li}.msda_loc", atol=TOL)
-        check_close(t["msda_aw"], g, f"t0.dec{li}.msda_aw", atol=TOL)
-        check_close(t["msda_core"], g, f"t0.dec{li}.msda_out", atol=TOL)
-        check_close(t["ca"], g, f"t0.dec{li}.ca", atol=TOL)
-        check_close(t["n2"], g, f"t0.dec{li}.n2", atol=TOL)
-        check_close(t["out"], g, f"t0.dec{li}.out", atol=TOL)
-        check_close(t["bbox_delta"], g, f"t0.dec{li}.bbox_delta", atol=TOL)
-    assert torch.allclose(r["y"][0], torch.from_numpy(g["y"][0]), atol=TOL)
+        check_close(t["sa"].transpose(0, 1), g, f"t0.dec{li}.sa", atol=TOL, rtol=RTOL)   # reference MHA is [L, B, E]
+        check_close(t["n1"], g, f"t0.dec{li}.n1", atol=TOL, rtol=RTOL)
+        check_close(t["msda_loc"], g, f"t0.dec{li}.msda_loc", atol=TOL, rtol=RTOL)
+        check_close(t["msda_aw"], g, f"t0.dec{li}.msda_aw", atol=TOL, rtol=RTOL)
+        check_close(t["msda_core"], g, f"t0.dec{li}.msda_out", atol=TOL, rtol=RTOL)
+        check_close(t["ca"], g, f"t0.dec{li}.ca", atol=TOL, rtol=RTOL)
+        check_close(t["n2"], g, f"t0.dec{li}.n2", atol=TOL, rtol=RTOL)
+        check_close(t["out"], g, f"t0.dec{li}.out", atol=TOL, rtol=RTOL)
+        check_close(t["bbox_delta"], g, f"t0.dec{li}.bbox_delta", atol=TOL, rtol=RTOL)
+    assert torch.allclose(r["y"][0], torch.from_numpy(g["y"][0]), atol=TOL, rtol=RTOL)
 
 
 @pytest.mark.parametrize("name", ["tiny", "tiny3", "c2"])
