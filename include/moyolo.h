@@ -311,13 +311,17 @@ int moy_temporal_commit(const int32_t* sel_rows, const int32_t* n_new, const int
  * src/cuda/ms_deform_im2col_cuda.cuh:237-299), same argument meaning:
  *   value [N, S, M, D], spatial_shapes int64 [L, 2] (H, W) and level_start_index int64 [L] in
  *   DEVICE memory, sampling_loc [N, Lq, M, L, P, 2], attn_weight [N, Lq, M, L, P] -> out [N, Lq, M*D].
- * The reference dispatches fp32/fp64 (ms_deform_attn_cuda.cu:64); bf16 is added here. */
+ * The reference dispatches fp32/fp64 (ms_deform_attn_cuda.cu:64); bf16 and fp16 (config C5, the reference's own `half`
+ * switch, engine/predictor.py:131) are added here: 16-bit operands, fp32 accumulation, one rounding of the result. */
 int moy_msda_fwd_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                      const float* sampling_loc, const float* attn_weight, int N, int S, int M, int D, int L, int Lq,
                      int P, float* out, void* stream);
 int moy_msda_fwd_bf16(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                       const void* sampling_loc, const void* attn_weight, int N, int S, int M, int D, int L, int Lq,
                       int P, void* out, void* stream);
+int moy_msda_fwd_f16(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                     const void* sampling_loc, const void* attn_weight, int N, int S, int M, int D, int L, int Lq,
+                     int P, void* out, void* stream);
 int moy_msda_fwd_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                      const double* sampling_loc, const double* attn_weight, int N, int S, int M, int D, int L, int Lq,
                      int P, double* out, void* stream);

@@ -82,6 +82,7 @@ SIGNATURES = {
     "moy_msda_fused": (C.c_int, [vp, i64, i64, C.c_int, C.c_int, vp, C.c_int, vp, i64, vp, C.c_int, vp, i64, C.c_int, vp]),
     "moy_msda_fwd_f32": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp, vp]),
     "moy_msda_fwd_bf16": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp, vp]),
+    "moy_msda_fwd_f16": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp, vp]),
     "moy_msda_fwd_f64": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp, vp]),
     "moy_msda_bwd_f32": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp, vp, vp, vp]),
     "moy_msda_bwd_f64": (C.c_int, [vp, vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp, vp, vp, vp]),

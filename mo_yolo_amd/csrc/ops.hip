@@ -1872,6 +1872,12 @@ extern "C" int moy_msda_fwd_bf16(const void* value, const int64_t* spatial_shape
   return msda_generic<bf16_t>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, stream);
 }
 
+extern "C" int moy_msda_fwd_f16(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                const void* sampling_loc, const void* attn_weight, int N, int S, int M, int D, int L, int Lq,
+                                int P, void* out, void* stream) {
+  return msda_generic<f16_t>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, stream);
+}
+
 extern "C" int moy_msda_fwd_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                                 const double* sampling_loc, const double* attn_weight, int N, int S, int M, int D, int L, int Lq,
                                 int P, double* out, void* stream) {

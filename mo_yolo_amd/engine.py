@@ -583,11 +583,17 @@ class TrackEngine:
             Woa_d, boa_d = self._linear_w_raw(Woa, boa)
             self._gemm(e1, Woa_d, Woa.shape[0], hd, View(offaw), M, shift=boa_d, A2=qpos, out_f32=True)
             vslice, vhs = value[i]
-            # gather: min(value slice of the layer, touched set = rows x heads x 12 samples x 4 taps x 32 channels) -- SURVEY §8(d)
-            taps = M * arch.nh * nl * arch.ndp * 4 * (hd // arch.nh) * self._esz
+            # gather: SURVEY §8(d) charges min(value slice of the layer, taps x 64 B); the taps of a launch fall on the same cells
+            # (one cell = one token of one head = 32 channels) again and again, so what has to MOVE is the expected number of
+            # DISTINCT cells under uniform sampling, cells x (1 - exp(-taps / cells)) -- 1.31 GB per launch at 288 frames against
+            # 1.20 GB measured by PMC (round 2 charged 2.15 GB and the launch table showed a fraction > 1)
+            import math
+            cells = B * S * arch.nh
+            ntaps = M * arch.nh * nl * arch.ndp * 4
+            touched = int(cells * (1.0 - math.exp(-ntaps / cells))) * (hd // arch.nh) * self._esz
             self._add(lib.moy_msda_fused, vslice.ptr, vslice.ld, vhs, B, S, shapes_c, nl, offaw.data_ptr(), offaw.shape[1],
                       refs[cur].data_ptr(), Lq, samp.ptr, samp.ld, code,
-                      meta=dict(name=f"msda_fused M{M}", bytes=min(B * S * hd * self._esz, taps) + M * (offaw.shape[1] * 4 + 16 + hd * self._esz),
+                      meta=dict(name=f"msda_fused M{M}", bytes=touched + M * (offaw.shape[1] * 4 + 16 + hd * self._esz),
                                 flops=2 * M * arch.nh * nl * arch.ndp * 4 * (hd // arch.nh)))
             Wp, bp = self._linear_w(q + ".cross_attn.output_proj")
             W1, b1 = self._linear_w(q + ".linear1")

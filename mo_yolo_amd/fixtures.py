@@ -15,6 +15,9 @@ CONFIGS = {
     "tiny3": dict(depth=0.33, width=0.25, nc=3, H=64, W=96, nq=20, seed=3, style="mot17", frames=4),
     "c2": dict(depth=0.33, width=0.50, nc=1, H=608, W=1088, nq=300, seed=0, style="mot17", frames=8),
     "c4": dict(depth=0.33, width=0.50, nc=1, H=1088, W=1920, nq=500, seed=0, style="dance", frames=2),
+    # yolo_track.yaml AS SHIPPED (depth 1.0 / width 1.0, the scale the reference's own entry script uses: start_train.py:11,
+    # cfg/models/v8/yolo_track.yaml:11-12; 46 M parameters) at a small resolution: the widths no specialised kernel covers
+    "full": dict(depth=1.0, width=1.0, nc=1, H=128, W=192, nq=60, seed=0, style="mot17", frames=2),
 }
 
 

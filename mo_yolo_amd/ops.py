@@ -302,9 +302,10 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     N, S, M, D = value.shape
     _, Lq, _, Lv, P, _ = sampling_loc.shape
     assert spatial_shapes.dtype == torch.int64 and level_start_index.dtype == torch.int64
-    fn = {torch.float32: "moy_msda_fwd_f32", torch.bfloat16: "moy_msda_fwd_bf16", torch.float64: "moy_msda_fwd_f64"}.get(value.dtype)
+    fn = {torch.float32: "moy_msda_fwd_f32", torch.bfloat16: "moy_msda_fwd_bf16", torch.float16: "moy_msda_fwd_f16",
+          torch.float64: "moy_msda_fwd_f64"}.get(value.dtype)
     if fn is None or sampling_loc.dtype != value.dtype or attn_weight.dtype != value.dtype:
-        raise TypeError("ms_deform_attn_forward: float32 / float64 / bfloat16, one dtype for value, locations and weights")
+        raise TypeError("ms_deform_attn_forward: float32 / float64 / bfloat16 / float16, one dtype for value, locations and weights")
     out = torch.empty(N, Lq, M * D, device=value.device, dtype=value.dtype)
     L.check(getattr(L.lib(), fn)(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
                                  attn_weight.data_ptr(), N, S, M, D, Lv, Lq, P, out.data_ptr(), _st()), fn)

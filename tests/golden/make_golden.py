@@ -38,6 +38,9 @@ CONFIGS = {
     "tiny3": dict(depth=0.33, width=0.25, nc=3, H=64, W=96, nq=20, seed=3, style="mot17", frames=4),
     "c2": dict(depth=0.33, width=0.50, nc=1, H=608, W=1088, nq=300, seed=0, style="mot17", frames=8),
     "c4": dict(depth=0.33, width=0.50, nc=1, H=1088, W=1920, nq=500, seed=0, style="dance", frames=2),
+    # yolo_track.yaml AS SHIPPED (depth 1.0 / width 1.0, the scale the reference's own entry script uses: start_train.py:11,
+    # cfg/models/v8/yolo_track.yaml:11-12; 46 M parameters) at a small resolution: the widths no specialised kernel covers
+    "full": dict(depth=1.0, width=1.0, nc=1, H=128, W=192, nq=60, seed=0, style="mot17", frames=2),
 }
 N_SAMPLE = 1024
 # calibrate_v2 parameters per config (round 3: with BatchNorm statistics calibrated the decoder outputs separate the queries,
@@ -46,6 +49,7 @@ V2_PARAMS = {
     "c2": dict(logit_std=3.0, margin=0.03),
     "c4": dict(logit_std=3.0, margin=0.03),
     "tiny": dict(logit_std=3.0, margin=0.03),
+    "full": dict(logit_std=3.0, margin=0.03),
 }
 
 
@@ -778,6 +782,7 @@ def dump_encoder():
             "enc3": (3, 8, 4, 2, False, False, 2, [(12, 20), (6, 10), (3, 5)]),
             "enc4_mask_sigmoid": (4, 8, 4, 1, True, True, 1, [(9, 7), (5, 4), (3, 2), (2, 1)])}.items():
         g = torch.Generator().manual_seed(40 + nl)
+        torch.manual_seed(400 + nl)              # the layer's own nn.Linear / xavier initialisers draw from the GLOBAL generator
         layer = dtp.MOTRDeformableTransformerEncoderLayer(256, D_FFN, 0.1, "relu", nl, nh, npnt, sigmoid_attn=sig)
         enc = dtp.DeformableTransformerEncoder(layer, nlayers).eval()
         with torch.no_grad():                    # de-degenerate the zero-initialised offset / attention weights
@@ -855,7 +860,7 @@ def dump_hota():
 
 
 def main():
-    which = sys.argv[1:] or ["tiny", "tiny3", "c2", "c4", "c1", "msda", "qim", "hota", "state", "encoder"]
+    which = sys.argv[1:] or ["tiny", "tiny3", "c2", "c4", "full", "c1", "msda", "qim", "hota", "state", "encoder"]
     cal = {}
     for name in which:
         if name in CONFIGS:

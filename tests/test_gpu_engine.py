@@ -138,6 +138,18 @@ def _direct_vs_golden(name, B):
     print(f"[{name}] {T} frames direct vs reference: max |y diff| {worst:.2e}")
 
 
+def test_engine_fp32_full_scale_yaml_vs_reference_golden():
+    """`yolo_track.yaml` at its OWN scale (depth 1.0 / width 1.0: 46 M parameters, 3 / 6 / 6 / 3 bottlenecks, 256- and 512-channel
+    3x3 convolutions, head inputs 256 / 512 / 512 -- the model the reference's entry script builds, start_train.py:11) at a small
+    resolution, free running, directly against the reference's outputs: none of the shape-specialised kernels (conv_ws, c2f_fused,
+    the N = 256 weight-stationary forms) applies at these widths, so this pins the general paths."""
+    _direct_vs_golden("full", 2)
+    cfg, arch, sd = fixture("full")
+    eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=2, dtype=torch.bfloat16)
+    names = [m["name"] for m in eng.meta]
+    assert not any(n.startswith(("c2f fused", "stem+conv1")) for n in names), names      # (those forms are s-scale shapes)
+
+
 def test_engine_fp32_c2_vs_reference_golden():
     """Config C2 (s-scale, 1088x608, nq 300): all 8 golden frames, direct comparison."""
     _direct_vs_golden("c2", 4)
@@ -159,20 +171,29 @@ def test_engine_bench_scale_kernel_paths_vs_small_batch():
     B = 6
     fr = torch.from_numpy(frames_u8(cfg, 0, B)).to(DEV)
     # (scores: the fixture's last score head amplifies the decoder output ~100x, DESIGN.md section 2 -- hs is the tight check)
-    for dt, tol_box, tol_score, tol_hs in ((torch.bfloat16, 0.02, 0.3, 0.06), (torch.float16, 2e-3, 0.05, 1.5e-2)):   # (measured: bf16 0.03, fp16 0.010)
+    from mo_yolo_amd.parity import engine_pair_stats
+    f32 = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=2, dtype=torch.float32)
+    ref = []
+    for t0 in range(0, B, 2):
+        ref.append({k: v.clone() for k, v in f32.forward(fr[t0:t0 + 2]).items()})
+    del f32
+    for dt in (torch.bfloat16, torch.float16):
         big = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt)
         ob = {k: v.clone() for k, v in big.forward(fr).items()}
         small = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=2, dtype=dt)
-        from mo_yolo_amd.parity import engine_pair_stats
-        for t0 in range(0, B, 2):
+        for i, t0 in enumerate(range(0, B, 2)):
             os_ = small.forward(fr[t0:t0 + 2])
             torch.cuda.synchronize()
-            st = engine_pair_stats({k: v[t0:t0 + 2] for k, v in ob.items() if hasattr(v, "shape") and v.shape[:1] == (B,)}, os_, arch.nq)
-            # (the 16-bit encoder scores are re-randomised at the 1e-3 level by the rounding of their inputs, so the two LayerNorm
-            # forms -- one pass in the weight-stationary score mode, two passes in the tiled kernel -- order a few near-ties differently)
+            sub = {k: v[t0:t0 + 2] for k, v in ob.items() if hasattr(v, "shape") and v.shape[:1] == (B,)}
+            st = engine_pair_stats(sub, os_, arch.nq)                 # bench-scale kernels vs small-batch kernels, same dtype
+            sf = engine_pair_stats(sub, ref[i], arch.nq)              # ... vs fp32: what the dtype itself costs on these frames
+            # (a random-init network amplifies a one-ulp difference in a summation order like any other rounding, DESIGN.md
+            # section 2: two correct 16-bit kernel paths differ by about as much as either differs from fp32 -- a bench-scale-only
+            # path going WRONG shows up as a multiple of that)
             assert st["topk_overlap"] > 0.9, st
-            assert st["box_max_err_matched"] < tol_box and st["score_max_err_matched"] < tol_score, (dt, st)
-            assert st["hs_max_err_matched"] < tol_hs, (dt, st)
+            for k in ("box_max_err_matched", "hs_max_err_matched", "score_max_err_matched"):
+                assert st[k] <= 1.5 * sf[k] + 1e-6, (dt, k, st, sf)
+            assert sf["box_max_err_matched"] < BARS_16[dt][0] and sf["hs_max_err_matched"] < BARS_16[dt][1], (dt, sf)
 
 
 def test_engine_fp16_c5_batched_sequences_graph():
@@ -208,14 +229,33 @@ def test_engine_fp16_c5_batched_sequences_graph():
     assert float(db) < 0.02 and float(ds) < 0.1
 
 
-@pytest.mark.parametrize("name,dt", [("tiny", torch.bfloat16), ("c2", torch.bfloat16), ("c2", torch.float16)])
-def test_engine_16bit_close_to_oracle(name, dt):
-    """16-bit activations/weights with fp32 accumulation, FREE RUNNING (own top-k), against the free-running oracle on the
-    fixture frames.  Bars = the measurements of the 2 x 600-frame study (tools/parity_stream.py -> profiles/parity_r02.json:
-    bf16 box 4.7e-4 / decoder output 0.049 / score 0.20 / births flipped 4.0 % of the active rows / top-k overlap 0.975;
-    fp16 8.6e-5 / 0.012 / 0.025 / 0.6 % / 0.997) with a margin of about 2x.  The score bar is loose by construction: the fixture's
-    last score head amplifies the decoder output ~100x, the decoder output itself is the tight check."""
-    from mo_yolo_amd.parity import engine_pair_stats
+def _eager_16bit_oracle(cfg, arch, sd, x_u8, dt):
+    """The oracle executed in `dt` by eager torch on the GPU: model and input cast to 16 bits, every op eager -- the reference's
+    own `half` switch (engine/predictor.py:131, nn/autobackend.py:108).  The YARDSTICK of the 16-bit engines: what the
+    arithmetic type costs on this network without any of this repository's kernels."""
+    sdh = {k: (v.to(DEV, dt) if v.is_floating_point() else v.to(DEV)) for k, v in sd.items()}
+    from mo_yolo_amd.synth import to_network_input
+    with torch.no_grad():
+        r = O.forward(to_network_input(x_u8).to(dt), sdh, arch, anchor_dtype=torch.float32)
+    sc = r["dec_scores"].float().sigmoid().max(-1).values.cpu()
+    return dict(topk_ind=r["topk_ind"].cpu(), boxes=r["dec_bboxes"].float().cpu(), scores=sc, obj_idxes=O.assign_ids(sc), hs=r["hs"].float().cpu())
+
+
+# absolute bars = 2 x the stream measurements of profiles/parity_r03_*.json (2 x 600 frames at C2, 2 x 96 at C4):
+#   (box, decoder output, score, births flipped / active rows, top-k overlap)
+BARS_16 = {torch.bfloat16: (9e-3, 1.3, 0.4, 0.08, 0.95), torch.float16: (5e-3, 0.6, 0.16, 0.02, 0.99)}
+
+
+@pytest.mark.parametrize("name,dt", [("tiny", torch.bfloat16), ("c2", torch.bfloat16), ("c2", torch.float16), ("c4", torch.bfloat16),
+                                     ("c4", torch.float16), ("full", torch.bfloat16), ("full", torch.float16)])
+def test_engine_16bit_within_the_budget_of_the_arithmetic_type(name, dt):
+    """16-bit activations / weights with fp32 accumulation, FREE RUNNING (own top-k), on the fixture frames against the pinned fp32
+    oracle -- and next to it the oracle itself run in the same 16-bit type by eager torch (`_eager_16bit_oracle`).  A random-init
+    network amplifies rounding noise (0.3 % per stored activation grows to 2.5 % at the feature maps whatever
+    executes it), so 'close to fp32' is a statement about the TYPE; what is asserted about the KERNELS is that the engine is never
+    further from fp32 than eager torch in that type, on boxes, decoder output, scores, flipped births and selected tokens.
+    Rows are matched by selected encoder token (mo_yolo_amd/parity.py)."""
+    from mo_yolo_amd.parity import engine_pair_stats, token_id_agreement
     cfg, arch, sd = fixture(name)
     B = min(4, cfg["frames"])
     eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt)
@@ -226,13 +266,26 @@ def test_engine_16bit_close_to_oracle(name, dt):
     torch.cuda.synchronize()
     assert torch.isfinite(out["y"]).all() and int(out["n_masked"].sum()) == 0
     sc = r["dec_scores"].sigmoid().max(-1).values
-    st = engine_pair_stats({k: v.clone() for k, v in out.items() if hasattr(v, "shape") and v.shape[:1] == (B,)},
-                           dict(topk_ind=r["topk_ind"], boxes=r["dec_bboxes"], scores=sc, obj_idxes=O.assign_ids(sc), hs=r["hs"]), arch.nq)
-    print(f"[{dt} {name}] {st}")
-    bars = {torch.bfloat16: (1.5e-3, 0.1, 0.4, 0.10, 0.94), torch.float16: (3e-4, 0.03, 0.06, 0.02, 0.99)}[dt]
+    want = dict(topk_ind=r["topk_ind"], boxes=r["dec_bboxes"], scores=sc, obj_idxes=O.assign_ids(sc), hs=r["hs"])
+    got = {k: v.clone() for k, v in out.items() if hasattr(v, "shape") and v.shape[:1] == (B,)}
+    yard = _eager_16bit_oracle(cfg, arch, sd, fr, dt)
+    st, sy = engine_pair_stats(got, want, arch.nq), engine_pair_stats(yard, want, arch.nq)
+    tk, ty = token_id_agreement(got, want, arch.nq), token_id_agreement(yard, want, arch.nq)
+    print(f"[{dt} {name}] engine {st} {tk}\n[{dt} {name}] eager torch {sy} {ty}")
+    for k in ("box_max_err_matched", "hs_max_err_matched", "score_max_err_matched"):
+        assert st[k] <= sy[k] * 1.0 + 1e-6, (k, st[k], sy[k])
+    assert st["births_flipped"] <= sy["births_flipped"] + 1, (st, sy)
+    assert st["topk_overlap"] >= sy["topk_overlap"] - 0.005, (st, sy)
+    assert tk["tokens_id_equal_frac"] >= ty["tokens_id_equal_frac"] - 0.02, (tk, ty)
+    bars = BARS_16[dt]
     assert st["box_max_err_matched"] < bars[0] and st["hs_max_err_matched"] < bars[1] and st["score_max_err_matched"] < bars[2], st
-    assert st["birth_flip_frac_of_active"] <= bars[3] or st["births_flipped"] <= 2, st
+    assert st["birth_flip_frac_of_active"] <= bars[3], st
     assert st["topk_overlap"] > bars[4], st
+    if dt == torch.float16 and name in ("c2", "c4"):
+        # the fixtures keep every score 0.03 away from the birth / miss thresholds (0.125 in the logit; fp16 moves a logit by 0.014):
+        # no birth may flip on a matched row.  The id NUMBERS follow the encoder-score order of the active tokens, which no
+        # conditioning of the score head makes 16-bit-proof (measured: tests/golden/make_golden.py:separate_topk) -- reported.
+        assert st["births_flipped"] == 0, st
 
 
 def test_engine_graph_replay_matches_eager():
@@ -285,45 +338,34 @@ def test_streamed_engines_equal_single_engine():
     assert torch.equal(got["n_rows"], want["n_rows"])
 
 
-def test_hota_parity_on_synthetic_stream():
-    """BASELINE metric, HOTA half: HOTA of the build's tracks vs HOTA of the oracle's tracks on the
-    same synthetic ground truth, with the reference evaluator's algorithm, on the fixture frames (the 2 x 600-frame figures are in
-    profiles/parity_r02.json)."""
-    from tests._util import hota_of_tracks
+def test_agreement_hota_against_the_oracle_tracks():
+    """BASELINE metric, HOTA half, as a figure that CAN FAIL: HOTA / DetA / AssA of the build's tracks scored AGAINST THE ORACLE'S
+    TRACKS as ground truth (100 = identical tracks; evaluator = the path's own, ultralytics/utils/hota.py:24-164), on the 8 fixture
+    frames, every engine free running.  (HOTA against the synthetic scene is ~0 for every engine -- a random-init decoder does not
+    localise -- so 'within 0.1 of the reference' was true by construction in round 2.)
+    fp32: 100 / 100 / 100 exactly.  16-bit: the detection half (DetA) is held to bars = the stream measurements of
+    profiles/parity_r03_c2.json minus a margin; the association half is REPORTED only: the reference hands ids out as the rank of a
+    row among the active rows of its frame (head.py:1232-1237), so one flipped birth renumbers every later row of that frame."""
+    from mo_yolo_amd.parity import agreement_hota, tracks_of
     cfg, arch, sd = fixture("c2")
     T = 8
     fr = torch.from_numpy(frames_u8(cfg, 0, T)).to(DEV)
-
-    def tracks(out):
-        rows, ids = [], []
-        for t in range(T):
-            k = int(out["n_ids"][t])
-            k = max(k, 0)
-            # active rows in query order: boxes of rows with id >= 0 (not conf filtered, like track_id)
-            act = (out["obj_idxes"][t] >= 0).cpu()
-            b = out["boxes"][t].cpu()[act]
-            xyxy = torch.stack([(b[:, 0] - b[:, 2] / 2) * cfg["W"], (b[:, 1] - b[:, 3] / 2) * cfg["H"],
-                                (b[:, 0] + b[:, 2] / 2) * cfg["W"], (b[:, 1] + b[:, 3] / 2) * cfg["H"]], -1)
-            rows.append(xyxy.numpy()); ids.append(out["obj_idxes"][t].cpu()[act].numpy())
-        return rows, ids
-
     with torch.no_grad():
         r = O.forward(net_input(cfg, 0, T), sd, arch)
-    ref_out = dict(obj_idxes=O.assign_ids(r["dec_scores"].sigmoid().max(-1).values), boxes=r["dec_bboxes"],
-                   n_ids=torch.zeros(T))
-    h_ref = hota_of_tracks(cfg, *tracks(ref_out))
+    ref_out = dict(obj_idxes=O.assign_ids(r["dec_scores"].sigmoid().max(-1).values), boxes=r["dec_bboxes"])
+    ref_trk = [tracks_of(ref_out, t, cfg["W"], cfg["H"]) for t in range(T)]
+    assert min(len(t[1]) for t in ref_trk) > 0
     res = {}
-    for dt in (torch.float32, torch.bfloat16):
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
         eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=T, dtype=dt)
-        out = eng.forward_with_topk(fr, r["topk_ind"]) if dt == torch.float32 else eng.forward(fr)
+        out = {k: v.clone() for k, v in eng.forward(fr).items()}
         torch.cuda.synchronize()
-        res[dt] = hota_of_tracks(cfg, *tracks({k: v.clone() for k, v in out.items()}))
-    d32 = abs(float(np.mean(res[torch.float32]["HOTA"])) - float(np.mean(h_ref["HOTA"]))) * 100
-    d16 = abs(float(np.mean(res[torch.bfloat16]["HOTA"])) - float(np.mean(h_ref["HOTA"]))) * 100
-    print(f"HOTA ref {100 * np.mean(h_ref['HOTA']):.3f}  fp32 delta {d32:.4f}  bf16 delta {d16:.4f}")
-    # north-star bar: HOTA within 0.1 of the reference path.  fp32: identical.  bf16 over 2 x 600 frames: <= 0.02 points
-    # (profiles/parity_r02.json); on these 8 frames one flipped birth already moves HOTA by ~0.1, hence the wider small-sample bar
-    assert d32 <= 0.1 and d16 <= 0.3
+        res[dt] = agreement_hota([tracks_of(out, t, cfg["W"], cfg["H"]) for t in range(T)], ref_trk, device=DEV)
+        print(f"[agreement-HOTA vs oracle tracks, {dt}] {res[dt]}")
+    for kind in ("compat", "published"):
+        assert res[torch.float32][kind] == {"HOTA": 100.0, "DetA": 100.0, "AssA": 100.0}, res[torch.float32]
+        assert res[torch.float16][kind]["DetA"] >= 90.0, res[torch.float16]
+        assert res[torch.bfloat16][kind]["DetA"] >= 75.0, res[torch.bfloat16]
 
 
 def test_side_state_copy_filter_and_fsqm_vs_oracle():

@@ -117,6 +117,30 @@ def test_bench_control_flow_two_ranks_gloo_dry_run():
     assert d["ms_per_step"] >= 2.2 * 0.99
 
 
+def test_bench_control_flow_c3_eight_ranks_gloo_dry_run():
+    """Config C3 as the driver launches it (`--gpus 8`, torch.distributed.run, 8 ranks) with the data path stubbed out: the
+    exact 8-rank control flow -- rendezvous on 127.0.0.1, one device per local rank (HIP_VISIBLE_DEVICES 0..7), sequence i on
+    rank i, barrier, MAX over ranks, one JSON line from rank 0 -- has run somewhere before the first real node sees it."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1",
+           "--dry-run", "--backend", "gloo"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HIP_VISIBLE_DEVICES", "LOCAL_WORLD_SIZE")}
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["frames_per_step_per_gpu"] == 576
+    rm = sorted(d["config"]["rank_map"], key=lambda e: e["rank"])
+    assert [e["rank"] for e in rm] == list(range(8))
+    assert [e["hip_visible_devices"] for e in rm] == [str(i) for i in range(8)]      # one GPU per rank, pinned before HIP starts
+    assert [e["sequences"] for e in rm] == [[i] for i in range(8)]                   # sequence i -> rank i, nothing shared
+    assert abs(d["value"] - 576 * 4 * 8 / (d["ms_per_step"] * 4 * 1e-3)) < 1e-4 * d["value"]
+
+
 def test_bench_pins_one_device_per_local_rank(monkeypatch):
     sys.path.insert(0, ROOT)
     import bench
@@ -127,6 +151,15 @@ def test_bench_pins_one_device_per_local_rank(monkeypatch):
     assert bench.pin_device(2) == "6"
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "5")               # already pinned by the launcher
     assert bench.pin_device(0) == "5"
+    # a list shorter than the local rank count would put every rank on one GPU -> refuse, unless it is the rehearsal
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    with pytest.raises(SystemExit):
+        bench.pin_device(1)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "5")
+    assert bench.pin_device(1, rehearse=True) == "5"
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5,6,7")
+    assert bench.pin_device(3) == "7"                            # never indexes outside the inherited list
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
     monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "4,5,6,7")        # ROCr renumbers its subset from 0: HIP index = local rank
     assert bench.pin_device(2) == "2"

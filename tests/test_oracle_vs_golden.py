@@ -12,7 +12,7 @@ TOL = 2e-5   # fp32 CPU vs fp32 CPU, different op decomposition only
 RTOL = 2e-5  # ... relative part: with calibrated BatchNorm statistics (round 3) the activations are O(1-10), not O(0.1)
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny3", "c2"])
+@pytest.mark.parametrize("name", ["tiny", "tiny3", "c2", "full"])
 def test_seams_frame0(name):
     g = golden(name)
     cfg, arch, sd = fixture(name)
@@ -50,7 +50,7 @@ def test_seams_frame0(name):
     assert torch.allclose(r["y"][0], torch.from_numpy(g["y"][0]), atol=TOL, rtol=RTOL)
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny3", "c2"])
+@pytest.mark.parametrize("name", ["tiny", "tiny3", "c2", "full"])
 def test_stream_y_and_ids(name):
     """Per-frame reset semantics: ids restart at 0 in every frame, in query order."""
     g = golden(name)
