@@ -607,6 +607,322 @@ static int launch_conv_ws_pipe(ConvWsParams& p, int B, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// PING-PONG form (round 3).  What the stamps of the lock-step kernel show (per C = 128 tile and wave: matrix pipe 9 200 cycles,
+// BN + SiLU 2 000, DMA issue 1 900, stores + barriers 900 -- 13 700 in all) is two waves per SIMD running the SAME program in
+// lock step: both sit in their MFMA loop together (each MFMA takes 32 cycles instead of 16: they share the pipe), then both
+// sit in the epilogue / DMA issue / store pass together while the matrix pipe idles.  The software-pipelined form above could not
+// undo that (its two waves still interleave at instruction granularity and the block's barriers re-align them every tile).
+// Here the two waves of a SIMD -- wave w (group A: waves 0-3) and wave w + 4 (group B) -- are put in ANTI-PHASE by construction.
+// A tile is cut into four barrier intervals; in every interval one group runs an MFMA half (RG output rows of its tile share,
+// alone on the pipe: 16 cycles per MFMA) while the other does the non-matrix work in the vector slots the MFMAs leave free:
+//
+//     interval   group A (waves 0-3)                                    group B (waves 4-7)
+//        0       MFMA half 1 of tile t                                  epilogue half 2 of tile t-1; DMA: patch pieces of t+1
+//        1       epilogue half 1 of t; DMA: patch pieces of t+1;        MFMA half 1 of tile t
+//                stores of the half-2 rows of tile t-1
+//        2       MFMA half 2 of tile t                                  epilogue half 1 of t; DMA: residual pieces of t+1
+//        3       epilogue half 2 of t; stores of the half-1 rows of t   MFMA half 2 of tile t
+//
+// A wave holds ONE accumulator half at a time (RG x NT fragments instead of MT x NT).  Two buffer sets (patch + staging /
+// residual image) alternate by tile parity.  Hazards: the patch of t+1 goes where the patch of t-1 lay (last read in interval 3
+// of t-1); the residual of t+1 goes into the staging image of t-1, whose last rows leave in interval 1 of t -- hence in interval 2.
+// Group A's vector-memory stream per tile is [KA patch pieces, NPS stores, NPS stores] and it retires the pieces with a counted
+// vmcnt(2 NPS) that leaves the stores in flight; group B's is [KB patch pieces, KR residual pieces], retired by vmcnt(0) at the
+// end of interval 3 (issued one or three intervals earlier).  Results are bit-identical to conv_ws_kernel (same taps in the same
+// order into the same accumulators; tests/test_gpu_ops.py).
+template <typename T, int C, int N, int TH, int WN, bool RES, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void conv_ws_pp_kernel(const ConvWsParams p) {
+  constexpr int PW = 18, PH = TH + 2, NPIX = PH * PW, CPP = C / 8, NCP = N / 8, TPX = TH * 16;
+  constexpr int PATCH_PIECES = (NPIX * CPP + 63) / 64, RES_PIECES = RES ? TPX * NCP / 64 : 0;
+  constexpr int STGB = TPX * N * 2, SETB = PATCH_PIECES * 1024 + STGB;
+  constexpr int WM = 8 / WN, MT = TH / WM, NT = N / 16 / WN, KC = C / 32;
+  constexpr int RG = MT / 2;                               // rows per half
+  constexpr int KA = (PATCH_PIECES + 7) / 8;               // patch pieces per wave of group A (interval 1): pieces [0, 4 KA)
+  constexpr int KB = (PATCH_PIECES - 4 * KA + 3) / 4;      // ... of group B (interval 0): pieces [4 KA, 4 KA + 4 KB)
+  constexpr int KR = RES_PIECES / 4;                       // residual pieces per wave of group B (interval 2)
+  constexpr int SETPX = WM * RG * 16;                      // pixels of a store set (the half-h rows of every wave)
+  constexpr int NPS = SETPX * NCP / 256;                   // 16-byte stores per thread of group A and store set
+  constexpr uint32_t OOB = 0x80000000u;
+  static_assert(MT % 2 == 0 && TH % WM == 0 && (N / 16) % WN == 0 && RES_PIECES % 4 == 0 && (SETPX * NCP) % 256 == 0, "tile vs waves");
+  static_assert(4 * KA + 4 * KB >= PATCH_PIECES && KB >= 0, "piece split");
+  static_assert(2 * SETB + 1024 <= 160 * 1024, "LDS budget");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int wn = wave % WN, wm = wave / WN;
+  const bool grpA = wave < 4;
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int t_first = xcd * p.per_xcd + slot;
+  const int t_limit = min((xcd + 1) * p.per_xcd, p.ntiles);
+  if (t_first >= t_limit) return;
+  const int n_mine = (t_limit - t_first + p.bpx - 1) / p.bpx;
+
+  const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+  const uint32_t scratch = lds_base + 2 * SETB;
+  const T* __restrict__ Ag = static_cast<const T*>(p.A);
+  const T* __restrict__ Rg = static_cast<const T*>(p.R);
+  T* __restrict__ Cg = static_cast<T*>(p.C);
+  const int64_t img_a = (int64_t)p.H * p.Wd * p.lda, img_r = (int64_t)p.H * p.Wd * p.ldr, img_c = (int64_t)p.H * p.Wd * p.ldc;
+
+  struct Tile { int b, y0, x0; bool live; };
+  auto tile_of = [&](int it) {
+    Tile t;
+    t.live = it < n_mine;
+    const int id = min(t_first + it * p.bpx, p.ntiles - 1);
+    t.b = (int)fdiv((uint32_t)id, p.fd_timg);
+    const int rem = id - t.b * p.tiles_img;
+    const int ty = (int)fdiv((uint32_t)rem, p.fd_tx);
+    t.y0 = ty * TH;
+    t.x0 = (rem - ty * p.tiles_x) * 16;
+    return t;
+  };
+  // patch piece pc of tile t -> LDS set `set` (pieces beyond the patch image: zeros into the scratch KiB, keeps the counts uniform)
+  auto patch_piece = [&](const Tile& t, int set, int pc) {
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    const int X = pc * 64 + lv, pix = X / CPP, sl = X % CPP;
+    const int py = pix / PW, px = pix - py * PW;
+    const int yy = t.y0 + py - 1, xx = t.x0 + px - 1;
+    const bool ok = t.live && pc < PATCH_PIECES && pix < NPIX && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.Wd;
+    const uint32_t voff = ok ? (uint32_t)(((yy * p.Wd + xx) * (int)p.lda + ((sl ^ cws_swz<C>(pix)) * 8)) * 2) : OOB;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Ag + (int64_t)t.b * img_a), 0, (uint32_t)(img_a * 2), 0x00020000);
+    if (ABL == 2) return;
+    cws_dma16(voff, rs, pc < PATCH_PIECES ? lds_base + set * SETB + pc * 1024 : scratch);
+  };
+  auto res_piece = [&](const Tile& t, int set, int pc) {
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    const int X = pc * 64 + lv, opx = X / NCP, sl = X % NCP;
+    const int yy = t.y0 + (opx >> 4), xx = t.x0 + (opx & 15);
+    const bool ok = t.live && yy < p.H && xx < p.Wd;
+    const uint32_t voff = ok ? (uint32_t)(((yy * p.Wd + xx) * (int)p.ldr + ((sl ^ (opx & (NCP - 1))) * 8)) * 2) : OOB;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>((RES ? Rg : Ag) + (int64_t)t.b * (RES ? img_r : img_a)), 0,
+                                                      (uint32_t)((RES ? img_r : img_a) * 2), 0x00020000);
+    if (ABL == 2) return;
+    cws_dma16(voff, rs, lds_base + set * SETB + PATCH_PIECES * 1024 + pc * 1024);
+  };
+
+  // weights / BN of this wave -> registers
+  u32x4 wf[NT][9][KC];
+  f32x4 sc[NT], sh[NT];
+  {
+    const T* Wg = static_cast<const T*>(p.W);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = (wn * NT + j) * 16;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int cc = 0; cc < KC; ++cc)
+          wf[j][tap][cc] = *reinterpret_cast<const u32x4*>(Wg + (int64_t)(n + r) * p.Kpad + tap * C + cc * 32 + q * 8);
+      sc[j] = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n + q * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+      sh[j] = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
+  // epilogue of one half: BN + SiLU (+ residual, in place) of RG x NT fragments -> staging image [pixel][N] of the tile
+  auto epi_half = [&](const f32x4 (&acc)[RG][NT], int half, unsigned char* stg) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int ch = (wn * NT + j) * 16 + q * 4;
+#pragma unroll
+      for (int y = 0; y < RG; ++y) {
+        f32x4 v = acc[y][j] * sc[j] + sh[j];
+        if (ABL != 1) { v.x = siluf_(v.x); v.y = siluf_(v.y); v.z = siluf_(v.z); v.w = siluf_(v.w); }
+        const int opx = (wm * MT + half * RG + y) * 16 + r;
+        unsigned char* cell = stg + opx * (N * 2) + ((((ch >> 3) ^ (opx & (NCP - 1))) * 16) + ((ch >> 2) & 1) * 8);
+        if (RES) {
+          const u32x2 res = *reinterpret_cast<const u32x2*>(cell);
+          v += f32x4{DT<T>::lo(res.x), DT<T>::hi(res.x), DT<T>::lo(res.y), DT<T>::hi(res.y)};
+        }
+        *reinterpret_cast<u32x2*>(cell) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+      }
+    }
+  };
+  // The MFMA groups of one half (same tap order as conv_ws_kernel: kx, cc outer; ky inner).
+  // Fragment addresses without per-read arithmetic: the pixel of a read is P + c (P = this lane's first pixel, c = a compile-time
+  // constant), its swizzle term depends on (P + c) & 7 = ((P & 7) + (c & 7)) & 7 only, and the k-block cc enters as an XOR of
+  // address bits that nothing else touches.  So 8 per-lane registers A[j] (j = c & 7), formed once per half, give every address
+  // as (A[c & 7] ^ (cc << 6)) + an immediate offset: at most one VALU operation per ds_read_b128 (the lock-step kernel's code
+  // spends 2-3 plus two hoisted registers per fragment row).  The reads of group g + 1 are issued before the MFMAs of group g.
+  const int pix0 = wm * MT * PW + r;
+  auto half_mfma = [&](auto half_c, uint32_t patch_off, f32x4 (&acc)[RG][NT]) {
+    constexpr int half = decltype(half_c)::value;
+    int pv = pix0;
+    asm volatile("" : "+v"(pv));
+    uint32_t A[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) A[j] = patch_off + (uint32_t)pv * (C * 2) + (uint32_t)((q ^ cws_swz<C>((pv & 7) + j)) * 16);
+#pragma unroll
+    for (int y = 0; y < RG; ++y)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto rd = [&](auto g_c, u32x4 (&buf)[RG + 2]) {
+      constexpr int g = decltype(g_c)::value, kx = g / KC, cc = g % KC;
+#pragma unroll
+      for (int y = 0; y < RG + 2; ++y) {
+        const int c = half * RG * PW + y * PW + kx;         // compile-time after unrolling
+        buf[y] = *reinterpret_cast<const u32x4*>(smem + ((A[c & 7] ^ (uint32_t)(cc * 64)) + (uint32_t)(c * (C * 2))));
+      }
+    };
+    u32x4 a[2][RG + 2];
+    rd(std::integral_constant<int, 0>{}, a[0]);
+    [&]<int... GI>(std::integer_sequence<int, GI...>) {
+      ([&] {
+        constexpr int kx = GI / KC, cc = GI % KC;
+        if constexpr (GI + 1 < 3 * KC) rd(std::integral_constant<int, GI + 1>{}, a[(GI + 1) & 1]);
+        if (ABL == 3 && GI > 0) return;
+#pragma unroll
+        for (int y = 0; y < RG; ++y)
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[y][j] = cws_mfma<T>(acc[y][j], wf[j][ky * 3 + kx][cc], a[GI & 1][y + ky]);
+      }(), ...);
+    }(std::make_integer_sequence<int, 3 * KC>{});
+  };
+  // group A's store pass over store set h (the half-h rows of every wave): thread ta = tid (0..255), chunk X = k * 256 + ta
+  auto store_set = [&](const Tile& t, const unsigned char* stg, int h, bool valid) {
+    const auto rsC = __builtin_amdgcn_make_buffer_rsrc(Cg + (int64_t)t.b * img_c, 0, (uint32_t)(img_c * 2), 0x00020000);
+    u32x4 vv[NPS];
+    auto geom = [&](int k, int& opx, int& row, int& x, int& c) {
+      const int X = k * 256 + tid, ps = X / NCP;
+      c = X % NCP;
+      const int rs_ = ps >> 4;
+      x = ps & 15;
+      row = (rs_ / RG) * MT + h * RG + (rs_ % RG);
+      opx = row * 16 + x;
+    };
+#pragma unroll
+    for (int k = 0; k < NPS; ++k) {
+      int opx, row, x, c;
+      geom(k, opx, row, x, c);
+      vv[k] = *reinterpret_cast<const u32x4*>(stg + opx * (N * 2) + ((c ^ (opx & (NCP - 1))) * 16));
+    }
+#pragma unroll
+    for (int k = 0; k < NPS; ++k) {
+      int opx, row, x, c;
+      geom(k, opx, row, x, c);
+      const bool ok = valid && ABL != 4 && t.y0 + row < p.H && t.x0 + x < p.Wd;
+      const int goff = (((t.y0 + row) * p.Wd + t.x0 + x) * (int)p.ldc + c * 8) * 2;
+      __builtin_amdgcn_raw_buffer_store_b128(vv[k], rsC, ok ? (uint32_t)goff : OOB, 0, 0);
+    }
+  };
+
+  // prologue: patch and residual of the first tile, by all eight waves
+  {
+    const Tile t0 = tile_of(0);
+#pragma unroll
+    for (int k = 0; k < (PATCH_PIECES + 7) / 8; ++k) patch_piece(t0, 0, wave + 8 * k);
+    if constexpr (RES) {
+#pragma unroll
+      for (int k = 0; k < RES_PIECES / 8; ++k) res_piece(t0, 0, wave + 8 * k);
+    }
+    cws_wait_vmcnt<0>();
+    __syncthreads();
+  }
+
+  f32x4 acc[RG][NT];
+#pragma unroll
+  for (int y = 0; y < RG; ++y)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  Tile prev = tile_of(0);
+  for (int it = 0; it < n_mine; ++it) {
+    const int set = it & 1, nset = set ^ 1;
+    const Tile cur = tile_of(it), nxt = tile_of(it + 1);
+    const uint32_t patch_off = (uint32_t)(set * SETB);
+    unsigned char* stg_cur = smem + set * SETB + PATCH_PIECES * 1024;
+    unsigned char* stg_prev = smem + nset * SETB + PATCH_PIECES * 1024;
+    // ---- interval 0
+    if (grpA) {
+      half_mfma(std::integral_constant<int, 0>{}, patch_off, acc);
+    } else {
+      if (it > 0) epi_half(acc, 1, stg_prev);
+#pragma unroll
+      for (int k = 0; k < KB; ++k) patch_piece(nxt, nset, 4 * KA + (wave - 4) + 4 * k);
+    }
+    __syncthreads();
+    // ---- interval 1
+    if (grpA) {
+      epi_half(acc, 0, stg_cur);
+#pragma unroll
+      for (int k = 0; k < KA; ++k) patch_piece(nxt, nset, wave + 4 * k);
+      store_set(prev, stg_prev, 1, it > 0);
+    } else {
+      half_mfma(std::integral_constant<int, 0>{}, patch_off, acc);
+    }
+    __syncthreads();
+    // ---- interval 2
+    if (grpA) {
+      half_mfma(std::integral_constant<int, 1>{}, patch_off, acc);
+    } else {
+      epi_half(acc, 0, stg_cur);
+      if constexpr (RES) {
+#pragma unroll
+        for (int k = 0; k < KR; ++k) res_piece(nxt, nset, (wave - 4) + 4 * k);
+      }
+    }
+    __syncthreads();
+    // ---- interval 3
+    if (grpA) {
+      epi_half(acc, 1, stg_cur);
+      store_set(cur, stg_cur, 0, true);
+      cws_wait_vmcnt<2 * NPS>();                                   // this wave's patch pieces of tile it+1; the stores stay in flight
+    } else {
+      half_mfma(std::integral_constant<int, 1>{}, patch_off, acc);
+      cws_wait_vmcnt<0>();                                         // this wave's patch + residual pieces of tile it+1
+    }
+    __syncthreads();
+    prev = cur;
+  }
+  // drain: group B's second half of the last tile, then its rows
+  {
+    unsigned char* stg_last = smem + ((n_mine - 1) & 1) * SETB + PATCH_PIECES * 1024;
+    if (!grpA) epi_half(acc, 1, stg_last);
+    __syncthreads();
+    if (grpA) store_set(prev, stg_last, 1, true);
+  }
+  cws_wait_vmcnt<0>();
+}
+
+template <typename T, int C, int N, int TH, int WN, bool RES, int ABL = 0>
+static int launch_conv_ws_pp(ConvWsParams& p, int B, hipStream_t st) {
+  constexpr int PATCH_PIECES = ((TH + 2) * 18 * (C / 8) + 63) / 64;
+  constexpr int LDS = 2 * (PATCH_PIECES * 1024 + TH * 16 * N * 2) + 1024;
+  if constexpr (ABL == 0 && std::is_same<T, bf16_t>::value && !RES) {
+    static int abl = -1;                   // MOY_CWS_ABL=1..4: timing-only builds (no SiLU / no DMA / one MFMA group / no stores)
+    if (abl < 0) { const char* e = getenv("MOY_CWS_ABL"); abl = e ? atoi(e) : 0; }
+    if (abl == 1) return launch_conv_ws_pp<T, C, N, TH, WN, RES, 1>(p, B, st);
+    if (abl == 2) return launch_conv_ws_pp<T, C, N, TH, WN, RES, 2>(p, B, st);
+    if (abl == 3) return launch_conv_ws_pp<T, C, N, TH, WN, RES, 3>(p, B, st);
+    if (abl == 4) return launch_conv_ws_pp<T, C, N, TH, WN, RES, 4>(p, B, st);
+  }
+  auto kern = conv_ws_pp_kernel<T, C, N, TH, WN, RES, ABL>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (LDS > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return MOY_ELAUNCH;
+    attr_set = true;
+  }
+  p.tiles_x = (p.Wd + 15) / 16;
+  const int tiles_y = (p.H + TH - 1) / TH;
+  p.tiles_img = p.tiles_x * tiles_y;
+  p.ntiles = B * p.tiles_img;
+  p.fd_timg = make_fastdiv((uint32_t)p.tiles_img);
+  p.fd_tx = make_fastdiv((uint32_t)p.tiles_x);
+  p.per_xcd = (p.ntiles + 7) / 8;
+  p.bpx = cws_num_cus() / 8;
+  if (p.bpx < 1) p.bpx = 1;
+  if (p.bpx > p.per_xcd) p.bpx = p.per_xcd;
+  hipLaunchKernelGGL(kern, dim3(8 * p.bpx), dim3(512), LDS, st, p);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stride-2 member of the family (the down-sampling convs of the backbone / neck, yolo_track.yaml:18-24,35,41: Cin -> Cout, 3x3,
 // stride 2, pad 1).  Same structure as conv_ws_kernel; what changes is the patch:
 //   * an output tile of TH x 16 pixels needs (2 TH + 1) x 33 input pixels; a patch row is stored PARITY-DE-INTERLEAVED --
@@ -856,6 +1172,11 @@ template <typename T>
 static int conv_ws_dispatch(ConvWsParams& p, int B, int C, bool res, hipStream_t st) {
   const int v = cws_variant();
   const bool sp = v & 1, occ2 = v & 2;
+  if (v & 8) {                             // ping-pong form (round 3)
+    if (C == 32) return res ? launch_conv_ws_pp<T, 32, 32, 16, 2, true>(p, B, st) : launch_conv_ws_pp<T, 32, 32, 16, 2, false>(p, B, st);
+    if (C == 64) return res ? launch_conv_ws_pp<T, 64, 64, 16, 4, true>(p, B, st) : launch_conv_ws_pp<T, 64, 64, 16, 4, false>(p, B, st);
+    if (C == 128) return res ? launch_conv_ws_pp<T, 128, 128, 8, 8, true>(p, B, st) : launch_conv_ws_pp<T, 128, 128, 8, 8, false>(p, B, st);
+  }
   if (v & 4) {                             // software-pipelined form
     if (C == 32) {
       if (occ2) return res ? launch_conv_ws_pipe<T, 32, 32, 16, 2, true, 2>(p, B, st) : launch_conv_ws_pipe<T, 32, 32, 16, 2, false, 2>(p, B, st);
