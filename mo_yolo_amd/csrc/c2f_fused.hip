@@ -382,7 +382,7 @@ static int c2f_num_cus() {
 template <typename T>
 static int launch_c2f(C2fParams& p, hipStream_t st) {
   static int diag = -1;
-  if (diag < 0) { const char* e = getenv("MOY_C2F_DIAG"); diag = e ? atoi(e) : 0; }
+  if (diag < 0) diag = garbage_mode_env("MOY_C2F_DIAG");
   auto kern = diag ? c2f_fused_kernel<T, 1> : c2f_fused_kernel<T, 0>;
   static bool attr_set = false;
   if (!attr_set) {

@@ -1,5 +1,7 @@
 // Shared device helpers for the gfx950 kernels of libmoyolo.so (wave64 everywhere).
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -172,5 +174,17 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st);
 // conv_ws.hip: persistent weight-stationary direct 3x3 convolution (MOY_ENOSYS when the shape is not its own)
 int conv_ws_try(const moy_gemm_args* a, hipStream_t st);
+
+// Timing-only / diagnostic modes (MOY_*_ABL, MOY_*_DIAG) produce GARBAGE results by design: they exist for tools/bench_gemm.py
+// and tools/probes/.  A variable left set in a production environment would corrupt outputs with rc = 0, so the first use says so
+// loudly on stderr.
+inline int garbage_mode_env(const char* name) {
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : 0;
+  if (v)
+    fprintf(stderr, "\n*** libmoyolo: %s=%d selects a TIMING-ONLY / DIAGNOSTIC kernel build: its RESULTS ARE GARBAGE by design. "
+                    "Unset it for any run whose outputs matter. ***\n\n", name, v);
+  return v;
+}
 
 }  // namespace moy

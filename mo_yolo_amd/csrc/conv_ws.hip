@@ -895,7 +895,7 @@ static int launch_conv_ws_pp(ConvWsParams& p, int B, hipStream_t st) {
   constexpr int LDS = 2 * (PATCH_PIECES * 1024 + TH * 16 * N * 2) + 1024;
   if constexpr (ABL == 0 && std::is_same<T, bf16_t>::value && !RES) {
     static int abl = -1;                   // MOY_CWS_ABL=1..4: timing-only builds (no SiLU / no DMA / one MFMA group / no stores)
-    if (abl < 0) { const char* e = getenv("MOY_CWS_ABL"); abl = e ? atoi(e) : 0; }
+    if (abl < 0) abl = garbage_mode_env("MOY_CWS_ABL");
     if (abl == 1) return launch_conv_ws_pp<T, C, N, TH, WN, RES, 1>(p, B, st);
     if (abl == 2) return launch_conv_ws_pp<T, C, N, TH, WN, RES, 2>(p, B, st);
     if (abl == 3) return launch_conv_ws_pp<T, C, N, TH, WN, RES, 3>(p, B, st);
@@ -1134,7 +1134,7 @@ static int launch_conv_ws(ConvWsParams& p, int B, hipStream_t st) {
   static_assert(G::LDS * OCC <= 160 * 1024, "LDS budget");
   if constexpr (ABL == 0 && std::is_same<T, bf16_t>::value && !RES) {
     static int abl = -1;                   // MOY_CWS_ABL=1..4: timing-only builds (no SiLU / no DMA / one MFMA group / no stores)
-    if (abl < 0) { const char* e = getenv("MOY_CWS_ABL"); abl = e ? atoi(e) : 0; }
+    if (abl < 0) abl = garbage_mode_env("MOY_CWS_ABL");
     if (abl == 1) return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 1>(p, B, st);
     if (abl == 2) return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 2>(p, B, st);
     if (abl == 3) return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 3>(p, B, st);

@@ -328,7 +328,7 @@ extern "C" int moy_decoder_tail(const moy_decoder_tail_args* a, void* stream) {
   }
   const int blocks = (a->M + TAIL_BM - 1) / TAIL_BM;
   static int abl = -1;
-  if (abl < 0) { const char* e = getenv("MOY_TAIL_ABL"); abl = e ? atoi(e) : 0; }
+  if (abl < 0) abl = garbage_mode_env("MOY_TAIL_ABL");
   if (abl == 1 && a->dtype == MOY_BF16) {
     auto k1 = decoder_tail_kernel<bf16_t, 1>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) != hipSuccess) return MOY_ELAUNCH;

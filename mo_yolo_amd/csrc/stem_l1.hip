@@ -302,7 +302,7 @@ static int launch_stem_l1(StemL1Params& p, hipStream_t st) {
   constexpr int WIN_B = (((4 * TH + 3) * 52 * 4 + 15) / 16) * 16, PATCH_B = (((2 * TH + 1) * 33 * 64 + 1023) / 1024) * 1024, STG_B = TH * 16 * 128;
   constexpr int LDS = WIN_B + PATCH_B + STG_B + 128;
   static int diag = -1;
-  if (diag < 0) { const char* e = getenv("MOY_SL1_DIAG"); diag = e ? atoi(e) : 0; }
+  if (diag < 0) diag = garbage_mode_env("MOY_SL1_DIAG");
   auto kern = diag ? stem_l1_kernel<T, 1> : stem_l1_kernel<T, 0>;
   static bool attr_set = false;
   if (!attr_set) {

@@ -932,6 +932,9 @@ class StreamedEngines:
         """frames [batch, ...] resident on the device (copied into input slot `slot`), or None when `load(frames, slot)` /
         an in-place producer already filled the slot: the step then moves no frame bytes.  Enqueue-only: outputs are valid
         after `synchronize()`."""
+        if self._split and slot != 0:
+            # capture_split() records its two graphs for input slot 0 only (ADVICE r2: the slot used to be ignored silently)
+            raise ValueError("split_priority replays the slot-0 graphs: use slot 0, or capture() per slot without split_priority")
         if not self._warm:
             self._warmup(frames, slot)
         cur = torch.cuda.current_stream()

@@ -325,13 +325,15 @@ def test_stem_and_first_downsample_fused(dt, B, H, W):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("B,H,W", [(2, 19, 45), (1, 152, 272), (3, 8, 30), (2, 9, 61), (1, 272, 480)])
+@pytest.mark.parametrize("B,H,W", [(2, 19, 45), (1, 152, 272), (3, 8, 30), (2, 9, 61), (1, 272, 480), (40, 40, 272)])
 def test_c2f_block_fused(dt, B, H, W):
     """moy_c2f_fused (C2f 64 -> [32 | 32] -> 64, n = 1, shortcut: block.py:219-240, :271-283; conv.py:36-38) against (i) the same
     block as four moy_gemm launches -- equal up to the fp32 summation order inside an MFMA, i.e. an ulp of T on a few values --
     and (ii) torch fp32 with every intermediate rounded to T where the launches store it.  Sizes: tiles cut by both image edges
     (W = 45 -> two tiles of 23; H = 19, 9 -> a last row group of 3 / 1 rows), the C2 and C4 layer-2 geometries (152 x 272 -> 10
-    tiles of 28; 272 x 480 -> 16 of 30), exactly one tile; input / output as channel slices of wider buffers."""
+    tiles of 28; 272 x 480 -> 16 of 30), exactly one tile; input / output as channel slices of wider buffers; and B x strips
+    (40 x 10 = 400) above the grid of one block per CU: blocks then walk WHOLE strips (nfull > 0) and share the
+    left-over strips as row ranges (rem > 0) -- the dealing the bench-scale launch (288 frames: nfull 11, rem 64) uses."""
     c = 32
     x = q(rnd(B, 64, H, W, seed=1), dt)
     ws = dict(cv1=q(rnd(64, 64, seed=2, scale=1 / 8), dt), m1=q(rnd(c, c, 3, 3, seed=3, scale=1 / 17), dt),
@@ -418,9 +420,11 @@ def test_stem_conv_mfma(B, H, W, Cout):
     assert torch.allclose(got, ref, atol=2e-2), float((got - ref).abs().max())
 
 
+@pytest.mark.parametrize("Cc", [16, 64, 128])
 @pytest.mark.parametrize("dt", DT)
-def test_sppf_pool_and_upsample(dt):
-    B, H, W, Cc = 2, 19, 34, 16
+def test_sppf_pool_and_upsample(dt, Cc):
+    """(Cc >= 32 at 16 bits takes the four-chunks-per-block form of sppf_pool_kernel)"""
+    B, H, W = 2, 19, 34
     x = q(rnd(B, Cc, H, W, seed=1), dt)
     xr = x.permute(0, 2, 3, 1).reshape(-1, Cc).contiguous().to(DEV, dt)
     y1 = F.max_pool2d(x, 5, 1, 2); y2 = F.max_pool2d(y1, 5, 1, 2); y3 = F.max_pool2d(y2, 5, 1, 2)
