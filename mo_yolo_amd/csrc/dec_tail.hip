@@ -49,43 +49,47 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
   const int r = lane & 15, q = lane >> 4;
   const int m0 = blockIdx.x * BM;
 
-  u32x4 wf[NT][8];
-  // this wave's 32 output rows of a [*, pitch] weight matrix, k columns koff .. koff+255.  (Requesting the next product's weights
-  // half a product ahead -- panels 0-3 once consumed -- was tried: hipcc then keeps both generations of the registers apart and
-  // spills 144 VGPRs; 132 us instead of 83.)
+  // This wave's 32 output rows of the current [*, pitch] weight matrix (k columns koff .. koff+255) as two K HALVES of four
+  // 32-wide panels: wa[0] = panels 0-3, wa[1] = panels 4-7.  Round 3: a product walks its K halves OUTERMOST (both row halves of
+  // half 0, then both of half 1; every accumulator still sees its panels in the order 0..7, so results are unchanged), and the
+  // moment a half has been consumed the SAME registers are re-requested with that half of the NEXT product's weights -- the load
+  // is in flight under the remaining MFMAs of this product, its epilogue and the barrier.  Round 2 fetched a whole chunk after
+  // the product that used the previous one (two chunks live = spills) and measured 36 % of the kernel waiting for those loads.
+  u32x4 wa[2][NT][4];
+  struct WSrc { const void* W; int row0, pitch, koff; };
   bool w_loaded = false;
-  auto load_w = [&](const void* W, int row0, int pitch, int koff) {
-    if constexpr (ABL == 1) { if (w_loaded) return; w_loaded = true; }
-    __builtin_amdgcn_sched_barrier(0);   // not above the MFMAs that still read the previous chunk (two chunks live = spills)
-    const T* Wg = static_cast<const T*>(W) + (int64_t)(row0 + wave * WC) * pitch + koff;
+  auto req_half = [&](int h, const WSrc& w) {
+    if constexpr (ABL == 1) { if (w_loaded) return; }
+    if (!w.W) return;
+    const T* Wg = static_cast<const T*>(w.W) + (int64_t)(w.row0 + wave * WC) * w.pitch + w.koff + h * 128;
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int pn = 0; pn < 8; ++pn) wf[j][pn] = *reinterpret_cast<const u32x4*>(Wg + (int64_t)(j * 16 + r) * pitch + pn * 32 + q * 8);
+      for (int pn = 0; pn < 4; ++pn) wa[h][j][pn] = *reinterpret_cast<const u32x4*>(Wg + (int64_t)(j * 16 + r) * w.pitch + pn * 32 + q * 8);
   };
   const int lbase = r * 512 + ((q ^ r) << 4);      // fragment of row i*16 + r, chunk (pn*4 + q) ^ r
-  // rows in two halves of 64: 16 fragment registers live instead of 32 (two accumulator sets + the weight chunk already fill
-  // the 256-register budget of 2 waves per SIMD)
-  auto gemm_acc = [&](const unsigned char* As, f32x4 (&acc)[MT][NT]) {
-    constexpr int HM = MT / 2, NSTEP = 16;          // step s = (row half hh = s / 8, panel pn = s % 8); fragments of step s+1 are
-    u32x4 af[2][HM];                                // requested before the MFMAs of step s
+  // rows in two halves of 64: 16 fragment registers live instead of 32
+  auto gemm_acc = [&](const unsigned char* As, f32x4 (&acc)[MT][NT], const WSrc& next) {
+    constexpr int RS = 4, HM = MT / RS, NSTEP = 8 * RS;   // step s = (K half kh, row part rp, panel kh * 4 + s % 4), K half outermost;
+    u32x4 af[2][HM];                                      // the fragments of step s+1 are requested before the MFMAs of step s
+    auto frag = [&](int s_, u32x4 (&buf)[HM]) {
+      const int kh = s_ / (4 * RS), rp = (s_ >> 2) % RS, pn = kh * 4 + (s_ & 3);
 #pragma unroll
-    for (int i = 0; i < HM; ++i) af[0][i] = *reinterpret_cast<const u32x4*>(As + (lbase + i * 8192));
+      for (int i = 0; i < HM; ++i) buf[i] = *reinterpret_cast<const u32x4*>(As + ((lbase ^ (pn * 64)) + (rp * HM + i) * 8192));
+    };
+    frag(0, af[0]);
 #pragma unroll
     for (int s_ = 0; s_ < NSTEP; ++s_) {
-      const int hh = s_ >> 3, pn = s_ & 7;
-      if (s_ + 1 < NSTEP) {
-        const int h2 = (s_ + 1) >> 3, p2 = (s_ + 1) & 7;
-#pragma unroll
-        for (int i = 0; i < HM; ++i)
-          af[(s_ + 1) & 1][i] = *reinterpret_cast<const u32x4*>(As + ((lbase ^ (p2 * 64)) + (h2 * HM + i) * 8192));
-      }
+      const int kh = s_ / (4 * RS), rp = (s_ >> 2) % RS, p4 = s_ & 3;
+      if (s_ + 1 < NSTEP) frag(s_ + 1, af[(s_ + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < HM; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[hh * HM + i][j] = tail_mfma<T>(acc[hh * HM + i][j], wf[j][pn], af[s_ & 1][i]);
+        for (int j = 0; j < NT; ++j) acc[rp * HM + i][j] = tail_mfma<T>(acc[rp * HM + i][j], wa[kh][j][p4], af[s_ & 1][i]);
       __builtin_amdgcn_sched_barrier(0);
+      if (s_ == NSTEP / 2 - 1) { req_half(0, next); __builtin_amdgcn_sched_barrier(0); }   // K half 0 consumed: its registers take the next product's
+      if (s_ == NSTEP - 1) { req_half(1, next); __builtin_amdgcn_sched_barrier(0); if constexpr (ABL == 1) w_loaded = true; }
     }
   };
   auto zero = [&](f32x4 (&acc)[MT][NT]) {
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
       const int m = min(m0 + row, p.M - 1);
       xr[k] = *reinterpret_cast<const u32x4*>(Xg + (int64_t)m * p.ld_samp + c * 8);
     }
-    load_w(p.Wp, 0, 256, 0);
+    { const WSrc w0{p.Wp, 0, 256, 0}; req_half(0, w0); req_half(1, w0); }
 #pragma unroll
     for (int k = 0; k < BM * 32 / NTHR; ++k) {
       const int id = tid + k * NTHR, row = id >> 5, c = id & 31;
@@ -167,8 +171,7 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
   // ---- P1: e2 = LN2(samp . Wp^T + bp + e1) -> XB
   {
     zero(acc);
-    gemm_acc(XA, acc);
-    load_w(p.W1, 0, 256, 0);                         // first FFN chunk, in flight under the LayerNorm
+    gemm_acc(XA, acc, WSrc{p.W1, 0, 256, 0});         // next: the first FFN chunk, in flight under the second K half and the LayerNorm
     __builtin_amdgcn_sched_barrier(0);
     const T* Eg = static_cast<const T*>(p.e1);       // residual rows: 8 bytes per lane and sub-tile
 #pragma unroll
@@ -196,8 +199,7 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
   const int nchunk = p.d_ffn >> 8;
   for (int c = 0; c < nchunk; ++c) {
     zero(acc);
-    gemm_acc(XB, acc);                               // wf = W1 rows [c*256 + wave*32, +32)
-    load_w(p.W2, 0, p.d_ffn, c * 256);               // linear2: this wave's 32 output rows, k slice of chunk c
+    gemm_acc(XB, acc, WSrc{p.W2, 0, p.d_ffn, c * 256});   // weights: W1 rows [c*256 + wave*32, +32); next: linear2, this wave's 32 output rows, k slice of chunk c
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = wave * WC + j * 16 + q * 4;
@@ -207,9 +209,7 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
         put4(XA, i * 16 + r, n, __builtin_elementwise_max(acc[i][j] + bb, f32x4{0.f, 0.f, 0.f, 0.f}));
     }
     __syncthreads();
-    gemm_acc(XA, acc3);
-    if (c + 1 < nchunk) load_w(p.W1, (c + 1) * 256, 256, 0);
-    else load_w(p.B0, 0, 256, 0);                    // box head, first layer
+    gemm_acc(XA, acc3, c + 1 < nchunk ? WSrc{p.W1, (c + 1) * 256, 256, 0} : WSrc{p.B0, 0, 256, 0});   // next: the following chunk, or the box head's first layer
     __syncthreads();                                 // XA is rewritten by the next chunk (or by e3 below)
   }
   // e3 = LN3(acc3 + b2 + e2) -> XA, and out
@@ -239,8 +239,7 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
 
   // ---- P3: box head on e3 (XA): t1 -> XB, t2 in registers, 4 dots per row, refinement
   zero(acc);
-  gemm_acc(XA, acc);
-  load_w(p.B1, 0, 256, 0);
+  gemm_acc(XA, acc, WSrc{p.B1, 0, 256, 0});
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = wave * WC + j * 16 + q * 4;
@@ -251,7 +250,7 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
   }
   __syncthreads();
   zero(acc);
-  gemm_acc(XB, acc);
+  gemm_acc(XB, acc, WSrc{nullptr, 0, 0, 0});
   float part[MT][4];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
