@@ -396,7 +396,9 @@ def main(argv=None):
             # further from fp32 on every one of them, same files); there is no `or few flips` escape any more.
             # births: stream means 4.3 % (bf16) / 0.9 % (fp16) of the active rows at C2, 5.0 % / 0.8 % at C4; on ~900 active rows the
             # sampling spread is +-0.7 % / +-0.3 %
-            bars = {"f32": (1e-4, 1e-3, 1e-3, 0.0), "f16": (5e-3, 0.6, 0.16, 0.03), "bf16": (9e-3, 1.3, 0.4, 0.09)}[dtype_name]
+            # (a 32-frame window is not the stream mean: frames 8..39 of sequence 0 measure 8.4 % for bf16 -- deterministic, the same
+            # on every device -- so the bars are 1.4 x that window and 2 x the fp16 one; eager torch bf16 on this network: 16.6 %)
+            bars = {"f32": (1e-4, 1e-3, 1e-3, 0.0), "f16": (5e-3, 0.6, 0.16, 0.03), "bf16": (9e-3, 1.3, 0.4, 0.12)}[dtype_name]
             st_ = parity["bench_engine_vs_fp32_engine"]
             parity["bars"] = {"box_matched": bars[0], "hs_matched": bars[1], "score_matched": bars[2], "birth_flip_frac_of_active": bars[3]}
             parity["ok"] = bool(st_["box_max_err_matched"] <= bars[0] and st_["hs_max_err_matched"] <= bars[1]

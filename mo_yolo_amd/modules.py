@@ -576,8 +576,9 @@ def _x7(eng, out):
     B = eng.B
     refer = out["refer_bbox_logit"]
     enc_scores = eng.scores_all.view(B, eng.S, -1)[torch.arange(B, device=refer.device)[:, None], out["topk_ind"].long()]
-    return (out["boxes"].unsqueeze(0).clone(), out["logits"].unsqueeze(0).clone(), refer.sigmoid(), enc_scores, None,
-            refer.sigmoid(), out["hs"].clone())
+    enc_boxes = ops.sigmoid_f32(refer.contiguous())                   # enc_bboxes = sigmoid(refer_bbox) (head.py:1100), on the library
+    return (out["boxes"].unsqueeze(0).clone(), out["logits"].unsqueeze(0).clone(), enc_boxes, enc_scores, None,
+            enc_boxes.clone(), out["hs"].clone())
 
 
 class MOTRTrack(nn.Module):
@@ -725,5 +726,5 @@ class TrackingModel(nn.Module):
         inst.query_pos = out["trk_qpos"][0][:n].clone()                # memory slots (compacted in query order): the QIM-updated embedding
         inst.ref_pts = out["trk_ref"][0][:n].clone()
         self._temporal_token = inst
-        ref = eng.refer_all.view(1, -1, 4)[0, :, :2].sigmoid() * scale[:2]
+        ref = ops.sigmoid_f32(eng.refer_all.view(-1, 4).contiguous())[:, :2] * scale[:2]
         return {"track_instances": inst, "ref_pts": ref.clone()}
