@@ -242,7 +242,10 @@ def main(argv=None):
             if a.temporal:
                 return torch.from_numpy(np.concatenate([s.frames(i, 1) for s in seqs])).to(dev)
             per = B // len(seqs)
-            return torch.from_numpy(np.concatenate([s.frames(i * per, per) for s in seqs])).to(dev)
+            # the synthetic sequences are 600 frames long by design (the rectangles have left the scene soon after):
+            # slot i starts at frame i * per while that stays inside the sequence, else the slots are windows 8 frames apart
+            t0 = i * per if (i + 1) * per <= 600 else 8 * i
+            return torch.from_numpy(np.concatenate([s.frames(t0, per) for s in seqs])).to(dev)
 
         if a.temporal:
             eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dtype, device=dev, temporal=a.temporal, n_inputs=n_slots)
