@@ -53,6 +53,9 @@ def parse(argv=None):
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-launch-table", action="store_true")
     ap.add_argument("--dump-launches", default=None, help="write the per-launch timing table (json) here")
+    ap.add_argument("--resize-from", default=None, metavar="HxW",
+                    help="frames arrive at this size (e.g. 1080x1920) and every step first stretch-resizes them on the device to the network "
+                         "resolution (moy_resize_linear_u8 = LetterBox scaleFill, predict.py:96-105): SURVEY §8(f) rank 3 inside the timed region")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="default C2 run at N=1 appends short C4 / C5 / temporal legs (5 steps each, child processes) under `extra`")
     return ap.parse_args(argv)
@@ -269,9 +272,26 @@ def main(argv=None):
             torch.cuda.synchronize()
             pipe.forward(slot=0)                          # first call: eager pass + graph capture
             torch.cuda.synchronize()
+            if a.resize_from:
+                # camera-resolution frames resident in HBM (one source slot per engine: the same pixels every step; only their
+                # SIZE matters to the resize kernel), resized on each engine's stream into the input slot its graph then reads
+                from mo_yolo_amd import ops as _ops
+                hs, ws = (int(v) for v in a.resize_from.lower().split("x"))
+                gsrc = torch.Generator(device="cpu").manual_seed(7)
+                src = [torch.randint(0, 256, (pipe.Bs, hs, ws, 3), dtype=torch.uint8, generator=gsrc).to(dev) for _ in pipe.engines]
+                line_extra["resize_from"] = f"{ws}x{hs}"
 
-            def step(i):
-                pipe.forward(slot=i % n_slots)
+                def step(i):
+                    slot = i % n_slots
+                    cur_s = torch.cuda.current_stream()
+                    for e, st_, sr in zip(pipe.engines, pipe.streams, src):
+                        st_.wait_stream(cur_s)
+                        with torch.cuda.stream(st_):
+                            _ops.resize_linear_u8(sr, (cfg["H"], cfg["W"]), out=e.inputs[slot])
+                    pipe.forward(slot=slot)
+            else:
+                def step(i):
+                    pipe.forward(slot=i % n_slots)
 
     if rank == 0:
         log("plan built and captured; warm-up")
