@@ -237,6 +237,28 @@ typedef struct moy_decoder_tail_args {
 
 int moy_decoder_tail(const moy_decoder_tail_args* args, void* stream);
 
+/* The row-wise MIDDLE of a decoder layer in one launch (round 3; csrc/dec_mid.hip), 16-bit types:
+ *   e1    = LayerNorm1(x + attn . Wo^T + bo)            MOTRDecoderLayer.forward, nn/modules/transformer.py:640-641
+ *                                                        (self_attn.out_proj, dropout = identity, norm1)
+ *   offaw = (e1 + qpos) . Woa^T + boa   (fp32)           MSDeformAttn.forward, transformer.py:262-266: sampling_offsets and
+ *                                                        attention_weights of with_pos_embed(embed, query_pos), :644
+ * Woa = [sampling_offsets.weight ; attention_weights.weight] as [rows, 256] T with rows = max(256, n_oa) (zero rows past n_oa),
+ * boa fp32 [n_oa]; n_oa = 8 heads * levels * 4 points * 3 (a multiple of 32, <= 512).  e1 is rounded to T exactly where the
+ * separate launches store it; e1 + qpos is formed as moy_gemm forms its A2 operand.  MOY_ENOSYS for fp32 (moy_gemm x 2). */
+typedef struct moy_decoder_mid_args {
+  const void* attn; int64_t ld_attn;   /* T [M, 256]: self-attention output before out_proj */
+  const void* x;    int64_t ld_x;      /* T [M, 256]: the layer input (residual) */
+  const void* qpos; int64_t ld_qpos;   /* T [M, 256]: query position embedding */
+  int32_t M;
+  const void* Wo; const float* bo; const float* ln_g; const float* ln_b;
+  const void* Woa; const float* boa; int32_t n_oa;
+  void* e1; int64_t ld_e1;             /* out: T [M, 256] */
+  float* offaw; int64_t ld_oa;         /* out: fp32 [M, n_oa] */
+  int32_t dtype;
+} moy_decoder_mid_args;
+
+int moy_decoder_mid(const moy_decoder_mid_args* args, void* stream);
+
 /* Query selection: per frame b, indices of the nq largest max_c scores[b, s, c], sorted
  * descending (torch.topk(enc_outputs_scores.max(-1).values, nq), head.py:1048).  Ties: lower
  * token index first.  scores fp32 [B, S, nc].  valid (optional) uint8 [S]: n_masked[b] receives

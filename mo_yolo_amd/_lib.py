@@ -44,6 +44,15 @@ class DecoderTailArgs(C.Structure):
     ]
 
 
+class DecoderMidArgs(C.Structure):
+    """Mirror of `moy_decoder_mid_args` (include/moyolo.h)."""
+    _fields_ = [
+        ("attn", vp), ("ld_attn", i64), ("x", vp), ("ld_x", i64), ("qpos", vp), ("ld_qpos", i64), ("M", i32),
+        ("Wo", vp), ("bo", vp), ("ln_g", vp), ("ln_b", vp), ("Woa", vp), ("boa", vp), ("n_oa", i32),
+        ("e1", vp), ("ld_e1", i64), ("offaw", vp), ("ld_oa", i64), ("dtype", i32),
+    ]
+
+
 class C2fArgs(C.Structure):
     """Mirror of `moy_c2f_args` (include/moyolo.h)."""
     _fields_ = [
@@ -70,6 +79,7 @@ SIGNATURES = {
     "moy_rowdot": (C.c_int, [vp, i64, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]),
     "moy_mlp_head": (C.c_int, [vp, i64, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp]),
     "moy_decoder_tail": (C.c_int, [C.POINTER(DecoderTailArgs), vp]),
+    "moy_decoder_mid": (C.c_int, [C.POINTER(DecoderMidArgs), vp]),
     "moy_topk": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "moy_pos2posemb": (C.c_int, [vp, C.c_int, vp, i64, C.c_int, vp]),
     "moy_mha_core": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, vp]),

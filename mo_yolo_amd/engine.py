@@ -577,11 +577,28 @@ class TrackEngine:
                 self._add(lib.moy_mha_core, qkv.ptr, qkv.ld, B, nq, arch.nh, hd, attn.ptr, attn.ld, code,
                           meta=dict(name=f"mha_core B{B} L{nq}", bytes=4 * M * hd * self._esz, flops=4 * B * nq * nq * hd))
             Wo, bo = self._linear_w(q + ".self_attn.out_proj")
-            self._gemm(attn, Wo, hd, hd, e1, M, shift=bo, R=x, ln=self._ln(q + ".norm1"))
             Woa = torch.cat([sd[q + ".cross_attn.sampling_offsets.weight"], sd[q + ".cross_attn.attention_weights.weight"]], 0)
             boa = torch.cat([sd[q + ".cross_attn.sampling_offsets.bias"], sd[q + ".cross_attn.attention_weights.bias"]], 0)
-            Woa_d, boa_d = self._linear_w_raw(Woa, boa)
-            self._gemm(e1, Woa_d, Woa.shape[0], hd, View(offaw), M, shift=boa_d, A2=qpos, out_f32=True)
+            n_oa = Woa.shape[0]
+            if self.dtype != torch.float32 and n_oa % 32 == 0 and n_oa <= 512 and os.environ.get("MOY_DEC_MID", "1") != "0":
+                # out_proj + norm1 and the offsets | weights linear of (e1 + query_pos) as ONE launch (csrc/dec_mid.hip)
+                Wpad = torch.zeros(max(256, n_oa), hd)
+                Wpad[:n_oa] = Woa
+                Woa_d, boa_d = self._weight(Wpad), self._dev(boa)
+                ln1 = self._ln(q + ".norm1")
+                t = L.DecoderMidArgs()
+                t.attn, t.ld_attn, t.x, t.ld_x, t.qpos, t.ld_qpos, t.M = attn.ptr, attn.ld, x.ptr, x.ld, qpos.ptr, qpos.ld, M
+                t.Wo, t.bo, t.ln_g, t.ln_b = Wo.data_ptr(), bo.data_ptr(), ln1[0].data_ptr(), ln1[1].data_ptr()
+                t.Woa, t.boa, t.n_oa = Woa_d.data_ptr(), boa_d.data_ptr(), n_oa
+                t.e1, t.ld_e1, t.offaw, t.ld_oa, t.dtype = e1.ptr, e1.ld, offaw.data_ptr(), offaw.shape[1], code
+                self._keep.append(t)
+                self._add(lib.moy_decoder_mid, C.byref(t),
+                          meta=dict(name=f"decoder_mid M{M}", bytes=4 * M * hd * 2 + M * n_oa * 4 + (hd + n_oa) * hd * 2,
+                                    flops=2 * M * hd * (hd + n_oa)))
+            else:
+                self._gemm(attn, Wo, hd, hd, e1, M, shift=bo, R=x, ln=self._ln(q + ".norm1"))
+                Woa_d, boa_d = self._linear_w_raw(Woa, boa)
+                self._gemm(e1, Woa_d, n_oa, hd, View(offaw), M, shift=boa_d, A2=qpos, out_f32=True)
             vslice, vhs = value[i]
             # gather: SURVEY §8(d) charges min(value slice of the layer, taps x 64 B); the taps of a launch fall on the same cells
             # (one cell = one token of one head = 32 channels) again and again, so what has to MOVE is the expected number of

@@ -242,6 +242,22 @@ def decoder_tail(samp, e1, Wp, bp, ln2, W1, b1, W2, b2, ln3, B0, c0, B1, c1, w2,
     return out, ref_out
 
 
+def decoder_mid(attn, x, qpos, Wo, bo, ln1, Woa, boa, n_oa):
+    """See moy_decoder_mid.  attn / x / qpos [M, 256] 16-bit; Wo [256, 256], Woa [max(256, n_oa), 256] in that dtype (zero rows past
+    n_oa); vectors fp32.  Returns (e1 [M, 256], offaw fp32 [M, n_oa])."""
+    _need_gpu(attn, x, qpos)
+    M = attn.shape[0]
+    e1 = torch.empty(M, 256, device=attn.device, dtype=attn.dtype)
+    offaw = torch.empty(M, n_oa, device=attn.device, dtype=torch.float32)
+    t = L.DecoderMidArgs()
+    t.attn, t.ld_attn, t.x, t.ld_x, t.qpos, t.ld_qpos, t.M = attn.data_ptr(), _ld(attn), x.data_ptr(), _ld(x), qpos.data_ptr(), _ld(qpos), M
+    t.Wo, t.bo, t.ln_g, t.ln_b = Wo.data_ptr(), bo.data_ptr(), ln1[0].data_ptr(), ln1[1].data_ptr()
+    t.Woa, t.boa, t.n_oa = Woa.data_ptr(), boa.data_ptr(), n_oa
+    t.e1, t.ld_e1, t.offaw, t.ld_oa, t.dtype = e1.data_ptr(), 256, offaw.data_ptr(), n_oa, _code(attn)
+    L.check(L.lib().moy_decoder_mid(C.byref(t), _st()), "moy_decoder_mid")
+    return e1, offaw
+
+
 def topk(scores, nq, valid=None):
     """scores fp32 [B, S, nc] -> (idx_local int32 [B, nq], idx_global, n_masked int32 [B])."""
     _need_gpu(scores)

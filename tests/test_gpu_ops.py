@@ -530,6 +530,42 @@ def test_decoder_tail_one_launch_equals_separate(dt, M, dffn):
     assert torch.allclose(ref_out.cpu(), r_box, atol=tol(dt, 1e-5, 2e-2))
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,n_oa", [(300 * 3 + 7, 288), (128, 288), (1000, 384), (513, 192), (200, 96)])
+def test_decoder_mid_one_launch_equals_separate(dt, M, n_oa):
+    """moy_decoder_mid (out_proj + norm1, then sampling_offsets | attention_weights of e1 + query_pos, in one launch) vs the two
+    moy_gemm launches it replaces and vs the torch fp32 chain with the same rounding points (transformer.py:640-646, :262-266);
+    n_oa = 8 heads x levels x 4 points x 3 for 3 / 4 / 2 / 1 levels (the remainder columns past 256 take the row-split product)."""
+    g = lambda *s_, seed, scale=1.0: rnd(*s_, seed=seed, scale=scale)
+    attn, x, qpos = q(g(M, 256, seed=1), dt), q(g(M, 256, seed=2), dt), q(g(M, 256, seed=3), dt)
+    Wo, Woa = q(g(256, 256, seed=4, scale=1 / 16), dt), q(g(n_oa, 256, seed=5, scale=1 / 16), dt)
+    bo, boa = g(256, seed=6, scale=0.1), g(n_oa, seed=7, scale=0.5)
+    g1, be1 = g(256, seed=8) * 0.2 + 1, g(256, seed=9, scale=0.1)
+    d = lambda t: t.to(DEV)
+    pw = lambda w: ops.pad_weight(w.to(DEV), dt)
+    ad, xd, qd = attn.to(DEV, dt), x.to(DEV, dt), qpos.to(DEV, dt)
+    Wpad = torch.zeros(max(256, n_oa), 256)
+    Wpad[:n_oa] = Woa
+    e1, offaw = ops.decoder_mid(ad, xd, qd, pw(Wo), d(bo), (d(g1), d(be1)), pw(Wpad), d(boa), n_oa)
+    # separate launches (the fp32 engines' path)
+    e1s = ops.gemm(ad, pw(Wo), 256, 256, shift=d(bo), R=xd, ln=(d(g1), d(be1)))
+    oas = ops.gemm(e1s, pw(Woa), n_oa, 256, shift=d(boa), A2=qd, out_f32=True)
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    diff = (e1.float() - e1s.float()).abs()
+    # a handful of elements may land on the other side of a rounding boundary (one-pass vs two-pass LayerNorm statistics)
+    assert float(diff.max()) <= 4 * ulp * float(e1s.float().abs().max()) and float((diff > 0).float().mean()) < 0.02
+    assert torch.allclose(offaw, oas, atol=tol(dt, 1e-5, 3e-2 if dt == torch.bfloat16 else 4e-3))
+    # the offsets / weights of the rows whose e1 agrees bit for bit agree to fp32 summation order
+    same = (diff.max(1).values == 0)
+    assert float(same.float().mean()) > 0.2
+    assert torch.allclose(offaw[same], oas[same], atol=2e-5, rtol=1e-5)
+    # torch fp32 chain with the storage-type rounding points
+    r_e1 = q(F.layer_norm(attn @ Wo.T + bo + x, (256,), g1, be1, 1e-5), dt)
+    assert torch.allclose(e1.float().cpu(), r_e1, atol=tol(dt, 1e-5, 4e-2))
+    r_oa = q(r_e1 + qpos, dt) @ Woa.T + boa
+    assert torch.allclose(offaw.cpu(), r_oa, atol=tol(dt, 1e-5, 6e-2))
+
+
 @pytest.mark.parametrize("B,S,nc,nq", [(1, 13566, 1, 300), (3, 315, 1, 50), (2, 126, 3, 20), (1, 42840, 1, 500), (2, 1000, 2, 1000)])
 def test_topk_matches_torch_and_flags_masked(B, S, nc, nq):
     sc = rnd(B, S, nc, seed=B + S)
