@@ -126,6 +126,15 @@ typedef struct moy_gemm_args {
    * value_proj outputs of the decoder layers: a layer's slice is then dense in HBM for the deformable gather). */
   int32_t plane_cols;
   int64_t plane_stride;
+  /* optional ROW RUNS (run_levels = 0: off; only with the narrow head and C == NULL, i.e. the score pass; no a_mask; 16-bit):
+   * the launch visits only the rows
+   *     b * run_period + run_tok0[l] + y * run_pitch[l] + x      b < M / run_period, l < run_levels, y < run_rows[l], x < run_len[l]
+   * -- per batch element one rectangle of every pyramid level: the tokens whose anchors are VALID (`_generate_anchors`,
+   * nn/modules/head.py:1007).  A masked token's feature is LN(enc_output.bias) whatever the frame shows (head.py:1039), so its
+   * score is a constant that the caller writes once; at 1088x608 that is 46 % of the rows.  Rows outside the runs are
+   * neither read nor written.  MOY_ENOSYS when the shape does not take the weight-stationary score kernel. */
+  int32_t run_levels, run_period;
+  int32_t run_tok0[4], run_pitch[4], run_len[4], run_rows[4];
 } moy_gemm_args;
 
 int moy_gemm(const moy_gemm_args* args, void* stream);

@@ -29,6 +29,7 @@ class GemmArgs(C.Structure):
         ("dot_w", vp), ("dot_b", vp), ("dot_out", vp), ("dot_n", i32),
         ("pre", vp), ("ld_pre", i64), ("pre_h", i32), ("pre_w", i32), ("a2_cols", i32),
         ("plane_cols", i32), ("plane_stride", i64),
+        ("run_levels", i32), ("run_period", i32), ("run_tok0", i32 * 4), ("run_pitch", i32 * 4), ("run_len", i32 * 4), ("run_rows", i32 * 4),
     ]
 
 

@@ -1008,6 +1008,7 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
     const int rc = gemm_wreg_try(a, st);
     if (rc != MOY_ENOSYS) return rc;
   }
+  if (a->run_levels) return MOY_ENOSYS;      // row runs exist in the weight-stationary score kernel only: the caller falls back to a_mask
   if (a->ksize == 3 && a->dtype != MOY_F32 && !ln) {
     const int rc = conv_ws_try(a, st);
     if (rc != MOY_ENOSYS) return rc;

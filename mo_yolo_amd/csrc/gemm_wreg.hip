@@ -42,6 +42,11 @@ struct WregParams {   // ngroups = N / (columns per block)
   int ngroups;   // N / 256
   int lanes;     // row-tile sequences per XCD
   int ntiles;    // ceil(M / BM)
+  // score mode with ROW RUNS (moy_gemm_args.run_*, round 3): only the rows b * run_period + tok0[l] + y * pitch[l] + x are visited
+  // (compact row c -> b = c / run_nv, v = c % run_nv -> level l by the compact starts -> (y, x) by the run length)
+  int run_levels, run_period, run_nv, run_mv;          // run_mv = (M / run_period) * run_nv compact rows
+  int run_cstart[4], run_len[4], run_tok0[4], run_pitch[4];
+  FastDiv fd_nv, fd_len[4];
   // score mode (LN = true): LayerNorm statistics + the narrow head of the normalised row, nothing else is written
   const float* ln_g;
   const float* ln_b;
@@ -182,8 +187,33 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
     dcol[jj] = (uint32_t)(((X % CPR) ^ (drow[jj] & 15)) * 16);
   }
   const uint32_t row_bytes = (uint32_t)(p.lda * 2);
+  // compact row -> row of A (score mode with row runs): arithmetic only -- a table lookup from global memory would put
+  // compiler-visible loads into the vector-memory queue that the counted waits of the DMA ring bookkeep by hand
+  auto run_row = [&](int c) {
+    const int b = (int)fdiv((uint32_t)c, p.fd_nv);
+    const int v = c - b * p.run_nv;
+    int cs = 0, len = p.run_len[0], tok0 = p.run_tok0[0], pitch = p.run_pitch[0];
+    uint32_t mg = p.fd_len[0].magic, shf = p.fd_len[0].shift;
+#pragma unroll
+    for (int l = 1; l < 4; ++l) {
+      const bool in = l < p.run_levels && v >= p.run_cstart[l];
+      cs = in ? p.run_cstart[l] : cs; len = in ? p.run_len[l] : len; tok0 = in ? p.run_tok0[l] : tok0; pitch = in ? p.run_pitch[l] : pitch;
+      mg = in ? p.fd_len[l].magic : mg; shf = in ? p.fd_len[l].shift : shf;
+    }
+    const uint32_t vv = (uint32_t)(v - cs);
+    const uint32_t y = (uint32_t)(((uint64_t)__umulhi(vv, mg) + vv) >> shf);
+    return b * p.run_period + tok0 + (int)y * pitch + (int)(vv - y * (uint32_t)len);
+  };
   auto issue_tile = [&](int tile, int buf) {
     const int m0 = min(tile, p.ntiles - 1) * BM;                   // over-fetch tiles past the end re-read the last one
+    if (LN && p.run_levels) {
+#pragma unroll
+      for (int jj = 0; jj < IPW; ++jj) {
+        const int row = run_row(min(m0 + drow[jj], p.run_mv - 1));
+        glds16(Ab, (uint32_t)row * row_bytes + dcol[jj], lds_w + buf * TILE_BYTES + jj * 1024);   // (M * lda * 2 < 4 GiB: checked by the host)
+      }
+      return;
+    }
     const unsigned char* tb = Ab + (int64_t)m0 * p.lda * 2;
     const int last = p.M - 1 - m0;                                 // last valid row of this tile (>= BM-1 except in the tail)
 #pragma unroll
@@ -315,7 +345,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
         const float rstd = 1.0f / sqrtf(var + 1e-5f);
         const int64_t nbytes = (int64_t)p.M * p.dot_n * 4;
         const auto rsD = __builtin_amdgcn_make_buffer_rsrc(p.dot_out, 0, (uint32_t)(nbytes < 0x7fffffffLL ? nbytes : 0x7fffffffLL), 0x00020000);
-        const uint32_t off = lane < BM ? (uint32_t)((m0 + row) * p.dot_n) * 4u : 0x80000000u;   // rows >= M: out of range, dropped
+        uint32_t off = lane < BM ? (uint32_t)((m0 + row) * p.dot_n) * 4u : 0x80000000u;   // rows >= M: out of range, dropped
+        if (p.run_levels) off = (lane < BM && m0 + row < p.run_mv) ? (uint32_t)(run_row(m0 + row) * p.dot_n) * 4u : 0x80000000u;
 #pragma unroll
         for (int c = 0; c < WREG_MAXDOT; ++c)
           if (c < p.dot_n) {
@@ -428,7 +459,7 @@ static int launch_wreg(WregParams& p, hipStream_t st) {
     attr_lds = lds;
   }
   const int slots = wreg_num_cus() / 8 * OCC;          // resident blocks per XCD
-  p.ntiles = (p.M + BM - 1) / BM;
+  p.ntiles = ((p.run_levels ? p.run_mv : p.M) + BM - 1) / BM;
   p.ngroups = p.N / (NW * WC);
   p.lanes = slots / p.ngroups;
   if (p.lanes < 1) return MOY_ENOSYS;
@@ -476,7 +507,14 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   if (score) {
     if (a->K != 256 || a->N != 256 || a->dot_n < 1 || a->dot_n > WREG_MAXDOT || a->act != MOY_ACT_NONE || a->c_rows_per_batch) return MOY_ENOSYS;
     if (a->a_mask && (a->mask_period < 64 || a->mask_period > 262144)) return MOY_ENOSYS;
-  } else if (a->ln_g || a->a_mask || a->dot_n || !a->C) {
+    if (a->run_levels) {
+      if (a->a_mask || a->run_levels > 4 || a->run_period <= 0 || (a->M % a->run_period) || (int64_t)a->M * a->lda * 2 > 0xffffffffLL) return MOY_ENOSYS;
+      for (int l = 0; l < a->run_levels; ++l)
+        if (a->run_len[l] <= 0 || a->run_rows[l] <= 0 || a->run_pitch[l] < a->run_len[l] || a->run_tok0[l] < 0 ||
+            a->run_tok0[l] + (a->run_rows[l] - 1) * a->run_pitch[l] + a->run_len[l] > a->run_period)
+          return MOY_EINVAL;
+    }
+  } else if (a->ln_g || a->a_mask || a->dot_n || !a->C || a->run_levels) {
     return MOY_ENOSYS;
   }
   static int kgen = -1;                    // MOY_WREG_KGEN=0: only the K = 256 forms (A/B runs)
@@ -502,6 +540,19 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   if (score) {
     p.ln_g = a->ln_g; p.ln_b = a->ln_b; p.dot_w = a->dot_w; p.dot_b = a->dot_b; p.dot_out = a->dot_out; p.dot_n = a->dot_n;
     p.a_mask = a->a_mask; p.mask_period = a->mask_period; p.fd_mask = make_fastdiv(a->mask_period > 0 ? a->mask_period : 1);
+    p.run_levels = a->run_levels;
+    if (a->run_levels) {
+      p.run_period = a->run_period;
+      int nv = 0;
+      for (int l = 0; l < 4; ++l) {
+        const bool on = l < a->run_levels;
+        p.run_cstart[l] = nv; p.run_len[l] = on ? a->run_len[l] : 1; p.run_tok0[l] = on ? a->run_tok0[l] : 0; p.run_pitch[l] = on ? a->run_pitch[l] : 1;
+        p.fd_len[l] = make_fastdiv((uint32_t)p.run_len[l]);
+        if (on) nv += a->run_len[l] * a->run_rows[l];
+      }
+      p.run_nv = nv; p.fd_nv = make_fastdiv((uint32_t)nv);
+      p.run_mv = (a->M / a->run_period) * nv;
+    }
     return a->dtype == MOY_BF16 ? launch_wreg<bf16_t, 32, 3, 2, true>(p, st) : launch_wreg<f16_t, 32, 3, 2, true>(p, st);
   }
   static int variant = -1;

@@ -44,7 +44,12 @@ def test_gemm_args_layout_matches_header():
             names += [r.strip().lstrip("*") for r in rest]
         else:
             names.append(first)
-    assert names == [f[0] for f in _lib.GemmArgs._fields_]
+    # arrays: `int32_t run_tok0[4]` in the header <-> ("run_tok0", c_int32 * 4) in the mirror
+    want = []
+    for f in _lib.GemmArgs._fields_:
+        n_el = getattr(f[1], "_length_", None)
+        want.append(f"{f[0]}[{n_el}]" if n_el else f[0])
+    assert names == want
 
 
 def test_version_and_errors_no_gpu_needed():
