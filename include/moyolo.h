@@ -242,6 +242,10 @@ typedef struct moy_decoder_tail_args {
   const void* B0; const float* c0; const void* B1; const float* c1; const float* w2; const float* c2;
   const float* ref_in; float* ref_out; /* fp32 [M, 4] */
   int32_t dtype;
+  /* optional (round 3; NULL = off): out_xp = out + qpos, T [M, 256] -- the q = k operand of the next layer's self-attention
+   * (with_pos_embed, transformer.py:637-638), element pairs added in fp32 and rounded once, as moy_gemm forms A + A2 */
+  const void* qpos; int64_t ld_qpos;
+  void* out_xp; int64_t ld_xp;
 } moy_decoder_tail_args;
 
 int moy_decoder_tail(const moy_decoder_tail_args* args, void* stream);

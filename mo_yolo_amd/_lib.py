@@ -42,6 +42,7 @@ class DecoderTailArgs(C.Structure):
         ("ln3_g", vp), ("ln3_b", vp), ("out", vp), ("ld_out", i64),
         ("B0", vp), ("c0", vp), ("B1", vp), ("c1", vp), ("w2", vp), ("c2", vp),
         ("ref_in", vp), ("ref_out", vp), ("dtype", i32),
+        ("qpos", vp), ("ld_qpos", i64), ("out_xp", vp), ("ld_xp", i64),
     ]
 
 

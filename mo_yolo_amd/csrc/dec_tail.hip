@@ -228,12 +228,26 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
   __syncthreads();
   {
     T* Og = static_cast<T*>(p.out);
+    // round 3: optionally also out + query_pos (the q = k operand of the NEXT layer's self-attention, transformer.py:637-638),
+    // formed as moy_gemm forms its A2 operand: the next layer's q | k projection is then a plain GEMM over it
+    T* Xg = static_cast<T*>(p.out_xp);
+    const T* Qg = static_cast<const T*>(p.qpos);
 #pragma unroll
     for (int k = 0; k < BM * 32 / NTHR; ++k) {
       const int id = tid + k * NTHR, row = id >> 5, c = id & 31;
-      if (m0 + row < p.M)
-        *reinterpret_cast<u32x4*>(Og + (int64_t)(m0 + row) * p.ld_out + c * 8) =
-            *reinterpret_cast<const u32x4*>(XA + row * 512 + ((c ^ (row & 15)) << 4));
+      if (m0 + row < p.M) {
+        const u32x4 e = *reinterpret_cast<const u32x4*>(XA + row * 512 + ((c ^ (row & 15)) << 4));
+        *reinterpret_cast<u32x4*>(Og + (int64_t)(m0 + row) * p.ld_out + c * 8) = e;
+        if (Xg) {
+          const u32x4 qv = *reinterpret_cast<const u32x4*>(Qg + (int64_t)(m0 + row) * p.ld_qpos + c * 8);
+          u32x4 sx;
+          sx.x = DT<T>::pack2(DT<T>::lo(e.x) + DT<T>::lo(qv.x), DT<T>::hi(e.x) + DT<T>::hi(qv.x));
+          sx.y = DT<T>::pack2(DT<T>::lo(e.y) + DT<T>::lo(qv.y), DT<T>::hi(e.y) + DT<T>::hi(qv.y));
+          sx.z = DT<T>::pack2(DT<T>::lo(e.z) + DT<T>::lo(qv.z), DT<T>::hi(e.z) + DT<T>::hi(qv.z));
+          sx.w = DT<T>::pack2(DT<T>::lo(e.w) + DT<T>::lo(qv.w), DT<T>::hi(e.w) + DT<T>::hi(qv.w));
+          *reinterpret_cast<u32x4*>(Xg + (int64_t)(m0 + row) * p.ld_xp + c * 8) = sx;
+        }
+      }
     }
   }
 
@@ -312,6 +326,8 @@ extern "C" int moy_decoder_tail(const moy_decoder_tail_args* a, void* stream) {
   if (a->M <= 0 || a->d_ffn <= 0 || (a->d_ffn % 256)) return MOY_EINVAL;
   if (a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_ENOSYS;   // fp32: the separate launches (the parity path)
   if ((a->ld_samp % 8) || (a->ld_e1 % 4) || (a->ld_out % 8) || a->ld_samp < 256 || a->ld_e1 < 256 || a->ld_out < 256) return MOY_EINVAL;
+  if (a->out_xp && (!a->qpos || (a->ld_xp % 8) || (a->ld_qpos % 8) || a->ld_xp < 256 || a->ld_qpos < 256 || !aligned16(a->out_xp) || !aligned16(a->qpos)))
+    return MOY_EINVAL;
   if (!aligned16(a->samp) || !aligned16(a->out) || !aligned16(a->Wp) || !aligned16(a->W1) || !aligned16(a->W2) || !aligned16(a->B0) ||
       !aligned16(a->B1) || !aligned16(a->w2) || !aligned16(a->bp) || !aligned16(a->b1) || !aligned16(a->b2) || !aligned16(a->c0) ||
       !aligned16(a->c1) || !aligned16(a->ln2_g) || !aligned16(a->ln2_b) || !aligned16(a->ln3_g) || !aligned16(a->ln3_b) ||

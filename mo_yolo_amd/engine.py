@@ -565,12 +565,26 @@ class TrackEngine:
         self.layer_out = []
         cur, nxt = 0, 1
         ecur, enxt = 0, 1
+        # x + query_pos of the next layer, written by the fused tail (16-bit engines): MOY_QKV_SPLIT=0 keeps the A2 form everywhere
+        use_xp = (self.dtype != torch.float32 and arch.d_ffn % 256 == 0 and os.environ.get("MOY_DEC_TAIL", "1") != "0"
+                  and os.environ.get("MOY_QKV_SPLIT", "1") != "0" and (M >= 65536 or os.environ.get("MOY_QKV_SPLIT") == "2"))
+        xp = View(self._buf(M, hd)) if use_xp else None
+        xp_ready = False
         for i in range(ndl):
             q = f"{d}.decoder.layers.{i}"
             # q | k | v in one launch: q = k = x + pos for the first 2*hd columns, v = x for the rest (transformer.py:637-640)
-            Wqkv, bqkv = self._linear_w_raw(sd[q + ".self_attn.in_proj_weight"], sd[q + ".self_attn.in_proj_bias"])
             x = embed[ecur]
-            self._gemm(x, Wqkv, 3 * hd, hd, qkv, M, shift=bqkv, A2=qpos, a2_cols=2 * hd)
+            if i > 0 and xp_ready:
+                # the previous layer's tail left x + query_pos in `xp`: q | k and v as two PLAIN products (at bench scale they take
+                # the weight-stationary kernel, which has no second A operand)
+                Wi, bi = sd[q + ".self_attn.in_proj_weight"], sd[q + ".self_attn.in_proj_bias"]
+                Wqk, bqk = self._linear_w_raw(Wi[:2 * hd], bi[:2 * hd])
+                Wv_, bv_ = self._linear_w_raw(Wi[2 * hd:], bi[2 * hd:])
+                self._gemm(xp, Wqk, 2 * hd, hd, qkv.slice(0, 2 * hd), M, shift=bqk)
+                self._gemm(x, Wv_, hd, hd, qkv.slice(2 * hd, hd), M, shift=bv_)
+            else:
+                Wqkv, bqkv = self._linear_w_raw(sd[q + ".self_attn.in_proj_weight"], sd[q + ".self_attn.in_proj_bias"])
+                self._gemm(x, Wqkv, 3 * hd, hd, qkv, M, shift=bqkv, A2=qpos, a2_cols=2 * hd)
             if n_max:   # keys: live track slots + this frame's detect queries
                 self._add(lib.moy_mha_core_masked, qkv.ptr, qkv.ld, B, Lq, arch.nh, hd, self.trk["n"].data_ptr(), n_max, attn.ptr,
                           attn.ld, code, meta=dict(name=f"mha_core B{B} L{Lq}", bytes=4 * M * hd * self._esz, flops=4 * B * Lq * Lq * hd))
@@ -631,6 +645,9 @@ class TrackEngine:
                 t.B0, t.c0, t.B1, t.c1, t.w2, t.c2 = (B0.data_ptr(), c0.data_ptr(), B1.data_ptr(), c1.data_ptr(), w2h.data_ptr(),
                                                       c2.data_ptr())
                 t.ref_in, t.ref_out, t.dtype = refs[cur].data_ptr(), refs[nxt].data_ptr(), code
+                if use_xp and i + 1 < ndl:
+                    t.qpos, t.ld_qpos, t.out_xp, t.ld_xp = qpos.ptr, qpos.ld, xp.ptr, xp.ld
+                    xp_ready = True
                 self._keep.append(t)
                 wb = (3 * hd * hd + 2 * hd * arch.d_ffn) * 2
                 self._add(lib.moy_decoder_tail, C.byref(t),

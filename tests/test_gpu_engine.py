@@ -290,6 +290,35 @@ def test_engine_16bit_within_the_budget_of_the_arithmetic_type(name, dt):
         assert st["births_flipped"] == 0, st
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_decoder_plan_variants_are_bit_identical(dt, monkeypatch):
+    """Round-3 plan changes that must not change a bit of the outputs.  (i) q | k and v as two plain products over the
+    `x + query_pos` the previous layer's tail wrote (`MOY_QKV_SPLIT`; at bench scale they take the weight-stationary kernel) instead
+    of one product with a second A operand, on the tiny fixture (forced: 2).  (ii) the score pass over the valid tokens only
+    (`MOY_SCORE_RUNS`) at the C2 shape with enough rows for the weight-stationary score kernel (B x S >= 65 536)."""
+    def run(name, B, env):
+        cfg, arch, sd = fixture(name)
+        fr = torch.from_numpy(frames_u8(cfg, 0, B)).to(DEV)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt)
+        out = {k: v.clone() for k, v in eng.forward(fr).items()}
+        torch.cuda.synchronize()
+        return out, [m["name"] for m in eng.meta], arch
+    keys = ("topk_ind", "logits", "boxes", "hs", "obj_idxes", "y", "rows")
+    a, na, arch = run("tiny", 3, {"MOY_QKV_SPLIT": "0"})
+    b, nb, _ = run("tiny", 3, {"MOY_QKV_SPLIT": "2"})
+    assert len(nb) == len(na) + (arch.ndl - 1), (len(na), len(nb))                  # one more launch per layer after the first
+    for k in keys:
+        assert torch.equal(a[k], b[k]), ("qkv split", k)
+    monkeypatch.delenv("MOY_QKV_SPLIT")
+    c, nc_, _ = run("c2", 5, {"MOY_SCORE_RUNS": "0"})
+    d, nd, _ = run("c2", 5, {"MOY_SCORE_RUNS": "1"})
+    assert not any("valid-runs" in n for n in nc_) and sum("valid-runs 7317/13566" in n for n in nd) == 1, nd
+    for k in keys:
+        assert torch.equal(c[k], d[k]), ("score runs", k)
+
+
 def test_engine_graph_replay_matches_eager():
     cfg, arch, sd = fixture("tiny")
     B = 2
