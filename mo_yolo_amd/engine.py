@@ -565,9 +565,10 @@ class TrackEngine:
         self.layer_out = []
         cur, nxt = 0, 1
         ecur, enxt = 0, 1
-        # x + query_pos of the next layer, written by the fused tail (16-bit engines): MOY_QKV_SPLIT=0 keeps the A2 form everywhere
+        # x + query_pos of the next layer, written by the fused tail (16-bit engines).  OFF by default (MOY_QKV_SPLIT=1 switches it on, 2
+        # forces it at any size): measured -0.2 ms on the sum of a pass's kernels and +-0 on the two-stream step (three interleaved pairs)
         use_xp = (self.dtype != torch.float32 and arch.d_ffn % 256 == 0 and os.environ.get("MOY_DEC_TAIL", "1") != "0"
-                  and os.environ.get("MOY_QKV_SPLIT", "1") != "0" and (M >= 65536 or os.environ.get("MOY_QKV_SPLIT") == "2"))
+                  and os.environ.get("MOY_QKV_SPLIT", "0") != "0" and (M >= 65536 or os.environ.get("MOY_QKV_SPLIT") == "2"))
         xp = View(self._buf(M, hd)) if use_xp else None
         xp_ready = False
         for i in range(ndl):

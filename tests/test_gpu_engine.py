@@ -311,7 +311,7 @@ def test_decoder_plan_variants_are_bit_identical(dt, monkeypatch):
     assert len(nb) == len(na) + (arch.ndl - 1), (len(na), len(nb))                  # one more launch per layer after the first
     for k in keys:
         assert torch.equal(a[k], b[k]), ("qkv split", k)
-    monkeypatch.delenv("MOY_QKV_SPLIT")
+    monkeypatch.setenv("MOY_QKV_SPLIT", "0")
     c, nc_, _ = run("c2", 5, {"MOY_SCORE_RUNS": "0"})
     d, nd, _ = run("c2", 5, {"MOY_SCORE_RUNS": "1"})
     assert not any("valid-runs" in n for n in nc_) and sum("valid-runs 7317/13566" in n for n in nd) == 1, nd
