@@ -36,6 +36,7 @@ struct ConvWsParams {
   int tiles_x, tiles_img, ntiles;
   int per_xcd, bpx;                 // tiles per XCD chunk, blocks per XCD
   FastDiv fd_timg, fd_tx;
+  int prio;                         // ping-pong form: raise the wave priority during its MFMA halves (MOY_CWS_PRIO, default 1)
 };
 
 template <int C>
@@ -653,6 +654,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_pp_kernel(const ConvWsParams p
   const int r = lane & 15, q = lane >> 4;
   const int wn = wave % WN, wm = wave / WN;
   const bool grpA = wave < 4;
+  const bool PRIO = p.prio != 0;
 
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int t_first = xcd * p.per_xcd + slot;
@@ -770,19 +772,29 @@ __global__ __launch_bounds__(512, 2) void conv_ws_pp_kernel(const ConvWsParams p
     };
     u32x4 a[2][RG + 2];
     rd(std::integral_constant<int, 0>{}, a[0]);
+    // The partner wave of this SIMD is in its vector phase: with equal priority the arbiter hands it the issue port by age and the
+    // MFMAs of this wave go out at HALF rate (stamps: 4 400 cycles for the 144 MFMAs of a half).  Raised priority for the matrix
+    // phase: an MFMA issues whenever the pipe is free, the partner's vector work fills the 8 cycles in 16 that an MFMA leaves.
+    if (PRIO) __builtin_amdgcn_s_setprio(2);
     [&]<int... GI>(std::integer_sequence<int, GI...>) {
       ([&] {
         constexpr int kx = GI / KC, cc = GI % KC;
         if constexpr (GI + 1 < 3 * KC) rd(std::integral_constant<int, GI + 1>{}, a[(GI + 1) & 1]);
+        // (pinning this order with sched_barriers and keeping A[] opaque was measured: 35 spilled VGPRs at C = 128, 302 us instead of 237)
         if (ABL == 3 && GI > 0) return;
+        // ky OUTSIDE the rows: consecutive MFMAs go to DIFFERENT accumulators.  A lone wave that issues three dependent MFMAs in
+        // a row (rows outside, as the lock-step kernel orders them -- there the partner's MFMAs fall in between) gets one MFMA per
+        // 32 cycles instead of 16 (stamps: 4 300 cycles for the 144 MFMAs of a half).  Every accumulator still sees its taps in the
+        // same order: results unchanged.
 #pragma unroll
-        for (int y = 0; y < RG; ++y)
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-          for (int ky = 0; ky < 3; ++ky)
+          for (int y = 0; y < RG; ++y)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[y][j] = cws_mfma<T>(acc[y][j], wf[j][ky * 3 + kx][cc], a[GI & 1][y + ky]);
       }(), ...);
     }(std::make_integer_sequence<int, 3 * KC>{});
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
   };
   // group A's store pass over store set h (the half-h rows of every wave): thread ta = tid (0..255), chunk X = k * 256 + ta
   auto store_set = [&](const Tile& t, const unsigned char* stg, int h, bool valid) {
@@ -831,6 +843,20 @@ __global__ __launch_bounds__(512, 2) void conv_ws_pp_kernel(const ConvWsParams p
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   Tile prev = tile_of(0);
+  // ABL == 5: diagnostic build, s_memtime stamps of wave 0 (group A) and wave 4 (group B): cycles of WORK in each of the four
+  // intervals (up to its barrier) and cycles spent AT the four barriers; sums over the block's tiles go to the start of the output
+  // tensor of block 0 (the build's outputs are garbage by design)
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+  auto stamp = [&](int i) {
+    if constexpr (ABL == 5) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      ph[i] += t - tprev;
+      tprev = t;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if constexpr (ABL == 5) tprev = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < n_mine; ++it) {
     const int set = it & 1, nset = set ^ 1;
     const Tile cur = tile_of(it), nxt = tile_of(it + 1);
@@ -845,7 +871,9 @@ __global__ __launch_bounds__(512, 2) void conv_ws_pp_kernel(const ConvWsParams p
 #pragma unroll
       for (int k = 0; k < KB; ++k) patch_piece(nxt, nset, 4 * KA + (wave - 4) + 4 * k);
     }
+    stamp(0);
     __syncthreads();
+    stamp(4);
     // ---- interval 1
     if (grpA) {
       epi_half(acc, 0, stg_cur);
@@ -855,7 +883,9 @@ __global__ __launch_bounds__(512, 2) void conv_ws_pp_kernel(const ConvWsParams p
     } else {
       half_mfma(std::integral_constant<int, 0>{}, patch_off, acc);
     }
+    stamp(1);
     __syncthreads();
+    stamp(5);
     // ---- interval 2
     if (grpA) {
       half_mfma(std::integral_constant<int, 1>{}, patch_off, acc);
@@ -866,7 +896,9 @@ __global__ __launch_bounds__(512, 2) void conv_ws_pp_kernel(const ConvWsParams p
         for (int k = 0; k < KR; ++k) res_piece(nxt, nset, (wave - 4) + 4 * k);
       }
     }
+    stamp(2);
     __syncthreads();
+    stamp(6);
     // ---- interval 3
     if (grpA) {
       epi_half(acc, 1, stg_cur);
@@ -876,8 +908,17 @@ __global__ __launch_bounds__(512, 2) void conv_ws_pp_kernel(const ConvWsParams p
       half_mfma(std::integral_constant<int, 1>{}, patch_off, acc);
       cws_wait_vmcnt<0>();                                         // this wave's patch + residual pieces of tile it+1
     }
+    stamp(3);
     __syncthreads();
+    stamp(7);
     prev = cur;
+  }
+  if constexpr (ABL == 5) {
+    if (blockIdx.x == 0 && (tid == 0 || tid == 256)) {
+      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.C) + (tid ? 16 : 0);
+      for (int i = 0; i < 8; ++i) dbg[i] = ph[i];
+      dbg[8] = (unsigned long long)n_mine;
+    }
   }
   // drain: group B's second half of the last tile, then its rows
   {
@@ -900,8 +941,14 @@ static int launch_conv_ws_pp(ConvWsParams& p, int B, hipStream_t st) {
     if (abl == 2) return launch_conv_ws_pp<T, C, N, TH, WN, RES, 2>(p, B, st);
     if (abl == 3) return launch_conv_ws_pp<T, C, N, TH, WN, RES, 3>(p, B, st);
     if (abl == 4) return launch_conv_ws_pp<T, C, N, TH, WN, RES, 4>(p, B, st);
+    if (abl == 5) return launch_conv_ws_pp<T, C, N, TH, WN, RES, 5>(p, B, st);
   }
   auto kern = conv_ws_pp_kernel<T, C, N, TH, WN, RES, ABL>;
+  {
+    static int prio = -1;
+    if (prio < 0) { const char* e = getenv("MOY_CWS_PRIO"); prio = e ? atoi(e) : 1; }
+    p.prio = prio;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     if (LDS > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)

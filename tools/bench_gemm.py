@@ -85,7 +85,13 @@ def main():
         ms = best[name]
         tot += ms
         print(f"{name:26s} M={M:8d} {ms*1e3:8.1f} us {alg/ms/1e6:7.0f} GB/s {flops/ms/1e9:7.1f} TF/s")
-        if os.environ.get("MOY_CWS_ABL") == "5":      # diagnostic build of csrc/conv_ws.hip: phase stamps of block 0, wave 0
+        if os.environ.get("MOY_CWS_ABL") == "5" and int(os.environ.get("MOY_CWS_VARIANT", "0")) & 8:   # ping-pong form: work / barrier cycles per interval, group A (wave 0) and B (wave 4)
+            d = f.out.view(torch.int64).flatten()[:32].cpu().tolist()
+            for g, o in (("A", 0), ("B", 16)):
+                n = max(d[o + 8], 1)
+                print(f"    group {g}: work per interval " + " ".join(f"{v / n:.0f}" for v in d[o:o + 4]) + " | at the barrier " +
+                      " ".join(f"{v / n:.0f}" for v in d[o + 4:o + 8]) + f"  (cycles per tile, {n} tiles)")
+        elif os.environ.get("MOY_CWS_ABL") == "5":      # diagnostic build of csrc/conv_ws.hip: phase stamps of block 0, wave 0
             d = f.out.view(torch.int64).flatten()[:8].cpu().tolist()
             n = max(d[7], 1)
             names = ["setup+dma", "mfma", "epilogue", "barrier1", "stores", "vmcnt", "barrier2"]
