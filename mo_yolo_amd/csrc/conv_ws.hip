@@ -24,6 +24,13 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef MOY_CWS_HOIST
+#define MOY_CWS_HOIST 1
+#endif
+#ifndef MOY_CWS_HOIST_128
+#define MOY_CWS_HOIST_128 0       // measured: 255 VGPRs, 247.3 vs 247.1 us -- nothing (hipcc re-derives the values anyway); 81 spills with the residual
+#endif
+
 namespace moy {
 
 struct ConvWsParams {
@@ -92,6 +99,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_ws_kernel(const ConvWsParam
   constexpr int DIST = NBUF - 1;
   constexpr int RG = MT < 4 ? MT : 4;      // output rows per fragment-row group
   constexpr uint32_t OOB = 0x80000000u;
+  // round 3: at C <= 64 the kernel has ~100 free registers, so the per-piece DMA geometry (a dozen VALU operations per piece and
+  // tile, in the phase where nothing hides them) lives in loop-invariant registers again: 270 -> 248 us at C = 64, 437 -> 413 at
+  // C = 32 (288 frames, same-device A/B of two builds); 152 -> 225-256 VGPRs, no spills
+  constexpr bool HOIST_GEOM = MOY_CWS_HOIST && (C <= 64 || (MOY_CWS_HOIST_128 && !RES));   // (C = 128 with the residual: 81 spilled VGPRs)
   static_assert(TH % WM == 0 && (N / 16) % WN == 0 && G::TPX * NCP % 512 == 0, "tile vs waves");
   static_assert(sizeof(T) == 2, "16-bit types");
 
@@ -118,7 +129,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_ws_kernel(const ConvWsParam
   auto piece_geom = [&](int pc, int& dy, int& dx, int& rel) {   // offsets relative to the tile origin; dy = -4096: never valid
     dy = -4096; dx = 0; rel = 0;
     int lv = lane;
-    asm volatile("" : "+v"(lv));   // opaque: keeps the per-piece geometry out of loop-invariant registers
+    if constexpr (!HOIST_GEOM) asm volatile("" : "+v"(lv));   // opaque: keeps the per-piece geometry out of loop-invariant registers
     if (pc < G::PATCH_PIECES) {
       const int X = pc * 64 + lv, pix = X / CPP, sl = X % CPP;
       const int py = pix / PW, px = pix - py * PW;
@@ -1038,7 +1049,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvS2Params p) {
     for (int k = 0; k < IPW; ++k) {
       const int pc = wave + 8 * k;
       int lv = lane;
-      asm volatile("" : "+v"(lv));
+      if constexpr (!MOY_CWS_HOIST) asm volatile("" : "+v"(lv));   // (round 3: the geometry may live in loop-invariant registers: 86 / 144 VGPRs were in use)
       const int X = pc * 64 + lv, pix = X / CPP, sl = X % CPP;
       const int row = pix / PW, s33 = pix - row * PW;
       const int col = s33 < 17 ? 2 * s33 : 2 * (s33 - 17) + 1;      // patch column of this de-interleaved slot
