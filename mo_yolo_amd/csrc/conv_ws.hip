@@ -27,6 +27,9 @@
 #ifndef MOY_CWS_HOIST
 #define MOY_CWS_HOIST 1
 #endif
+#ifndef MOY_CWS_PREGEOM
+#define MOY_CWS_PREGEOM 0         // measured (C = 128, 288 frames): the loop top shrinks 1 900 -> 560 cycles per tile, the kernel 244 -> 241 us at
+#endif                            // 38x68 and 96 -> 101 us at 19x34: the cycles reappear as barrier waits (the younger wave of each SIMD is the critical path)
 #ifndef MOY_CWS_HOIST_128
 #define MOY_CWS_HOIST_128 0       // measured: 255 VGPRs, 247.3 vs 247.1 us -- nothing (hipcc re-derives the values anyway); 81 spills with the residual
 #endif
@@ -196,6 +199,35 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_ws_kernel(const ConvWsParam
 #pragma unroll
     for (int k = 0; k < IPW; ++k) issue_piece(d, k);
   };
+  // PREGEOM (round 3, where HOIST_GEOM has no registers: C = 128): the lane offsets of the NEXT tile's pieces are formed in the
+  // shadow of this tile's MFMAs (the matrix pipe is the bound there, the vector slots are free) and wait in IPW registers; the loop
+  // top then only issues -- it used to spend ~20 vector operations per piece with nothing to hide them
+  constexpr bool PREGEOM = MOY_CWS_PREGEOM && !HOIST_GEOM && !SPREAD;
+  uint32_t vo[IPW];
+  auto comp_vo = [&](const TileDma& d) {
+#pragma unroll
+    for (int k = 0; k < IPW; ++k) {
+      const int pc = wave + 8 * k;
+      const bool is_res = RES && pc >= G::PATCH_PIECES;
+      int dy, dx, rel;
+      piece_geom(pc, dy, dx, rel);
+      const int yy = d.y0 + dy, xx = d.x0 + dx;
+      const bool ok = d.live && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.Wd;
+      vo[k] = ok ? (uint32_t)((is_res ? d.off_r : d.off_a) + rel) : OOB;
+      asm volatile("" : "+v"(vo[k]));      // materialised HERE (the scheduler would otherwise sink the arithmetic to its use at the loop top)
+    }
+  };
+  auto issue_pre = [&](const TileDma& d) {
+#pragma unroll
+    for (int k = 0; k < IPW; ++k) {
+      const int pc = wave + 8 * k;
+      const bool is_res = RES && pc >= G::PATCH_PIECES;
+      const uint32_t dst = pc < G::PIECES ? d.dst + pc * 1024 : scratch;
+      if (ABL == 2) continue;
+      if (is_res) cws_dma16(vo[k], d.rsR, dst);
+      else cws_dma16(vo[k], d.rsA, dst);
+    }
+  };
 
   // ---- weights of this wave -> registers (MFMA A operand: lane (r, q) holds W[n = .. + r][k = tap*C + cc*32 + q*8 .. +7])
   u32x4 wf[NT][9][KC];
@@ -245,10 +277,13 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_ws_kernel(const ConvWsParam
     }
   };
   if constexpr (ABL == 5) tprev = __builtin_amdgcn_s_memtime();
+  if constexpr (PREGEOM) comp_vo(tile_setup(DIST, 0));
   for (int it = 0; it < n_mine; ++it) {
     int nset = set + DIST; if (nset >= NBUF) nset -= NBUF;
     const TileDma nd = tile_setup(it + DIST, nset);
-    if constexpr (!SPREAD) {
+    if constexpr (PREGEOM) {
+      issue_pre(nd);
+    } else if constexpr (!SPREAD) {
 #pragma unroll
       for (int k = 0; k < IPW; ++k) issue_piece(nd, k);
     }
@@ -277,6 +312,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_ws_kernel(const ConvWsParam
               if (k * NG / IPW == gi) issue_piece(nd, k);
           }
           if (ABL == 3 && (kx | cc)) continue;
+          if constexpr (PREGEOM) {
+            if (kx == 1 && cc == 0 && g == 0) comp_vo(tile_setup(it + 1 + DIST, 0));     // (only y0 / x0 / offsets / live of the set-up are used)
+          }
           u32x4 a[RG + 2];
 #pragma unroll
           for (int y = 0; y < RG + 2; ++y) {
