@@ -121,6 +121,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_ws_kernel(const ConvWsParam
   const int t_limit = min((xcd + 1) * p.per_xcd, p.ntiles);
   if (t_first >= t_limit) return;
   const int n_mine = (t_limit - t_first + p.bpx - 1) / p.bpx;
+  // static priority for the younger wave of every SIMD (MI355X_MICROARCH.md, "two waves per SIMD", item 4): with equal priority the
+  // arbiter serves the older wave first and waves 4-7 become the critical path of every tile (MOY_CWS_PRIO bit 1, A/B knob)
+  if ((p.prio & 2) && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
   const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);
   const uint32_t scratch = lds_base + NBUF * G::SETB + (RES ? 0 : G::STGB);
@@ -1238,6 +1241,11 @@ static int launch_conv_ws(ConvWsParams& p, int B, hipStream_t st) {
     if (abl == 5) return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 5>(p, B, st);
   }
   auto kern = conv_ws_kernel<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, ABL>;
+  {
+    static int prio = -1;
+    if (prio < 0) { const char* e = getenv("MOY_CWS_PRIO"); prio = e ? atoi(e) : 1; }
+    p.prio = prio;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     if (G::LDS > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess)
