@@ -15,13 +15,15 @@
 //     conflict-free (lanes of a 16-lane group hit 16 distinct chunk slots mod 16);
 //   * MFMA operands swapped (weights = A): a lane owns 4 consecutive output channels of one row, as in gemm.hip, and the k
 //     order per accumulator is the same 8 panels of 32 -> results are bit-identical to the tiled kernel;
-//   * epilogue per WAVE (its 64 columns = one 128-B line per row): accumulators -> wave-private LDS strip in the output
-//     type -> 16-byte stores of whole lines; no block barrier, so one wave's epilogue overlaps the other waves' MFMAs;
+//   * epilogue per WAVE straight from the accumulators: the weight rows are dealt to the MFMA fragments so that a lane ends up
+//     with 8 consecutive output channels of a row -> 16-byte stores, 64 contiguous bytes per row and store instruction, no LDS
+//     round trip and no block barrier, so one wave's epilogue overlaps the other waves' MFMAs;
 //   * grid = 8 XCDs x slots; the N/256 column groups of one row-tile sequence sit on the SAME XCD and advance in lock step,
 //     so an activation tile is fetched from HBM once and hits that XCD's L2 for the other groups.
 #include "common.hpp"
 
 #include <type_traits>
+#include <utility>
 
 namespace moy {
 
@@ -88,12 +90,14 @@ __device__ __forceinline__ f32x4 mfma16<f16_t>(f32x4 acc, u32x4 w, u32x4 a) {
 constexpr int WREG_MAXDOT = 4;           // classes of the fused narrow head in score mode
 template <int BM, int NBUF, bool LN, int NW = 4, int WC = 64, int K = 256>
 constexpr int wreg_lds_bytes() {
-  // A ring | (store mode) 4 epilogue strips | scale, shift | (score mode) g*w per class, G/B constants, row partials [BM][6][16]
-  return NBUF * BM * K * 2 + (LN ? 0 : NW * BM * (WC * 2 + 8)) + NW * WC * 8 + (LN ? WREG_MAXDOT * 1024 + 64 + BM * ((2 + WREG_MAXDOT) * 64 + 16) : 0);
+  // A ring | scale, shift (score mode reads them from LDS) | (score mode) g*w per class, G/B constants, row partials [BM][6][16]
+  return NBUF * BM * K * 2 + NW * WC * 8 + (LN ? WREG_MAXDOT * 1024 + 64 + BM * ((2 + WREG_MAXDOT) * 64 + 16) : 0);
 }
 
 // WC = output columns per wave (64: K = 256 only; 32: K up to 512 fits the registers), K = reduction length (multiple of 128).
-template <typename T, int BM, int NBUF, int OCC, bool LN, int NW, int WC, int K>
+// ABL (timing-only builds, MOY_WREG_ABL, garbage results): bit 0 no MFMAs, bit 1 output stores dropped, bit 2 no activation DMA past
+// the prologue, bit 4 s_memtime stamps per phase at the head of C
+template <typename T, int BM, int NBUF, int OCC, bool LN, int NW, int WC, int K, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParams p) {
   static_assert((NW == 4 || NW == 8) && (!LN || (NW == 4 && WC == 64 && K == 256)), "score mode: 4 waves x 64 columns, K = 256");
   static_assert((WC == 32 || WC == 64) && K % 128 == 0 && K <= 512, "column width per wave / reduction length");
@@ -106,12 +110,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
   constexpr int TILE_BYTES = BM * KB;
   constexpr int IPW = TILE_BYTES / 1024 / NW;  // DMA instructions per wave and tile
   constexpr int DIST = NBUF - 1;           // tiles in flight ahead of the one being computed
-  constexpr int EP_PITCH = WC * 2 + 8;     // bytes per row of the wave's epilogue strip
-  constexpr int LPR = WC / 8;              // lanes per row in the store pass (16 bytes each)
-  constexpr int RPI = 64 / LPR;            // rows per store instruction
-  constexpr int NST = LN ? 0 : BM / RPI;   // 16-byte store instructions per wave and tile (score mode: see below)
-  constexpr int EP_BYTES = LN ? 0 : NW * BM * EP_PITCH;
-  static_assert(BM % 16 == 0 && IPW >= 1 && IPW * NW * 1024 == TILE_BYTES && BM % RPI == 0, "tile");
+  constexpr int NST = LN ? 0 : MT * NT / 2;   // 16-byte store instructions per wave and tile (score mode: see below)
+  static_assert(BM % 16 == 0 && IPW >= 1 && IPW * NW * 1024 == TILE_BYTES && NT % 2 == 0, "tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -126,8 +126,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
   if (t0 >= p.ntiles) return;
   const int n_mine = (p.ntiles - t0 + tstep - 1) / tstep;
 
-  unsigned char* ep = smem + NBUF * TILE_BYTES + wave * (BM * EP_PITCH);
-  float* ssc = reinterpret_cast<float*>(smem + NBUF * TILE_BYTES + EP_BYTES);
+  float* ssc = reinterpret_cast<float*>(smem + NBUF * TILE_BYTES);
   float* ssh = ssc + BNB;
   float* gw = ssh + BNB;                   // score mode: ln_g[n] * dot_w[c][n]
   float* GB = gw + WREG_MAXDOT * 256;      // [0..3] sum_n gw[c][n]; [4..7] sum_n ln_b[n] * dot_w[c][n] + dot_b[c]
@@ -223,33 +222,136 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
     }
   };
 
-  // ---- weights of this wave's 64 columns -> registers (MFMA A operand: lane (r,q) holds W[n = j*16 + r][k = pn*32 + q*8 ..+7])
+  // ---- weights of this wave's WC columns -> registers (MFMA A operand: lane (r,q) supplies row r of fragment j, k = pn*32 + q*8 ..+7).
+  // Store mode: fragment row r of the pair (2t, 2t+1) is channel 32t + 8(r>>2) + 4(j&1) + (r&3), so that the output lane (r, q) --
+  // which owns fragment rows 4q..4q+3 -- holds channels 32t + 8q + 0..3 from fragment 2t and + 4..7 from 2t+1: 8 consecutive ones.
+  // (A permutation of which channel sits where; every output is the same sum in the same k order.)  Score mode: channel j*16 + r.
   u32x4 wf[NT][KP];
   {
     const T* Wg = static_cast<const T*>(p.W) + (int64_t)(nb + wave * WC) * K;
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int pn = 0; pn < KP; ++pn) wf[j][pn] = *reinterpret_cast<const u32x4*>(Wg + (j * 16 + r) * K + pn * 32 + q * 8);
+      for (int pn = 0; pn < KP; ++pn) {
+        const int ch = LN ? j * 16 + r : (j >> 1) * 32 + (r >> 2) * 8 + (j & 1) * 4 + (r & 3);
+        wf[j][pn] = *reinterpret_cast<const u32x4*>(Wg + ch * K + pn * 32 + q * 8);
+      }
   }
 
+  // Per-lane scale / shift of the 8 channels a lane owns in each channel pair-group t (store mode; see the weight load)
+  float scr[LN ? 1 : NT / 2][8], shr[LN ? 1 : NT / 2][8];
+  if constexpr (!LN) {
+#pragma unroll
+    for (int t = 0; t < NT / 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = nb + wave * WC + t * 32 + q * 8 + e;
+        scr[t][e] = p.scale ? p.scale[c] : 1.0f;
+        shr[t][e] = p.shift ? p.shift[c] : 0.0f;
+      }
+  }
   // prologue: DIST tiles in flight (tiles past the end are clamped re-reads that nobody consumes: the counts stay uniform)
+  const int ncol = nb + wave * WC;             // a wave's columns: inside one plane (plane_cols % 64 == 0) or two planes of 32
 #pragma unroll
   for (int d = 0; d < DIST; ++d) issue_tile(t0 + d * tstep, d);
   wait_vmcnt<(DIST - 1) * IPW>();
   __syncthreads();
 
+  f32x4 acc[MT][NT];
+  // ---- epilogue of this wave's BM x WC strip, straight from the accumulators: with the permuted weight rows a lane owns 8
+  // CONSECUTIVE channels (32t + 8q ..+7) of row i*16 + r -- 16 bytes, the four lanes q of a row 64 contiguous bytes, the 16 rows of
+  // a store instruction 16 runs of 64 B (head planes: ONE run of 1 KB).  No LDS round trip.
+  // What round 3 measured here (tools/probes/wreg_ablate.py, stamps of MOY_WREG_ABL=16): the kernel moves 14 GB and the write path
+  // of a CU buffers far less than a tile, so a store instruction WAITS AT ISSUE for the memory system (1 300-1 800 of a 4 000-cycle
+  // tile).  Anti-phase waves of a SIMD, and the four stores paced through the NEXT tile's MFMAs, both only moved that wait around:
+  // the tile period is the drain time of its 48 KB (stores + DMA without any MFMA: 2.65-3.0 ms of the 3.15), i.e. the kernel runs
+  // at ~85 % of the rate this device COPIES at (5.25 TB/s), not at the 6.9 TB/s it fills at.
+  u32x4 pk[MT][NT / 2];
+  auto convert = [&]() {
+    if constexpr (!LN) {
+    auto stage = [&](auto act_c) {
+      constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+      for (int t = 0; t < NT / 2; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = acc[i][2 * t + (e >> 2)][e & 3] * scr[t][e] + shr[t][e];
+            if constexpr (ACT == MOY_ACT_SILU) x = siluf_(x);
+            else if constexpr (ACT == MOY_ACT_RELU) x = fmaxf(x, 0.f);
+            else if constexpr (ACT == MOY_ACT_SIGMOID) x = fast_sigmoid(x);
+            v[e] = x;
+          }
+          pk[i][t] = u32x4{DT<T>::pack2(v[0], v[1]), DT<T>::pack2(v[2], v[3]), DT<T>::pack2(v[4], v[5]), DT<T>::pack2(v[6], v[7])};
+        }
+    };
+    switch (p.act) {   // wave-uniform
+      case MOY_ACT_SILU: stage(std::integral_constant<int, MOY_ACT_SILU>{}); break;
+      case MOY_ACT_RELU: stage(std::integral_constant<int, MOY_ACT_RELU>{}); break;
+      case MOY_ACT_SIGMOID: stage(std::integral_constant<int, MOY_ACT_SIGMOID>{}); break;
+      default: stage(std::integral_constant<int, MOY_ACT_NONE>{}); break;
+    }
+    }
+  };
+  // store k = i * (NT/2) + t of the tile whose first row is m0.  Rows past M fall outside the descriptor's range (or get an
+  // out-of-range offset) and are dropped by the range check: the NST stores are unconditional (the counted waits rely on it).
+  auto store_piece = [&](auto kc, int m0) {
+    if constexpr (!LN) {
+    constexpr int k = decltype(kc)::value, i = k / (NT / 2), t = k % (NT / 2);
+    const bool live = !(ABL & 2);
+    const int rr = i * 16 + r;
+    if (WC == 64 && p.plane_cols == 32) {
+      // head planes [plane][row][32]: pair-group t of the wave IS plane 2w + t; a store instruction = 16 rows x 64 B = 1 KB contiguous
+      T* cb = static_cast<T*>(p.C) + (int64_t)((ncol >> 5) + t) * p.plane_stride + (int64_t)(live ? m0 : 0) * 32;
+      const int64_t left = live ? (int64_t)(p.M - m0) * 64 : 0;
+      const auto rsC = __builtin_amdgcn_make_buffer_rsrc(cb, 0, (uint32_t)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(pk[i][t], rsC, (uint32_t)rr * 64u + q * 16, 0, 0);
+    } else if (p.c_rpb) {
+      // output row remap (level-major token scatter of input_proj, head.py:1023-1028): the row offset is per lane; the host
+      // guarantees that the whole C buffer is addressable with 31 bits
+      const auto rsC = __builtin_amdgcn_make_buffer_rsrc(static_cast<T*>(p.C) + ncol, 0, 0x7fffffffu, 0x00020000);
+      const int m = m0 + rr;
+      const int bq = (int)fdiv((uint32_t)m, p.fd_rpb);
+      const uint32_t mo = (uint32_t)(bq * p.c_bstride + (m - bq * p.c_rpb));
+      const uint32_t vo = (live && m < p.M) ? (mo * (uint32_t)p.ldc + t * 32 + q * 8) * 2u : 0x80000000u;
+      __builtin_amdgcn_raw_buffer_store_b128(pk[i][t], rsC, vo, 0, 0);
+    } else {
+      const int pl = p.plane_cols ? ncol / p.plane_cols : 0;
+      T* cb = static_cast<T*>(p.C) + (int64_t)pl * p.plane_stride + (int64_t)(live ? m0 : 0) * p.ldc + (ncol - pl * p.plane_cols);
+      const int64_t left = live ? ((int64_t)(p.M - 1 - m0) * p.ldc + WC) * 2 : 0;
+      const auto rsC = __builtin_amdgcn_make_buffer_rsrc(cb, 0, (uint32_t)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(pk[i][t], rsC, (uint32_t)(rr * (int)p.ldc + q * 8 + t * 32) * 2u, 0, 0);
+    }
+    }
+  };
+  auto store_all = [&](int m0) {
+    [&]<int... Ks>(std::integer_sequence<int, Ks...>) { (store_piece(std::integral_constant<int, Ks>{}, m0), ...); }
+    (std::make_integer_sequence<int, NST>{});
+  };
   // fragment read: row i*16 + r, chunk (pn*4 + q) ^ r  ==  byte (i*16 + r)*KB + ((pn*64) ^ ((q ^ r) << 4))
   const int rbase = r * KB, xq = (q ^ r) << 4;
   int buf = 0;
+  // ABL bit 4: s_memtime stamps per phase, summed over the tiles of block 0 (waves 0 and 4) and left at the head of C (garbage there)
+  uint64_t tph[5] = {0, 0, 0, 0, 0}, tlast = 0;
+  auto stamp = [&](int k) {
+    if constexpr (ABL & 16) {
+      const uint64_t t = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tph[k] += t - tlast;
+      tlast = t;
+    }
+  };
+  if constexpr (ABL & 16) { tlast = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
   for (int it = 0; it < n_mine; ++it) {
     const int tile = t0 + it * tstep;
     {
       int nbuf = buf + DIST; if (nbuf >= NBUF) nbuf -= NBUF;
-      issue_tile(tile + DIST * tstep, nbuf);
+      if constexpr (!(ABL & 4)) issue_tile(tile + DIST * tstep, nbuf);
     }
+    stamp(0);
     const unsigned char* As = smem + buf * TILE_BYTES;
-    f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -259,9 +361,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
     u32x4 af[2][MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) af[0][i] = *reinterpret_cast<const u32x4*>(As + (rbase + xq + i * 16 * KB));
-#pragma unroll
-    for (int pn = 0; pn < KP; ++pn) {
-      if (pn + 1 < KP) {
+    auto panel = [&](auto pc) {
+      constexpr int pn = decltype(pc)::value;
+      if constexpr (pn + 1 < KP) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
           af[(pn + 1) & 1][i] = *reinterpret_cast<const u32x4*>(As + (rbase + (((pn + 1) * 64) ^ xq) + i * 16 * KB));
@@ -270,10 +372,16 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<T>(acc[i][j], wf[j][pn], af[pn & 1][i]);
+        for (int j = 0; j < NT; ++j) {
+          if constexpr (ABL & 1) { if (pn == 0) acc[i][j] = __builtin_bit_cast(f32x4, wf[j][i] ^ af[0][i]); }
+          else acc[i][j] = mfma16<T>(acc[i][j], wf[j][pn], af[pn & 1][i]);
+        }
       __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    [&]<int... Ps>(std::integer_sequence<int, Ps...>) { (panel(std::integral_constant<int, Ps>{}), ...); }
+    (std::make_integer_sequence<int, KP>{});
 
+    stamp(1);
     if constexpr (LN) {
       // ---- score mode: row statistics of v = acc * scale + shift (masked token rows: v = shift, i.e. a zero A row) and the
       // narrow head: every lane leaves its partial sums in LDS, wave 0 adds the 16 partials of each row after ONE barrier
@@ -356,83 +464,23 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
       }
       // Wave 0's few score stores are not counted below: its wait then also retires that many of the youngest DMA pieces.
     } else {
-    // ---- epilogue of this wave's BM x 64 strip
-    const int m0 = tile * BM;
-    auto stage = [&](auto act_c) {
-      constexpr int ACT = decltype(act_c)::value;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(ssc + wave * WC + j * 16 + q * 4);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(ssh + wave * WC + j * 16 + q * 4);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          f32x4 v = acc[i][j] * sc + sh;
-          if constexpr (ACT == MOY_ACT_SILU) { v.x = siluf_(v.x); v.y = siluf_(v.y); v.z = siluf_(v.z); v.w = siluf_(v.w); }
-          else if constexpr (ACT == MOY_ACT_RELU) { v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f}); }
-          else if constexpr (ACT == MOY_ACT_SIGMOID) { v.x = fast_sigmoid(v.x); v.y = fast_sigmoid(v.y); v.z = fast_sigmoid(v.z); v.w = fast_sigmoid(v.w); }
-          *reinterpret_cast<u32x2*>(ep + (i * 16 + r) * EP_PITCH + (j * 16 + q * 4) * 2) =
-              u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
-        }
-      }
-    };
-    switch (p.act) {   // wave-uniform
-      case MOY_ACT_SILU: stage(std::integral_constant<int, MOY_ACT_SILU>{}); break;
-      case MOY_ACT_RELU: stage(std::integral_constant<int, MOY_ACT_RELU>{}); break;
-      case MOY_ACT_SIGMOID: stage(std::integral_constant<int, MOY_ACT_SIGMOID>{}); break;
-      default: stage(std::integral_constant<int, MOY_ACT_NONE>{}); break;
+      convert();
+      store_all(tile * BM);
     }
-    {
-      // rows past M fall outside the descriptor and are dropped by the range check: the NST stores are unconditional
-      // (all strip reads first, then the stores back to back; the vmcnt bookkeeping below counts exactly NST)
-      const int cc = lane % LPR, rr0 = lane / LPR;
-      const int ncol = nb + wave * WC;         // a wave's columns: inside one plane (plane_cols % 64 == 0) or two planes of 32
-      u32x2 lo[NST], hi[NST];
-#pragma unroll
-      for (int k = 0; k < NST; ++k) {
-        const int rr = rr0 + k * RPI;
-        lo[k] = *reinterpret_cast<const u32x2*>(ep + rr * EP_PITCH + cc * 16);
-        hi[k] = *reinterpret_cast<const u32x2*>(ep + rr * EP_PITCH + cc * 16 + 8);
-      }
-      if (WC == 64 && p.plane_cols == 32) {
-        // head planes [plane][row][32]: lanes 0-3 / 4-7 of a row group write the row's 64 B of plane 2w / 2w+1, so a store
-        // instruction lays down 512 contiguous bytes per plane; rows past M get an out-of-range offset (dropped)
-        T* cb = static_cast<T*>(p.C) + (int64_t)(ncol >> 5) * p.plane_stride + (int64_t)m0 * 32;
-        const auto rsC = __builtin_amdgcn_make_buffer_rsrc(cb, 0, 0x7fffffffu, 0x00020000);
-        const uint32_t pofs = (uint32_t)((cc >> 2) * p.plane_stride * 2 + (cc & 3) * 16);
-#pragma unroll
-        for (int k = 0; k < NST; ++k) {
-          const int rr = rr0 + k * RPI;
-          const uint32_t vo = m0 + rr < p.M ? pofs + (uint32_t)rr * 64u : 0x80000000u;
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[k].x, lo[k].y, hi[k].x, hi[k].y}, rsC, vo, 0, 0);
-        }
-      } else if (p.c_rpb) {
-        // output row remap (level-major token scatter of input_proj, head.py:1023-1028): the row offset is per lane, rows past
-        // M get an out-of-range offset; the host guarantees that the whole C buffer is addressable with 31 bits
-        const auto rsC = __builtin_amdgcn_make_buffer_rsrc(static_cast<T*>(p.C) + ncol, 0, 0x7fffffffu, 0x00020000);
-#pragma unroll
-        for (int k = 0; k < NST; ++k) {
-          const int m = m0 + rr0 + k * RPI;
-          const int bq = (int)fdiv((uint32_t)m, p.fd_rpb);
-          const uint32_t mo = (uint32_t)(bq * p.c_bstride + (m - bq * p.c_rpb));
-          const uint32_t vo = m < p.M ? (mo * (uint32_t)p.ldc + cc * 8) * 2u : 0x80000000u;
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[k].x, lo[k].y, hi[k].x, hi[k].y}, rsC, vo, 0, 0);
-        }
-      } else {
-        const int pl = p.plane_cols ? ncol / p.plane_cols : 0;
-        T* cb = static_cast<T*>(p.C) + (int64_t)pl * p.plane_stride + (int64_t)m0 * p.ldc + (ncol - pl * p.plane_cols);
-        const int64_t left = ((int64_t)(p.M - 1 - m0) * p.ldc + WC) * 2;
-        const auto rsC = __builtin_amdgcn_make_buffer_rsrc(cb, 0, (uint32_t)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
-        const uint32_t voff0 = (uint32_t)(rr0 * (int)p.ldc + cc * 8) * 2, vstep = (uint32_t)p.ldc * 2 * RPI;
-#pragma unroll
-        for (int k = 0; k < NST; ++k)
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo[k].x, lo[k].y, hi[k].x, hi[k].y}, rsC, voff0 + k * vstep, 0, 0);
-      }
-    }
-    }
+    stamp(2);
     // tile it+1 must have landed; the younger DMA tiles and the stores issued since stay in flight
-    wait_vmcnt<(DIST - 1) * (IPW + NST) + NST>();
+    if constexpr (ABL & 4) wait_vmcnt<NST>(); else wait_vmcnt<(DIST - 1) * (IPW + NST) + NST>();
+    stamp(3);
     __syncthreads();
+    stamp(4);
     if (++buf == NBUF) buf = 0;
+  }
+  if constexpr (ABL & 16) {
+    if (blockIdx.x == 0 && (wave == 0 || wave == NW / 2) && lane == 0) {
+      uint64_t* d = static_cast<uint64_t*>(p.C) + (wave ? 8 : 0);
+      for (int k = 0; k < 5; ++k) d[k] = tph[k];
+      d[5] = (uint64_t)n_mine;
+    }
   }
   wait_vmcnt<0>();   // clamped over-fetch tiles still target this block's LDS
 }
@@ -448,10 +496,10 @@ static int wreg_num_cus() {
   return n;
 }
 
-template <typename T, int BM, int NBUF, int OCC, bool LN = false, int NW = 4, int WC = 64, int K = 256>
+template <typename T, int BM, int NBUF, int OCC, bool LN = false, int NW = 4, int WC = 64, int K = 256, int ABL = 0>
 static int launch_wreg(WregParams& p, hipStream_t st) {
   const int lds = wreg_lds_bytes<BM, NBUF, LN, NW, WC, K>() + (LN && p.a_mask ? ((p.mask_period + 31) / 32) * 4 : 0);
-  auto kern = gemm_wreg_kernel<T, BM, NBUF, OCC, LN, NW, WC, K>;
+  auto kern = gemm_wreg_kernel<T, BM, NBUF, OCC, LN, NW, WC, K, ABL>;
   static int attr_lds = 0;
   if (lds > 65536 && lds > attr_lds) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -560,13 +608,23 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   // measured on the value projection (M = 1.3 M, N = 1536, bf16; tiled kernel 1951 us): 4 waves x 256 columns, BM 32 / 3 buffers /
   // 2 blocks per CU 1168 us; BM 64 / 3 buffers / 1 block per CU 1254 us; BM 64 / 2 buffers 1274 us; BM 32 / 4 buffers 1458 us (one
   // block per CU fits); 8 waves x 512 columns, BM 32 / 3 buffers, one block per CU: 6 % faster than the first (same device) -- half as
-  // many blocks re-fetch an activation tile that has left the L2
+  // many blocks re-fetch an activation tile that has left the L2.  (Those variants left the tree in round 3; MOY_WREG_VARIANT=2
+  // keeps the 4-wave form selectable for A/B runs.)
   if (a->dtype == MOY_BF16) {
-    if (variant == 1) return launch_wreg<bf16_t, 64, 3, 1>(p, st);
     if (variant == 2 || a->N % 512) return launch_wreg<bf16_t, 32, 3, 2>(p, st);
-    if (variant == 3) return launch_wreg<bf16_t, 32, 4, 1, false, 8>(p, st);      // 8 waves, ring of 4 (three tiles ahead)
-    if (variant == 4) return launch_wreg<bf16_t, 64, 2, 1, false, 8>(p, st);      // 8 waves, 64-row tiles, ring of 2
-    if (variant == 5) return launch_wreg<bf16_t, 16, 4, 1, false, 8>(p, st);      // 8 waves, 16-row tiles, ring of 4
+    // timing-only builds of the value-projection form (tools/probes/wreg_ablate.py): see the kernel's ABL comment
+    static const int abl = garbage_mode_env("MOY_WREG_ABL");
+    switch (abl) {
+      case 1: return launch_wreg<bf16_t, 32, 3, 1, false, 8, 64, 256, 1>(p, st);
+      case 2: return launch_wreg<bf16_t, 32, 3, 1, false, 8, 64, 256, 2>(p, st);
+      case 3: return launch_wreg<bf16_t, 32, 3, 1, false, 8, 64, 256, 3>(p, st);
+      case 4: return launch_wreg<bf16_t, 32, 3, 1, false, 8, 64, 256, 4>(p, st);
+      case 5: return launch_wreg<bf16_t, 32, 3, 1, false, 8, 64, 256, 5>(p, st);
+      case 6: return launch_wreg<bf16_t, 32, 3, 1, false, 8, 64, 256, 6>(p, st);
+      case 16: return launch_wreg<bf16_t, 32, 3, 1, false, 8, 64, 256, 16>(p, st);
+      case 22: return launch_wreg<bf16_t, 32, 3, 1, false, 8, 64, 256, 22>(p, st);
+      default: break;
+    }
     return launch_wreg<bf16_t, 32, 3, 1, false, 8>(p, st);
   }
   if (a->N % 512) return launch_wreg<f16_t, 32, 3, 2>(p, st);

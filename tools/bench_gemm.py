@@ -22,6 +22,11 @@ SHAPES = [
     ("L3 3x3s2 64->128", 3, 2, 152, 272, 64, 128, False),
     ("L4m 3x3 64->64", 3, 1, 76, 136, 64, 64, False),
     ("L4cv2 1x1 256->128", 1, 1, 76, 136, 256, 128, False),
+    ("L4cv1 1x1 128->128", 1, 1, 76, 136, 128, 128, False),
+    ("L6cv1 1x1 256->256", 1, 1, 38, 68, 256, 256, False),
+    ("L6cv2 1x1 512->256", 1, 1, 38, 68, 512, 256, False),
+    ("N15cv2 1x1 384->256", 1, 1, 38, 68, 384, 256, False),
+    ("P3proj 1x1 128->256", 1, 1, 76, 136, 128, 256, False),
     ("L6m 3x3 128->128", 3, 1, 38, 68, 128, 128, False),
     ("L5 3x3s2 128->256", 3, 2, 76, 136, 128, 256, False),
     ("L8m 3x3 128->128 P5", 3, 1, 19, 34, 128, 128, False),
