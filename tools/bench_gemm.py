@@ -29,6 +29,8 @@ SHAPES = [
     ("P3proj 1x1 128->256", 1, 1, 76, 136, 128, 256, False),
     ("L6m 3x3 128->128", 3, 1, 38, 68, 128, 128, False),
     ("L5 3x3s2 128->256", 3, 2, 76, 136, 128, 256, False),
+    ("N19 3x3s2 128->128", 3, 2, 76, 136, 128, 128, False),
+    ("L7 3x3s2 256->256", 3, 2, 38, 68, 256, 256, False),
     ("L8m 3x3 128->128 P5", 3, 1, 19, 34, 128, 128, False),
     ("value 1x1 256->1536", 1, 1, 1, 13566, 256, 1536, False),
     ("encout+ln 256->256", 1, 1, 1, 13566, 256, 256, True),
