@@ -59,6 +59,12 @@ struct WregParams {   // ngroups = N / (columns per block)
   const uint8_t* a_mask;
   int mask_period;
   FastDiv fd_mask;
+  // accumulator seed (moy_gemm_args.pre; PRE forms): row m = (b, y, x) of a [B, pre_h, pre_w] raster starts from the fp32 row
+  // (b * lowhw + (y/2) * loww + x/2) of pre
+  const float* pre;
+  int64_t ld_pre;
+  int pre_w, pre_hw, pre_loww, pre_lowhw;
+  FastDiv fd_pre_hw, fd_pre_w;
 };
 
 // LDS-DMA of 16 bytes per lane: LDS[m0 + lane*16 ..] <- *gsrc.  M0 is compiler-reserved: saved and restored in the statement.
@@ -69,6 +75,21 @@ __device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_
                : "=&s"(keep)
                : "v"(voff), "s"(lds_dst), "s"(sbase)
                : "memory");
+}
+
+// 16-byte buffer load whose completion the CALLER bookkeeps (counted vmcnt): hipcc knows nothing of the LDS-DMA pieces in the
+// queue, so for a load it can see it would wait vmcnt(0) at the first use and drain the ring.  The destination is not valid
+// until a wait_vmcnt_tie() that covers it has run.
+__device__ __forceinline__ void bload16_async(u32x4& dst, uint32_t voff, __amdgpu_buffer_rsrc_t rs, int) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(dst) : "v"(voff), "s"(rs) : "memory");
+}
+__device__ __forceinline__ void bload16_async_16(u32x4& dst, uint32_t voff, __amdgpu_buffer_rsrc_t rs) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=&v"(dst) : "v"(voff), "s"(rs) : "memory");
+}
+// counted wait that the four async destinations depend on (the "+v" ties keep every use of them behind it)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_tie(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
 }
 
 template <int N>
@@ -97,7 +118,7 @@ constexpr int wreg_lds_bytes() {
 // WC = output columns per wave (64: K = 256 only; 32: K up to 512 fits the registers), K = reduction length (multiple of 128).
 // ABL (timing-only builds, MOY_WREG_ABL, garbage results): bit 0 no MFMAs, bit 1 output stores dropped, bit 2 no activation DMA past
 // the prologue, bit 4 s_memtime stamps per phase at the head of C
-template <typename T, int BM, int NBUF, int OCC, bool LN, int NW, int WC, int K, int ABL = 0>
+template <typename T, int BM, int NBUF, int OCC, bool LN, int NW, int WC, int K, int ABL = 0, bool PRE = false>
 __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParams p) {
   static_assert((NW == 4 || NW == 8) && (!LN || (NW == 4 && WC == 64 && K == 256)), "score mode: 4 waves x 64 columns, K = 256");
   static_assert((WC == 32 || WC == 64) && K % 128 == 0 && K <= 512, "column width per wave / reduction length");
@@ -252,9 +273,33 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
   }
   // prologue: DIST tiles in flight (tiles past the end are clamped re-reads that nobody consumes: the counts stay uniform)
   const int ncol = nb + wave * WC;             // a wave's columns: inside one plane (plane_cols % 64 == 0) or two planes of 32
+  // PRE: the seed rows of a tile are fetched one tile ahead, straight into registers (each lane: the 8 channels it owns of its MT
+  // rows = MT * NT 16-byte loads), issued BEFORE that pass's DMA so that one counted wait covers both
+  static_assert(!PRE || (!LN && DIST == 2 && MT * NT == 4 && ABL == 0), "seeded form: 8 waves x 32 columns or 4 x 32, 32-row tiles, two tiles in flight");
+  u32x4 seed[PRE ? 4 : 1];
+  [[maybe_unused]] const auto rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pre), 0, 0x7fffffffu, 0x00020000);   // (size checked by the host)
+  [[maybe_unused]] auto issue_seed = [&](int tile, u32x4 (&dst)[PRE ? 4 : 1]) {
+    if constexpr (PRE) {
+      const int m0 = min(tile, p.ntiles - 1) * BM;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const uint32_t m = (uint32_t)min(m0 + i * 16 + r, p.M - 1);
+        const int b = (int)fdiv(m, p.fd_pre_hw), rem = (int)m - b * p.pre_hw;
+        const int y = (int)fdiv((uint32_t)rem, p.fd_pre_w), x = rem - y * p.pre_w;
+        const uint32_t row = (uint32_t)(b * p.pre_lowhw + (y >> 1) * p.pre_loww + (x >> 1));
+#pragma unroll
+        for (int t = 0; t < NT / 2; ++t) {
+          const uint32_t vo = (row * (uint32_t)p.ld_pre + (uint32_t)(ncol + t * 32 + q * 8)) * 4u;
+          bload16_async(dst[(i * (NT / 2) + t) * 2], vo, rsP, 0);
+          bload16_async_16(dst[(i * (NT / 2) + t) * 2 + 1], vo, rsP);
+        }
+      }
+    }
+  };
+  if constexpr (PRE) issue_seed(t0, seed);
 #pragma unroll
   for (int d = 0; d < DIST; ++d) issue_tile(t0 + d * tstep, d);
-  wait_vmcnt<(DIST - 1) * IPW>();
+  if constexpr (PRE) wait_vmcnt_tie<(DIST - 1) * IPW>(seed[0], seed[1], seed[2], seed[3]); else wait_vmcnt<(DIST - 1) * IPW>();
   __syncthreads();
 
   f32x4 acc[MT][NT];
@@ -346,16 +391,27 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
   if constexpr (ABL & 16) { tlast = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
   for (int it = 0; it < n_mine; ++it) {
     const int tile = t0 + it * tstep;
+    u32x4 seed_next[PRE ? 4 : 1];
+    if constexpr (PRE) {
+      // acc[i][2t], acc[i][2t+1] = the lane's channels 32t + 8q + 0..3 / + 4..7 of row i*16 + r: the two halves of its seed row
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_bit_cast(f32x4, seed[(i * (NT / 2) + (j >> 1)) * 2 + (j & 1)]);
+      issue_seed(tile + tstep, seed_next);
+    }
     {
       int nbuf = buf + DIST; if (nbuf >= NBUF) nbuf -= NBUF;
       if constexpr (!(ABL & 4)) issue_tile(tile + DIST * tstep, nbuf);
     }
     stamp(0);
     const unsigned char* As = smem + buf * TILE_BYTES;
+    if constexpr (!PRE) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // fragments of panel pn+1 are requested before the MFMAs of panel pn (counted lgkmcnt): with one wave per SIMD nothing
     // else hides the LDS latency
     u32x4 af[2][MT];
@@ -469,7 +525,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
     }
     stamp(2);
     // tile it+1 must have landed; the younger DMA tiles and the stores issued since stay in flight
-    if constexpr (ABL & 4) wait_vmcnt<NST>(); else wait_vmcnt<(DIST - 1) * (IPW + NST) + NST>();
+    if constexpr (PRE) {
+      // queue, oldest first: DMA(it+1), stores(it-1), seed(it+1), DMA(it+2), stores(it): the next tile's seed AND patch are needed
+      wait_vmcnt_tie<IPW + NST>(seed_next[0], seed_next[1], seed_next[2], seed_next[3]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) seed[k] = seed_next[k];
+    } else if constexpr (ABL & 4) wait_vmcnt<NST>();
+    else wait_vmcnt<(DIST - 1) * (IPW + NST) + NST>();
     stamp(3);
     __syncthreads();
     stamp(4);
@@ -496,10 +558,10 @@ static int wreg_num_cus() {
   return n;
 }
 
-template <typename T, int BM, int NBUF, int OCC, bool LN = false, int NW = 4, int WC = 64, int K = 256, int ABL = 0>
+template <typename T, int BM, int NBUF, int OCC, bool LN = false, int NW = 4, int WC = 64, int K = 256, int ABL = 0, bool PRE = false>
 static int launch_wreg(WregParams& p, hipStream_t st) {
   const int lds = wreg_lds_bytes<BM, NBUF, LN, NW, WC, K>() + (LN && p.a_mask ? ((p.mask_period + 31) / 32) * 4 : 0);
-  auto kern = gemm_wreg_kernel<T, BM, NBUF, OCC, LN, NW, WC, K, ABL>;
+  auto kern = gemm_wreg_kernel<T, BM, NBUF, OCC, LN, NW, WC, K, ABL, PRE>;
   static int attr_lds = 0;
   if (lds > 65536 && lds > attr_lds) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -548,7 +610,7 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   const bool is128 = a->N == 128 && n128 && (a->K == 128 || a->K == 256);
   if (a->ksize != 1 || (!is128 && (a->N % 256 || a->N / 256 > 16))) return MOY_ENOSYS;
   if (a->K != 128 && a->K != 256 && a->K != 384 && a->K != 512) return MOY_ENOSYS;
-  if (a->A2 || a->a_rows || a->R || a->out_f32 || a->pre) return MOY_ENOSYS;
+  if (a->A2 || a->a_rows || a->R || a->out_f32) return MOY_ENOSYS;
   // score mode: LayerNorm + narrow head with NO feature output (C == NULL; moy_gemm documents it); the normalised rows
   // themselves are the tiled kernel's job
   const bool score = a->ln_g && !a->C;
@@ -565,9 +627,17 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   } else if (a->ln_g || a->a_mask || a->dot_n || !a->C || a->run_levels) {
     return MOY_ENOSYS;
   }
+  static int preok = -1;                   // MOY_WREG_PRE=0: seeded launches stay on the tiled kernel (A/B runs)
+  if (preok < 0) { const char* e = getenv("MOY_WREG_PRE"); preok = e ? atoi(e) : 1; }
+  const bool seeded = a->pre != nullptr;   // (shape and alignment of the seed were validated by moy_gemm)
+  if (seeded) {
+    const bool form = (is128 && a->K == 128) || (!is128 && a->K == 256);
+    const int64_t seed_bytes = (int64_t)(a->M / (a->pre_h * a->pre_w)) * (a->pre_h / 2) * (a->pre_w / 2) * a->ld_pre * 4;
+    if (!preok || score || !form || a->plane_cols || a->c_rows_per_batch || seed_bytes > 0x7fffffffLL) return MOY_ENOSYS;
+  }
   static int kgen = -1;                    // MOY_WREG_KGEN=0: only the K = 256 forms (A/B runs)
   if (kgen < 0) { const char* e = getenv("MOY_WREG_KGEN"); kgen = e ? atoi(e) : 1; }
-  const bool general = a->K != 256 || a->c_rows_per_batch || is128;       // the 32-columns-per-wave forms
+  const bool general = a->K != 256 || a->c_rows_per_batch || is128 || seeded;       // the 32-columns-per-wave forms
   if (general && (!kgen || a->plane_cols)) return MOY_ENOSYS;
   if (a->c_rows_per_batch) {               // per-lane 32-bit byte offsets into the remapped C
     const int64_t rows = ((int64_t)a->M / a->c_rows_per_batch + 1) * a->c_batch_stride;
@@ -583,6 +653,13 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   p.C = a->C; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.ngroups = a->N / 256;
   p.plane_cols = a->plane_cols; p.plane_stride = a->plane_stride;
   p.c_rpb = a->c_rows_per_batch; p.c_bstride = a->c_batch_stride; p.fd_rpb = make_fastdiv(p.c_rpb > 0 ? p.c_rpb : 1);
+  if (seeded) {
+    p.pre = a->pre; p.ld_pre = a->ld_pre; p.pre_w = a->pre_w; p.pre_hw = a->pre_h * a->pre_w;
+    p.pre_loww = a->pre_w / 2; p.pre_lowhw = (a->pre_h / 2) * (a->pre_w / 2);
+    p.fd_pre_hw = make_fastdiv((uint32_t)p.pre_hw); p.fd_pre_w = make_fastdiv((uint32_t)p.pre_w);
+    if (is128) return a->dtype == MOY_BF16 ? launch_wreg<bf16_t, 32, 3, 2, false, 4, 32, 128, 0, true>(p, st) : launch_wreg<f16_t, 32, 3, 2, false, 4, 32, 128, 0, true>(p, st);
+    return a->dtype == MOY_BF16 ? launch_wreg<bf16_t, 32, 3, 1, false, 8, 32, 256, 0, true>(p, st) : launch_wreg<f16_t, 32, 3, 1, false, 8, 32, 256, 0, true>(p, st);
+  }
   if (is128) return a->dtype == MOY_BF16 ? launch_wreg_n128<bf16_t>(p, a->K, st) : launch_wreg_n128<f16_t>(p, a->K, st);
   if (general) return a->dtype == MOY_BF16 ? launch_wreg_k<bf16_t>(p, a->K, st) : launch_wreg_k<f16_t>(p, a->K, st);
   if (score) {

@@ -192,6 +192,33 @@ def test_gemm_upsampled_accumulator_seed(dt):
     assert torch.allclose(got, ref, atol=tol(dt, 2e-5, 3e-2), rtol=tol(dt, 1e-5, 1e-2))
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,K,B,H,W", [(128, 128, 25, 38, 70), (256, 256, 25, 38, 70), (128, 128, 6, 76, 136)])
+def test_gemm_seeded_weight_stationary_kernel_bit_identical_to_tiled(dt, N, K, B, H, W):
+    """The two seeded 1x1 convs of the neck (yolo_track.yaml:28-33 after the Upsample / Concat fold) at launch sizes that take the
+    weight-stationary kernel: the seed rows arrive one tile ahead by hand-counted asynchronous loads.  Bit-identical to the tiled
+    kernel (the same rows submitted as launches of whole images below 65536 rows), ragged last tile, output into a channel slice."""
+    M, hw = B * H * W, (H // 2) * (W // 2)
+    x, w = q(rnd(M, K, seed=41), dt), q(rnd(N, K, seed=42, scale=1 / math.sqrt(K)), dt)
+    sc, sh = rnd(N, seed=43) * 0.2 + 1, rnd(N, seed=44, scale=0.1)
+    seed = rnd(B * hw, N + 8, seed=45).to(DEV)                      # fp32 half-resolution product, pitch > N
+    xd, wd = x.to(DEV, dt), ops.pad_weight(w.to(DEV), dt)
+    kw = dict(scale=sc.to(DEV), shift=sh.to(DEV), act=L.ACT_SILU)
+    out = torch.full((M + 1, N + 32), 7.0, device=DEV, dtype=dt)
+    ops.gemm(xd, wd, N, K, out=out[:M, 16:16 + N], pre=(seed[:, :N], H, W), **kw)
+    two = torch.empty(M, N, device=DEV, dtype=dt)
+    per = max(1, 65535 // (H * W))
+    for b0 in range(0, B, per):
+        b1 = min(B, b0 + per)
+        ops.gemm(xd[b0 * H * W:b1 * H * W], wd, N, K, out=two[b0 * H * W:b1 * H * W], pre=(seed[b0 * hw:b1 * hw, :N], H, W), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:M, 16:16 + N], two), "seeded weight-stationary kernel differs from the tiled kernel"
+    assert bool((out[M] == 7.0).all()) and bool((out[:, :16] == 7.0).all()) and bool((out[:, 16 + N:] == 7.0).all())
+    up = seed[:, :N].view(B, H // 2, W // 2, N).repeat_interleave(2, 1).repeat_interleave(2, 2).reshape(M, N).cpu()
+    ref = F.silu((x @ w.T + up) * sc + sh)
+    assert torch.allclose(two.float().cpu(), ref, atol=tol(dt, 2e-5, 3e-2), rtol=tol(dt, 1e-5, 1e-2))
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_layernorm_residual_prologue_add_gather_mask(dt):
     M, N, K = 333, 256, 256
