@@ -121,12 +121,16 @@ constexpr int wreg_lds_bytes() {
 template <typename T, int BM, int NBUF, int OCC, bool LN, int NW, int WC, int K, int ABL = 0, bool PRE = false>
 __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParams p) {
   static_assert((NW == 4 || NW == 8) && (!LN || (NW == 4 && WC == 64 && K == 256)), "score mode: 4 waves x 64 columns, K = 256");
-  static_assert((WC == 32 || WC == 64) && K % 128 == 0 && K <= 512, "column width per wave / reduction length");
+  static_assert((WC == 32 || WC == 64) && K % 64 == 0 && K <= 512, "column width per wave / reduction length");
   constexpr int BNB = NW * WC;             // output columns per block
   constexpr int MT = BM / 16;              // row sub-tiles per wave (every wave covers all BM rows)
   constexpr int NT = WC / 16;              // column sub-tiles per wave
   constexpr int KB = K * 2;                // bytes per activation row
-  constexpr int CPR = K / 8;               // 16-byte chunks per row (a multiple of 16: the swizzle stays inside groups of 16)
+  constexpr int CPR = K / 8;               // 16-byte chunks per row
+  // swizzle: chunk ^ (row & SWZ) must stay inside the row.  K a multiple of 128: groups of 16, every ds_read_b128 conflict-free.
+  // K = 192 (24 chunks, the P3 neck C2f's cv2): groups of 8 -- rows r and r + 8 of a fragment then share bank slots (two LDS cycles
+  // more per read), which a kernel bound by HBM does not notice
+  constexpr int SWZ = CPR % 16 == 0 ? 15 : 7;
   constexpr int KP = K / 32;               // MFMA k panels
   constexpr int TILE_BYTES = BM * KB;
   constexpr int IPW = TILE_BYTES / 1024 / NW;  // DMA instructions per wave and tile
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
   for (int jj = 0; jj < IPW; ++jj) {
     const int X = (wave * IPW + jj) * 64 + lane;
     drow[jj] = X / CPR;
-    dcol[jj] = (uint32_t)(((X % CPR) ^ (drow[jj] & 15)) * 16);
+    dcol[jj] = (uint32_t)(((X % CPR) ^ (drow[jj] & SWZ)) * 16);
   }
   const uint32_t row_bytes = (uint32_t)(p.lda * 2);
   // compact row -> row of A (score mode with row runs): arithmetic only -- a table lookup from global memory would put
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
     (std::make_integer_sequence<int, NST>{});
   };
   // fragment read: row i*16 + r, chunk (pn*4 + q) ^ r  ==  byte (i*16 + r)*KB + ((pn*64) ^ ((q ^ r) << 4))
-  const int rbase = r * KB, xq = (q ^ r) << 4;
+  const int rbase = r * KB, xq = ((q ^ r) & SWZ) << 4;
   int buf = 0;
   // ABL bit 4: s_memtime stamps per phase, summed over the tiles of block 0 (waves 0 and 4) and left at the head of C (garbage there)
   uint64_t tph[5] = {0, 0, 0, 0, 0}, tlast = 0;
@@ -594,6 +598,7 @@ template <typename T>
 static int launch_wreg_n128(WregParams& p, int K, hipStream_t st) {
   switch (K) {
     case 128: return launch_wreg<T, 32, 3, 2, false, 4, 32, 128>(p, st);
+    case 192: return launch_wreg<T, 32, 3, 2, false, 4, 32, 192>(p, st);
     case 256: return launch_wreg<T, 32, 3, 2, false, 4, 32, 256>(p, st);
     default: return MOY_ENOSYS;
   }
@@ -607,9 +612,9 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   if (a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_ENOSYS;
   static int n128 = -1;                    // MOY_WREG_N128=0: N = 128 stays on the tiled kernel (A/B runs)
   if (n128 < 0) { const char* e = getenv("MOY_WREG_N128"); n128 = e ? atoi(e) : 1; }
-  const bool is128 = a->N == 128 && n128 && (a->K == 128 || a->K == 256);
+  const bool is128 = a->N == 128 && n128 && (a->K == 128 || a->K == 192 || a->K == 256);
   if (a->ksize != 1 || (!is128 && (a->N % 256 || a->N / 256 > 16))) return MOY_ENOSYS;
-  if (a->K != 128 && a->K != 256 && a->K != 384 && a->K != 512) return MOY_ENOSYS;
+  if (a->K != 128 && a->K != 256 && a->K != 384 && a->K != 512 && !(is128 && a->K == 192)) return MOY_ENOSYS;
   if (a->A2 || a->a_rows || a->R || a->out_f32) return MOY_ENOSYS;
   // score mode: LayerNorm + narrow head with NO feature output (C == NULL; moy_gemm documents it); the normalised rows
   // themselves are the tiled kernel's job

@@ -103,10 +103,10 @@ def test_gemm_weight_stationary_kernel_bit_identical_to_tiled(dt, M, N, act):
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("K,N,act,rpb", [(128, 256, "silu", 0), (384, 256, "silu", 0), (512, 512, "none", 0), (128, 256, "none", 2584),
-                                          (256, 256, "none", 646), (128, 128, "silu", 0), (256, 128, "silu", 0)])
+                                          (256, 256, "none", 646), (128, 128, "silu", 0), (256, 128, "silu", 0), (192, 128, "silu", 0)])
 def test_gemm_weight_stationary_general_k_and_row_remap(dt, K, N, act, rpb):
     """The 32-columns-per-wave forms of the weight-stationary kernel (8 waves: K in {128, 256, 384, 512}, N % 256 == 0; 4 waves:
-    N == 128, K in {128, 256}; M >= 65536; 1x1 convs with 256 / 128 outputs and input_proj with its level-major token scatter,
+    N == 128, K in {128, 192, 256}; M >= 65536; 1x1 convs with 256 / 128 outputs and input_proj with its level-major token scatter,
     head.py:1023-1028): bit-identical to the tiled kernel
     (two launches of < 65536 rows), ragged last tile, guard rows / columns untouched."""
     nb = 27 if rpb else 0

@@ -23,6 +23,7 @@ SHAPES = [
     ("L4m 3x3 64->64", 3, 1, 76, 136, 64, 64, False),
     ("L4cv2 1x1 256->128", 1, 1, 76, 136, 256, 128, False),
     ("L4cv1 1x1 128->128", 1, 1, 76, 136, 128, 128, False),
+    ("N18cv2 1x1 192->128", 1, 1, 76, 136, 192, 128, False),
     ("L6cv1 1x1 256->256", 1, 1, 38, 68, 256, 256, False),
     ("L6cv2 1x1 512->256", 1, 1, 38, 68, 512, 256, False),
     ("N15cv2 1x1 384->256", 1, 1, 38, 68, 384, 256, False),
