@@ -19,7 +19,11 @@
 //     with 8 consecutive output channels of a row -> 16-byte stores, 64 contiguous bytes per row and store instruction, no LDS
 //     round trip and no block barrier, so one wave's epilogue overlaps the other waves' MFMAs;
 //   * grid = 8 XCDs x slots; the N/256 column groups of one row-tile sequence sit on the SAME XCD and advance in lock step,
-//     so an activation tile is fetched from HBM once and hits that XCD's L2 for the other groups.
+//     so an activation tile is fetched from HBM once and hits that XCD's L2 for the other groups;
+//   * other forms of the same kernel: 8 waves x 32 columns (1x1 convs / input_proj with 256 outputs, K in {128, 256, 384, 512}),
+//     4 waves x 32 columns, two blocks per CU (128 outputs, K in {128, 192, 256}), score mode (LayerNorm + narrow head, no
+//     feature output), and the SEEDED forms (moy_gemm_args.pre: accumulators start from the nearest-2x rows of a half-resolution
+//     fp32 product, fetched one tile ahead by hand-counted asynchronous register loads).
 #include "common.hpp"
 
 #include <type_traits>
@@ -80,7 +84,7 @@ __device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_
 // 16-byte buffer load whose completion the CALLER bookkeeps (counted vmcnt): hipcc knows nothing of the LDS-DMA pieces in the
 // queue, so for a load it can see it would wait vmcnt(0) at the first use and drain the ring.  The destination is not valid
 // until a wait_vmcnt_tie() that covers it has run.
-__device__ __forceinline__ void bload16_async(u32x4& dst, uint32_t voff, __amdgpu_buffer_rsrc_t rs, int) {
+__device__ __forceinline__ void bload16_async(u32x4& dst, uint32_t voff, __amdgpu_buffer_rsrc_t rs) {
   asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(dst) : "v"(voff), "s"(rs) : "memory");
 }
 __device__ __forceinline__ void bload16_async_16(u32x4& dst, uint32_t voff, __amdgpu_buffer_rsrc_t rs) {
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
 #pragma unroll
         for (int t = 0; t < NT / 2; ++t) {
           const uint32_t vo = (row * (uint32_t)p.ld_pre + (uint32_t)(ncol + t * 32 + q * 8)) * 4u;
-          bload16_async(dst[(i * (NT / 2) + t) * 2], vo, rsP, 0);
+          bload16_async(dst[(i * (NT / 2) + t) * 2], vo, rsP);
           bload16_async_16(dst[(i * (NT / 2) + t) * 2 + 1], vo, rsP);
         }
       }
