@@ -320,34 +320,6 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
   // the tile period is the drain time of its 48 KB (stores + DMA without any MFMA: 2.65-3.0 ms of the 3.15), i.e. the kernel runs
   // at ~85 % of the rate this device COPIES at (5.25 TB/s), not at the 6.9 TB/s it fills at.
   u32x4 pk[MT][NT / 2];
-  auto convert = [&]() {
-    if constexpr (!LN) {
-    auto stage = [&](auto act_c) {
-      constexpr int ACT = decltype(act_c)::value;
-#pragma unroll
-      for (int t = 0; t < NT / 2; ++t)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float x = acc[i][2 * t + (e >> 2)][e & 3] * scr[t][e] + shr[t][e];
-            if constexpr (ACT == MOY_ACT_SILU) x = siluf_(x);
-            else if constexpr (ACT == MOY_ACT_RELU) x = fmaxf(x, 0.f);
-            else if constexpr (ACT == MOY_ACT_SIGMOID) x = fast_sigmoid(x);
-            v[e] = x;
-          }
-          pk[i][t] = u32x4{DT<T>::pack2(v[0], v[1]), DT<T>::pack2(v[2], v[3]), DT<T>::pack2(v[4], v[5]), DT<T>::pack2(v[6], v[7])};
-        }
-    };
-    switch (p.act) {   // wave-uniform
-      case MOY_ACT_SILU: stage(std::integral_constant<int, MOY_ACT_SILU>{}); break;
-      case MOY_ACT_RELU: stage(std::integral_constant<int, MOY_ACT_RELU>{}); break;
-      case MOY_ACT_SIGMOID: stage(std::integral_constant<int, MOY_ACT_SIGMOID>{}); break;
-      default: stage(std::integral_constant<int, MOY_ACT_NONE>{}); break;
-    }
-    }
-  };
   // store k = i * (NT/2) + t of the tile whose first row is m0.  Rows past M fall outside the descriptor's range (or get an
   // out-of-range offset) and are dropped by the range check: the NST stores are unconditional (the counted waits rely on it).
   auto store_piece = [&](auto kc, int m0) {
@@ -379,9 +351,35 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
     }
     }
   };
-  auto store_all = [&](int m0) {
-    [&]<int... Ks>(std::integer_sequence<int, Ks...>) { (store_piece(std::integral_constant<int, Ks>{}, m0), ...); }
-    (std::make_integer_sequence<int, NST>{});
+  // one piece k = i * (NT/2) + t at a time: scale / shift / activation / pack, then its store -- 4 packed registers live, not NST * 4
+  auto convert_store = [&](int m0) {
+    if constexpr (!LN) {
+    auto stage = [&](auto act_c) {
+      constexpr int ACT = decltype(act_c)::value;
+      auto piece = [&](auto kc) {
+        constexpr int k = decltype(kc)::value, i = k / (NT / 2), t = k % (NT / 2);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = acc[i][2 * t + (e >> 2)][e & 3] * scr[t][e] + shr[t][e];
+          if constexpr (ACT == MOY_ACT_SILU) x = siluf_(x);
+          else if constexpr (ACT == MOY_ACT_RELU) x = fmaxf(x, 0.f);
+          else if constexpr (ACT == MOY_ACT_SIGMOID) x = fast_sigmoid(x);
+          v[e] = x;
+        }
+        pk[i][t] = u32x4{DT<T>::pack2(v[0], v[1]), DT<T>::pack2(v[2], v[3]), DT<T>::pack2(v[4], v[5]), DT<T>::pack2(v[6], v[7])};
+        store_piece(kc, m0);
+      };
+      [&]<int... Ks>(std::integer_sequence<int, Ks...>) { (piece(std::integral_constant<int, Ks>{}), ...); }
+      (std::make_integer_sequence<int, NST>{});
+    };
+    switch (p.act) {   // wave-uniform
+      case MOY_ACT_SILU: stage(std::integral_constant<int, MOY_ACT_SILU>{}); break;
+      case MOY_ACT_RELU: stage(std::integral_constant<int, MOY_ACT_RELU>{}); break;
+      case MOY_ACT_SIGMOID: stage(std::integral_constant<int, MOY_ACT_SIGMOID>{}); break;
+      default: stage(std::integral_constant<int, MOY_ACT_NONE>{}); break;
+    }
+    }
   };
   // fragment read: row i*16 + r, chunk (pn*4 + q) ^ r  ==  byte (i*16 + r)*KB + ((pn*64) ^ ((q ^ r) << 4))
   const int rbase = r * KB, xq = ((q ^ r) & SWZ) << 4;
@@ -528,8 +526,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
       }
       // Wave 0's few score stores are not counted below: its wait then also retires that many of the youngest DMA pieces.
     } else {
-      convert();
-      store_all(tile * BM);
+      convert_store(tile * BM);
     }
     stamp(2);
     // tile it+1 must have landed; the younger DMA tiles and the stores issued since stay in flight
