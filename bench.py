@@ -27,6 +27,7 @@ ALG_BYTES_FRAME = {"c2": 0.415e9, "c4": 1.154e9}
 ALG_WEIGHT_BYTES = 0.0257e9
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 matrix peak (same guide)
+MFMA_SUSTAINED_TFLOPS = 2410.0   # what v_mfma_f32_16x16x32_bf16 sustains on this pool (tools/probes/mfma_peak.hip)
 
 
 def parse(argv=None):
@@ -383,6 +384,12 @@ def main(argv=None):
             floors = [max(mm["bytes"] / (HBM_PEAK_GBS * 1e9), mm["flops"] / (MFMA_PEAK_TFLOPS * 1e12)) * 1e3 for mm in eng.meta]
             roof_step["sum_of_launch_floors_ms"] = round(sum(floors), 3)
             roof_step["sum_of_floors_frac"] = round(sum(floors) / max(sum(per), 1e-9), 4)
+            # the same against what THIS device sustains: the copy rate measured above (a stream that reads and writes does not get the
+            # fill rate: DESIGN.md round-3 item 12) and the sustained MFMA rate -- informative, never `roofline.frac`
+            cp = roof_step.get("copy_peak_gbs_measured")
+            if isinstance(cp, float) and cp > 0:
+                sf = [max(mm["bytes"] / (cp * 1e9), mm["flops"] / (MFMA_SUSTAINED_TFLOPS * 1e12)) * 1e3 for mm in eng.meta]
+                roof_step["sum_of_sustained_floors_frac"] = round(sum(sf) / max(sum(per), 1e-9), 4)
             worst_l = max(range(nL), key=lambda i: floors[i] / max(per[i], 1e-9))
             roof_step["max_launch_floor_frac"] = {"name": eng.meta[worst_l]["name"], "frac": round(floors[worst_l] / max(per[worst_l], 1e-9), 4)}
             top = sorted(range(nL), key=lambda i: -per[i])[:8]
