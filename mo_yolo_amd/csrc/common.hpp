@@ -71,6 +71,18 @@ struct DT<f16_t> {
   }
   static __device__ __forceinline__ float lo(uint32_t w) { return h2f((uint16_t)(w & 0xffffu)); }
   static __device__ __forceinline__ float hi(uint32_t w) { return h2f((uint16_t)(w >> 16)); }
+  // acc + half(w) * g in ONE instruction (v_fma_mix_f32 reads the fp16 half itself; same single rounding as convert + v_fma_f32:
+  // the conversion is exact) -- the gather kernels spent a v_cvt_f32_f16 (4.3 cycles, tools/probes/valu_rates.hip) per value on it
+  static __device__ __forceinline__ float fma_lo(uint32_t w, float g, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(w), "v"(g), "v"(acc));
+    return d;
+  }
+  static __device__ __forceinline__ float fma_hi(uint32_t w, float g, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(w), "v"(g), "v"(acc));
+    return d;
+  }
   static __device__ __forceinline__ f32x4 load4(const f16_t* p) {
     u32x2 w = *reinterpret_cast<const u32x2*>(p);
     return f32x4{lo(w.x), hi(w.x), lo(w.y), hi(w.y)};
@@ -87,6 +99,8 @@ struct DT<bf16_t> {
   static constexpr int code = MOY_BF16;
   static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf2(lo, hi); }
   static __device__ __forceinline__ float lo(uint32_t w) { return bflo(w); }
+  static __device__ __forceinline__ float fma_lo(uint32_t w, float g, float acc) { return __builtin_fmaf(bflo(w), g, acc); }
+  static __device__ __forceinline__ float fma_hi(uint32_t w, float g, float acc) { return __builtin_fmaf(bfhi(w), g, acc); }
   static __device__ __forceinline__ float hi(uint32_t w) { return bfhi(w); }
   static __device__ __forceinline__ f32x4 load4(const bf16_t* p) {
     u32x2 w = *reinterpret_cast<const u32x2*>(p);

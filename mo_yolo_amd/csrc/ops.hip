@@ -805,8 +805,8 @@ __global__ __launch_bounds__(256) void msda_planes_kernel(const T* __restrict__ 
       for (int t = 0; t < 2; ++t) {                      // same order of the four corners per sample as the kernel above
         const u32x4 w = tap[pnt][t];
         const float g = wgt[pnt][t];
-        acc[0] += DT<T>::lo(w.x) * g; acc[1] += DT<T>::hi(w.x) * g; acc[2] += DT<T>::lo(w.y) * g; acc[3] += DT<T>::hi(w.y) * g;
-        acc[4] += DT<T>::lo(w.z) * g; acc[5] += DT<T>::hi(w.z) * g; acc[6] += DT<T>::lo(w.w) * g; acc[7] += DT<T>::hi(w.w) * g;
+        acc[0] = DT<T>::fma_lo(w.x, g, acc[0]); acc[1] = DT<T>::fma_hi(w.x, g, acc[1]); acc[2] = DT<T>::fma_lo(w.y, g, acc[2]); acc[3] = DT<T>::fma_hi(w.y, g, acc[3]);
+        acc[4] = DT<T>::fma_lo(w.z, g, acc[4]); acc[5] = DT<T>::fma_hi(w.z, g, acc[5]); acc[6] = DT<T>::fma_lo(w.w, g, acc[6]); acc[7] = DT<T>::fma_hi(w.w, g, acc[7]);
       }
   };
   if constexpr (MODE == 0) {                              // all levels' taps in flight at once
