@@ -15,7 +15,7 @@ for case in range(ncases):
     dt = rng.choice([torch.bfloat16, torch.float16])
     kind = rng.choice(["seed128", "seed256", "k192", "planes", "plain256", "n128k256"])
     H, W = 2 * rng.randint(8, 40), 2 * rng.randint(8, 70)
-    B = 65536 // (H * W) + rng.randint(1, 3)
+    B = (65536 // (H * W) + rng.randint(1, 3)) * int(os.environ.get("WS_SCALE", 1))   # WS_SCALE: long row-tile sequences per block
     M = B * H * W
     if kind == "seed128": N, K = 128, 128
     elif kind == "seed256": N, K = 256, 256
