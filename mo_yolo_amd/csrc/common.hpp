@@ -71,8 +71,8 @@ struct DT<f16_t> {
   }
   static __device__ __forceinline__ float lo(uint32_t w) { return h2f((uint16_t)(w & 0xffffu)); }
   static __device__ __forceinline__ float hi(uint32_t w) { return h2f((uint16_t)(w >> 16)); }
-  // acc + half(w) * g in ONE instruction (v_fma_mix_f32 reads the fp16 half itself; same single rounding as convert + v_fma_f32:
-  // the conversion is exact) -- the gather kernels spent a v_cvt_f32_f16 (4.3 cycles, tools/probes/valu_rates.hip) per value on it
+  // acc + half(w) * g in ONE instruction (v_fma_mix_f32 reads the fp16 half itself; one rounding, as convert + v_fma_f32: the
+  // conversion is exact) -- the gather kernels spent a v_cvt_f32_f16 (4.3 cycles, tools/probes/valu_rates.hip) per value on it
   static __device__ __forceinline__ float fma_lo(uint32_t w, float g, float acc) {
     float d;
     asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(w), "v"(g), "v"(acc));
