@@ -674,10 +674,7 @@ class TrackEngine:
         self.y = torch.zeros(B, Lq, 4 + nc, device=self.dev)
         self.scores = torch.zeros(B, Lq, device=self.dev)
         self.obj_idxes = torch.zeros(B, Lq, device=self.dev, dtype=torch.int64)
-        self.rows = torch.zeros(B, Lq, 6, device=self.dev)
-        self.track_id = torch.zeros(B, Lq, device=self.dev, dtype=torch.int64)
-        self.n_rows = torch.zeros(B, device=self.dev, dtype=torch.int32)
-        self.n_ids = torch.zeros(B, device=self.dev, dtype=torch.int32)
+        self._alloc_result_block(Lq, with_ids=True)
         if not n_max:
             self._add(lib.moy_assign_post, self.logits.data_ptr(), self.boxes.data_ptr(), B, nq, nc,
                       C.c_float(self.score_thresh), C.c_float(self.conf), C.c_float(self.img_wh[0]), C.c_float(self.img_wh[1]),
@@ -789,8 +786,7 @@ class TrackEngine:
                       C.c_float(stride), a_off, A, self.y.data_ptr(), code,
                       meta=dict(name=f"detect_decode M{M}", bytes=M * ((64 + nc) * self._esz + (4 + nc) * 4), flops=0))
             a_off += hh * ww
-        self.rows = torch.zeros(B, self.max_det, 6, device=self.dev)
-        self.n_rows = torch.zeros(B, device=self.dev, dtype=torch.int32)
+        self._alloc_result_block(self.max_det, with_ids=False)
         gain, padx, pady, cw, ch_ = 1.0, 0.0, 0.0, 0.0, 0.0
         if self.orig_hw is not None:                     # ops.scale_boxes, utils/ops.py:116-128
             oh, ow = self.orig_hw
@@ -801,6 +797,40 @@ class TrackEngine:
                   C.c_float(7680.0), C.c_float(gain), C.c_float(padx), C.c_float(pady), C.c_float(cw), C.c_float(ch_),
                   self.rows.data_ptr(), self.n_rows.data_ptr(),
                   meta=dict(name=f"nms B{B} A{A}", bytes=B * (A * (4 + nc) * 4 + self.max_det * 24), flops=0))
+
+    def _alloc_result_block(self, rows_per_frame: int, with_ids: bool):
+        """Everything a predictor reads back per chunk -- rows [B, R, 6] f32 | track_id [B, R] i64 | n_rows [B] i32 | n_ids [B] i32
+        (predict.py:43-94's TrackResults inputs) -- lives in ONE contiguous device block, so that the caller's device-to-host
+        transfer is a single copy (`result_block`; `unpack_result_block` reads a host copy of it).  The reference pays one
+        blocking `.cpu()` per tensor and frame (predict.py:27-76); round 3's predictor paid four per chunk."""
+        B, R = self.B, rows_per_frame
+        o_rows = 0
+        o_tid = o_rows + B * R * 6 * 4
+        o_nr = o_tid + (B * R * 8 if with_ids else 0)
+        o_ni = o_nr + (B * 4 + 7) // 8 * 8
+        end = o_ni + ((B * 4 + 7) // 8 * 8 if with_ids else 0)
+        blk = torch.zeros(end, device=self.dev, dtype=torch.uint8)
+        self.result_block = blk
+        self._result_layout = dict(B=B, R=R, with_ids=with_ids, o_tid=o_tid, o_nr=o_nr, o_ni=o_ni, nbytes=end)
+        self.rows = blk[o_rows:o_tid].view(torch.float32).view(B, R, 6)
+        self.n_rows = blk[o_nr:o_nr + B * 4].view(torch.int32)
+        if with_ids:
+            self.track_id = blk[o_tid:o_nr].view(torch.int64).view(B, R)
+            self.n_ids = blk[o_ni:o_ni + B * 4].view(torch.int32)
+
+    def unpack_result_block(self, host_block):
+        """Views (numpy) of a HOST copy of `result_block`: rows, track_id (or None), n_rows, n_ids (or None)."""
+        import numpy as np
+        lay = self._result_layout
+        a = host_block.numpy() if isinstance(host_block, torch.Tensor) else host_block
+        B, R = lay["B"], lay["R"]
+        rows = a[:lay["o_tid"]].view(np.float32).reshape(B, R, 6)
+        n_rows = a[lay["o_nr"]:lay["o_nr"] + 4 * B].view(np.int32)
+        if not lay["with_ids"]:
+            return rows, None, n_rows, None
+        tid = a[lay["o_tid"]:lay["o_nr"]].view(np.int64).reshape(B, R)
+        n_ids = a[lay["o_ni"]:lay["o_ni"] + 4 * B].view(np.int32)
+        return rows, tid, n_rows, n_ids
 
     def _score_runs(self, valid_host):
         """Round 3: the score pass over the VALID tokens only.  A masked token's enc_output feature is LN(enc_output.bias) whatever

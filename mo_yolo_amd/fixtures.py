@@ -18,6 +18,9 @@ CONFIGS = {
     # yolo_track.yaml AS SHIPPED (depth 1.0 / width 1.0, the scale the reference's own entry script uses: start_train.py:11,
     # cfg/models/v8/yolo_track.yaml:11-12; 46 M parameters) at a small resolution: the widths no specialised kernel covers
     "full": dict(depth=1.0, width=1.0, nc=1, H=128, W=192, nq=60, seed=0, style="mot17", frames=2),
+    # the same 46 M-parameter weights at the headline resolution and query count: a TIMING configuration (bench.py --config full);
+    # its calibration overlay is "full"'s (BatchNorm statistics and score heads found at 128 x 192), no golden of its own
+    "full_c2": dict(depth=1.0, width=1.0, nc=1, H=608, W=1088, nq=300, seed=0, style="mot17", frames=0, calib="full"),
 }
 
 
@@ -27,5 +30,5 @@ def fixture(name: str):
     cfg = dict(CONFIGS[name], name=name)
     arch = build_arch(cfg["depth"], cfg["width"], cfg["nc"], cfg["nq"])
     sd = make_fixture_state_dict(arch, cfg["seed"])
-    apply_calibration(sd, name)
+    apply_calibration(sd, cfg.get("calib", name))
     return cfg, arch, sd

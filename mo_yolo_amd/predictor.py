@@ -48,15 +48,45 @@ class TrackResults:
                 f.writelines(t + "\n" for t in lines)
 
 
+class _HostRing:
+    """Pinned host staging of the predictor's stream loop: `depth` frame buffers in (one chunk each) and `depth` result
+    blocks out.  A buffer is reused only after the transfer that read / wrote it has completed (its event)."""
+
+    def __init__(self, depth, in_shape, in_dtype, out_bytes):
+        self.depth = depth
+        self.inp = [torch.empty(in_shape, dtype=in_dtype).pin_memory() for _ in range(depth)]
+        self.out = [torch.empty(out_bytes, dtype=torch.uint8).pin_memory() for _ in range(depth)]
+        self.h2d_done = [None] * depth
+        self.d2h_done = [None] * depth
+
+
+def _stage(dst: torch.Tensor, src: np.ndarray, threads: int = 4):
+    """Pageable frames -> pinned staging buffer (numpy releases the GIL in the copy, so a few threads reach the host's copy rate)."""
+    d = dst.numpy()
+    k = src.shape[0]
+    if k * src[0].nbytes < (8 << 20) or threads <= 1:
+        np.copyto(d[:k], src)
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    cuts = [k * i // threads for i in range(threads + 1)]
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(lambda ab: np.copyto(d[ab[0]:ab[1]], src[ab[0]:ab[1]]), zip(cuts[:-1], cuts[1:])))
+
+
 class TrackPredictor:
     def __init__(self, arch, state_dict, imgsz=(608, 1088), conf=0.25, dtype=torch.float32, device="cuda", batch=1,
-                 graph=False, temporal=0):
+                 graph=False, temporal=0, ring=3):
         """`temporal` = track slots per sequence (0: the shipped per-frame-reset semantics).  In temporal mode the `batch`
         frames of a chunk are ONE time step of `batch` sequences running in lockstep (source order t0s0, t0s1, ..., t1s0, ...);
-        call `reset_sequences()` at the start of new videos (`is_first`, head.py:199-205)."""
+        call `reset_sequences()` at the start of new videos (`is_first`, head.py:199-205).
+        `ring` = depth of the host-fed pipeline (round 4): pinned staging buffers, device input slots and pinned result
+        blocks; chunk j+1 is copied in on a copy stream while chunk j computes, and chunk j's results (ONE packed
+        device-to-host copy: rows | ids | counts) are read on the host while chunk j+1 computes."""
         self.arch, self.sd, self.imgsz, self.conf, self.dtype, self.device = arch, state_dict, tuple(imgsz), conf, dtype, device
-        self.batch, self.graph, self.temporal = batch, graph, int(temporal)
+        self.batch, self.graph, self.temporal, self.ring = batch, graph, int(temporal), max(2, int(ring))
         self._engines = {}
+        self._rings = {}
+        self._copy_stream = None
 
     def reset_sequences(self, which=None):
         for eng in self._engines.values():
@@ -66,20 +96,32 @@ class TrackPredictor:
         key = (fmt, tuple(orig_hw or self.imgsz))
         if key not in self._engines:
             H, W = self.imgsz
+            resized = fmt == "u8" and key[1] != self.imgsz
             eng = TrackEngine(self.arch, self.sd, H, W, batch=self.batch, dtype=self.dtype, device=self.device,
-                              input_format=fmt, conf=self.conf, scale_boxes=(fmt == "u8"), orig_hw=key[1], temporal=self.temporal)
+                              input_format=fmt, conf=self.conf, scale_boxes=(fmt == "u8"), orig_hw=key[1], temporal=self.temporal,
+                              n_inputs=1 if resized else self.ring)
             if self.graph:
                 eng.forward(torch.zeros_like(eng.input))
                 eng.capture()
                 eng.reset_sequence()                      # the warm-up frames must not leave tracks behind
             self._engines[key] = eng
+            if fmt == "u8":
+                oh, ow = key[1]
+                ring = _HostRing(self.ring, (self.batch, oh, ow, 3), torch.uint8, eng.result_block.numel())
+                # frames of another size land in device staging buffers first and are stretch-resized into the engine's input
+                ring.dev_in = ([torch.empty(self.batch, oh, ow, 3, dtype=torch.uint8, device=eng.dev) for _ in range(self.ring)]
+                               if resized else eng.inputs)
+                ring.compute_done = [None] * self.ring
+                ring.resized = resized
+                self._rings[key] = ring
         return self._engines[key]
 
     def preprocess(self, im):
         """List of uint8 BGR HWC frames (any size) or float [B,3,H,W] in [0,1] at network resolution.
         Frames of another size are stretch-resized on the device like `pre_transform` does with
         LetterBox(scaleFill) (MOTRtrack/predict.py:96-105, data/augment.py:573-576: cv2 INTER_LINEAR, no padding);
-        the BGR->RGB / CHW / float / 255 arithmetic of predictor.py:125-133 is fused into the stem kernel."""
+        the BGR->RGB / CHW / float / 255 arithmetic of predictor.py:125-133 is fused into the stem kernel.
+        uint8 frames stay on the HOST here: `__call__` moves them chunk by chunk through the pinned ring."""
         if isinstance(im, torch.Tensor):
             if im.dim() != 4 or im.shape[1] != 3 or tuple(im.shape[2:]) != self.imgsz:
                 raise ValueError(f"tensor source must be [B,3,{self.imgsz[0]},{self.imgsz[1]}]")
@@ -89,35 +131,88 @@ class TrackPredictor:
         arr = np.stack(im) if not isinstance(im, np.ndarray) else im
         if arr.dtype != np.uint8 or arr.ndim != 4 or arr.shape[3] != 3:
             raise ValueError("frame source must be uint8 [B,H,W,3] BGR (frames of one size)")
-        return torch.from_numpy(np.ascontiguousarray(arr)).to(self.device), "u8"
+        return np.ascontiguousarray(arr), "u8"
+
+    def _results_of(self, eng, host_block, k, orig_hw, paths, s):
+        rows, tid, n_rows, n_ids = eng.unpack_result_block(host_block)
+        res = []
+        for b in range(k):
+            t = None if n_ids[b] < 0 else tid[b, :n_ids[b]].copy()
+            res.append(TrackResults(rows[b, :n_rows[b]].copy(), t, orig_hw, path=(paths[s + b] if paths else "")))
+        return res
 
     @torch.no_grad()
     def __call__(self, source, paths: Sequence[str] | None = None) -> List[TrackResults]:
         x, fmt = self.preprocess(source)
         orig_hw = tuple(x.shape[1:3]) if fmt == "u8" else self.imgsz
         eng = self._engine(fmt, orig_hw)
-        results: List[TrackResults] = []
         n = x.shape[0]
         if self.temporal and n % self.batch:
             # batch element b is SEQUENCE b with persistent query memory: padding a short chunk with another sequence's frame
             # would advance the memory, id counter and miss counters of the padded sequences
             raise ValueError(f"temporal mode: the source must hold whole time steps ({self.batch} sequences per step), got {n} frames")
+        if fmt == "u8":
+            return self._run_host_fed(eng, x, orig_hw, paths)
+        # float tensor source (LoadTensor, data/loaders.py:316-332): already on the device; one packed result copy per chunk
+        results: List[TrackResults] = []
         for s in range(0, n, self.batch):
             chunk = x[s:s + self.batch]
             k = chunk.shape[0]
             if k < self.batch:                                     # ragged tail (per-frame mode only): pad with the last frame
                 chunk = torch.cat([chunk, chunk[-1:].expand(self.batch - k, *chunk.shape[1:])], 0)
-            if fmt == "u8" and orig_hw != self.imgsz:
-                ops.resize_linear_u8(chunk.contiguous(), self.imgsz, out=eng.input)
-                out = eng.forward(None)
+            eng.forward(chunk.contiguous())
+            results += self._results_of(eng, eng.result_block.cpu(), k, orig_hw, paths, s)
+        return results
+
+    def _run_host_fed(self, eng, x: np.ndarray, orig_hw, paths):
+        """The stream loop of `BasePredictor.stream_inference` (engine/predictor.py:256-344) for host frames, pipelined:
+        [stage chunk j+1 into pinned memory + H2D on the copy stream] || [chunk j on the device] || [read chunk j-1's rows].
+        The reference does `im.to(device)` from pageable memory and a `.cpu()` per result tensor, all blocking (predictor.py:130,
+        predict.py:27-76)."""
+        ring = self._rings[("u8", tuple(orig_hw))]
+        dev = eng.dev
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=dev)
+        cs, main = self._copy_stream, torch.cuda.current_stream(dev)
+        n, B, D = x.shape[0], self.batch, ring.depth
+        results: List[TrackResults] = []
+        pending = None                                             # (ring index, k, s) of the chunk whose results are in flight
+        for j, s in enumerate(range(0, n, B)):
+            r = j % D
+            k = min(B, n - s)
+            if ring.h2d_done[r] is not None:
+                ring.h2d_done[r].synchronize()                     # the transfer that last read this staging buffer
+            _stage(ring.inp[r], x[s:s + k])
+            if k < B:                                              # ragged tail (per-frame mode only): pad with the last frame
+                ring.inp[r].numpy()[k:] = x[s + k - 1]
+            with torch.cuda.stream(cs):
+                if ring.compute_done[r] is not None:
+                    cs.wait_event(ring.compute_done[r])            # the step that last read this device slot
+                ring.dev_in[r].copy_(ring.inp[r], non_blocking=True)
+                ring.h2d_done[r] = torch.cuda.Event()
+                ring.h2d_done[r].record(cs)
+            main.wait_event(ring.h2d_done[r])
+            if ring.resized:
+                ops.resize_linear_u8(ring.dev_in[r], self.imgsz, out=eng.input)
+                eng.forward(None)
             else:
-                out = eng.forward(chunk.contiguous())
-            rows, tid = out["rows"].cpu().numpy(), out["track_id"].cpu().numpy()
-            n_rows, n_ids = out["n_rows"].cpu().numpy(), out["n_ids"].cpu().numpy()
-            for b in range(k):
-                t = None if n_ids[b] < 0 else tid[b, :n_ids[b]].copy()
-                results.append(TrackResults(rows[b, :n_rows[b]].copy(), t, orig_hw,
-                                            path=(paths[s + b] if paths else "")))
+                eng.forward(None, slot=r)
+            ring.compute_done[r] = torch.cuda.Event()
+            ring.compute_done[r].record(main)
+            if ring.d2h_done[r] is not None:
+                ring.d2h_done[r].synchronize()
+            ring.out[r].copy_(eng.result_block, non_blocking=True)     # ONE device-to-host copy per chunk
+            ring.d2h_done[r] = torch.cuda.Event()
+            ring.d2h_done[r].record(main)
+            if pending is not None:
+                pr, pk, ps = pending
+                ring.d2h_done[pr].synchronize()
+                results += self._results_of(eng, ring.out[pr], pk, orig_hw, paths, ps)
+            pending = (r, k, s)
+        if pending is not None:
+            pr, pk, ps = pending
+            ring.d2h_done[pr].synchronize()
+            results += self._results_of(eng, ring.out[pr], pk, orig_hw, paths, ps)
         return results
 
 
@@ -144,7 +239,7 @@ class DetectionPredictor:
             k = chunk.shape[0]
             if k < self.batch:
                 chunk = torch.cat([chunk, chunk[-1:].expand(self.batch - k, *chunk.shape[1:])], 0)
-            out = self.eng.forward(chunk.contiguous())
-            rows, n = out["rows"].cpu().numpy(), out["n_rows"].cpu().numpy()
+            self.eng.forward(chunk.contiguous())
+            rows, _, n, _ = self.eng.unpack_result_block(self.eng.result_block.cpu())     # one device-to-host copy per chunk
             res += [rows[b, :n[b]].copy() for b in range(k)]
         return res

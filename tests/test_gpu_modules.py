@@ -317,6 +317,47 @@ def test_predictor_stretch_resizes_foreign_frame_sizes():
                                [[float(v) for v in l.split()] for l in w.txt_lines()], atol=1e-5)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_predictor_host_ring_equals_resident_frames_bit_for_bit(dt):
+    """the host-fed pipeline (pageable frames -> pinned ring -> H2D on a copy stream -> input slot j % ring ->
+    step -> ONE packed device-to-host copy) returns exactly what the engine computes on frames already resident in HBM: same
+    rows, same ids, same counts, bit for bit, over more chunks than the ring is deep and with a ragged tail
+    (engine/predictor.py:117-134, 256-344)."""
+    from mo_yolo_amd.engine import TrackEngine
+    cfg, arch, sd = fixture("tiny")
+    Bc, T = 3, 17                                                       # 6 chunks through a ring of 3; the last holds 2 frames
+    frames = SyntheticSequence(2, cfg["H"], cfg["W"]).frames(0, T)
+    pred = TrackPredictor(arch, sd, imgsz=(cfg["H"], cfg["W"]), conf=0.25, batch=Bc, graph=True, dtype=dt, ring=3)
+    got = pred(frames, paths=[f"f{t}" for t in range(T)])
+    assert len(got) == T and [r.path for r in got] == [f"f{t}" for t in range(T)]
+    eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=Bc, dtype=dt, orig_hw=(cfg["H"], cfg["W"]))
+    dev = torch.from_numpy(frames).cuda()
+    n_act = 0
+    for s in range(0, T, Bc):
+        chunk = dev[s:s + Bc]
+        k = chunk.shape[0]
+        if k < Bc:
+            chunk = torch.cat([chunk, chunk[-1:].expand(Bc - k, *chunk.shape[1:])])
+        o = eng.forward(chunk.contiguous())
+        torch.cuda.synchronize()
+        rows, tid, nr, ni = (o[key].cpu().numpy() for key in ("rows", "track_id", "n_rows", "n_ids"))
+        for b in range(k):
+            r = got[s + b]
+            assert np.array_equal(r.boxes.view(np.uint32), rows[b, :nr[b]].view(np.uint32))         # bit for bit
+            assert (r.track_id is None) == (ni[b] < 0)
+            if r.track_id is not None:
+                assert np.array_equal(r.track_id, tid[b, :ni[b]])
+                n_act += len(r.track_id)
+    assert n_act > 0
+    # a second call reuses the ring (events of the previous call still attached to its buffers)
+    again = pred(frames[:7])
+    assert all(np.array_equal(a.boxes, b.boxes) for a, b in zip(again, got[:7]))
+    # the packed block is what the separate tensors alias: one copy carries all four
+    r2, t2, n2, i2 = eng.unpack_result_block(eng.result_block.cpu())
+    assert np.array_equal(r2, eng.rows.cpu().numpy()) and np.array_equal(t2, eng.track_id.cpu().numpy())
+    assert np.array_equal(n2, eng.n_rows.cpu().numpy()) and np.array_equal(i2, eng.n_ids.cpu().numpy())
+
+
 def test_box_iou_vs_validator_formula():
     """moy_box_iou vs `_calculate_box_ious` (val.py:517-553) incl. degenerate boxes, ragged frames and empty sides."""
     from mo_yolo_amd import ops

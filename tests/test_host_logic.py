@@ -139,6 +139,17 @@ def test_bench_control_flow_c3_eight_ranks_gloo_dry_run():
     assert [e["hip_visible_devices"] for e in rm] == [str(i) for i in range(8)]      # one GPU per rank, pinned before HIP starts
     assert [e["sequences"] for e in rm] == [[i] for i in range(8)]                   # sequence i -> rank i, nothing shared
     assert abs(d["value"] - 576 * 4 * 8 / (d["ms_per_step"] * 4 * 1e-3)) < 1e-4 * d["value"]
+    # the per-rank table that makes the first hardware run diagnosable -- 8 distinct devices, 8 sequences, 8 timings
+    rk = d["config"]["ranks"]
+    assert [e["rank"] for e in rk] == list(range(8)) and [e["local_rank"] for e in rk] == list(range(8))
+    assert len({e["hip_visible_devices"] for e in rk}) == 8
+    assert sorted(sq for e in rk for sq in e["sequences"]) == list(range(8))
+    assert all(e["dt_local_s"] > 0 and e["fps_local"] > 0 for e in rk)
+    assert max(e["dt_local_s"] for e in rk) <= d["ms_per_step"] * 4 * 1e-3 * 1.0001       # the line's time is the MAX over ranks
+    cpus = [e["cpus"] for e in rk]
+    assert all(c for c in cpus)
+    if len(os.sched_getaffinity(0)) >= 16:
+        assert len(set(cpus)) == 8                                # every rank pinned its own slice of the host cores
 
 
 def test_bench_pins_one_device_per_local_rank(monkeypatch):
