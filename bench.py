@@ -66,6 +66,7 @@ def parse(argv=None):
     ap.add_argument("--predictor", action="store_true",
                     help="time the PRODUCT entry point instead of the engine: TrackPredictor.__call__ on host uint8 frames (pinned ring in, "
                          "one packed device-to-host copy of the rows out, TrackResults built on the host)")
+    ap.add_argument("--pinned-source", action="store_true", help="--predictor: the caller's frames already lie in page-locked memory")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="default C2 run at N=1 appends the other workloads (child processes, 20 steps each) under `extra`")
     return ap.parse_args(argv)
@@ -196,6 +197,23 @@ def copy_peak_gbs(dev):
     return 2 * n / (ms * 1e-3) / 1e9
 
 
+def h2d_peak_gbs(dev):
+    """Box-measured host-to-device rate: 1 GiB from pinned host memory, hipMemcpyAsync on the current stream."""
+    import torch
+    n = 1 << 30
+    h = torch.empty(n, dtype=torch.uint8).pin_memory()
+    d = torch.empty(n, dtype=torch.uint8, device=dev)
+    d.copy_(h, non_blocking=True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        d.copy_(h, non_blocking=True)
+    e1.record()
+    torch.cuda.synchronize()
+    return n / (e0.elapsed_time(e1) / 3 * 1e-3) / 1e9
+
+
 def log(msg):
     """Progress on stderr (a long silent run is taken to be hung by the GPU pool's watchdog)."""
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -302,12 +320,18 @@ def main(argv=None):
             from mo_yolo_amd.predictor import TrackPredictor
             pipe = None
             pred = TrackPredictor(arch, sd, imgsz=(cfg["H"], cfg["W"]), dtype=dtype, device=dev, batch=B, graph=not a.no_graph)
-            n_chunks = 3
-            host_frames = torch.cat([batch_frames(k).cpu() for k in range(n_chunks)]).numpy()
+            n_chunks = 6
+            host_frames = torch.cat([batch_frames(k % 2).cpu() for k in range(n_chunks)])
+            if a.pinned_source:
+                host_frames = host_frames.pin_memory()               # a decoder that writes into page-locked memory: no staging copy
+            else:
+                host_frames = host_frames.numpy()
             pred(host_frames[:B])                                # builds the engine, the ring and the graphs
             eng = next(iter(pred._engines.values()))
-            line_extra["predictor"] = (f"TrackPredictor.__call__ on {n_chunks * B} pageable host frames per step (chunks of {B}): stage into "
-                                       "pinned ring -> H2D on a copy stream -> step -> ONE packed D2H -> TrackResults on the host")
+            line_extra["predictor"] = (f"TrackPredictor.__call__ on {n_chunks * B} host frames per step (chunks of {B}), source = "
+                                       + ("one PINNED uint8 tensor (no staging copy)" if a.pinned_source else
+                                          "a pageable numpy array (staged into the pinned ring by 8 host threads)")
+                                       + " -> H2D on a copy stream -> step -> ONE packed D2H -> TrackResults on the host")
             n_results = [0]
 
             def step(i):
@@ -412,6 +436,15 @@ def main(argv=None):
 
     roof = roof_step = parity = None
     cpu = None
+    if rank == 0 and not a.dry_run and (a.from_host or a.predictor):
+        # what crossed the host link inside the timed region, next to what the link of THIS box moves when it does nothing else
+        fb = (hs * ws * 3) if a.from_host else cfg["H"] * cfg["W"] * 3
+        try:
+            link = round(h2d_peak_gbs(dev), 1)
+        except Exception as e:  # pragma: no cover
+            link = repr(e)
+        line_extra["host_link"] = {"h2d_gbs_in_timed_region": round(fps / world * fb / 1e9, 2), "h2d_peak_gbs_measured": link,
+                                   "bytes_per_frame": fb, "spec": "PCIe Gen5 x16, 63 GB/s per direction (MI355X_MICROARCH.md)"}
     if rank == 0 and not a.dry_run:
         out = eng.outputs()
         Bs = eng.B
@@ -638,6 +671,7 @@ def main(argv=None):
                 ("c2_bf16_from_host", ["--from-host"], 20),
                 ("c2_bf16_from_host_1080p_resize", ["--from-host", "--resize-from", "1080x1920"], 20),
                 ("c2_bf16_predictor", ["--predictor"], 5),
+                ("c2_bf16_predictor_pinned_source", ["--predictor", "--pinned-source"], 5),
                 ("c2_bf16_sustained_200_steps", [], 200))
         for name, flags, nsteps in legs:
             log(f"extra leg {name}")
@@ -650,7 +684,7 @@ def main(argv=None):
                 d = json.loads(lines[-1])
                 extra[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
                                "dtype": d["dtype"], "workload": d["config"]["workload"], "parity": d.get("parity"), "rc": r.returncode}
-                for key in ("from_host", "predictor", "resize_from"):
+                for key in ("from_host", "predictor", "resize_from", "host_link"):
                     if key in d["config"]:
                         extra[name][key] = d["config"][key]
                 if d.get("roofline"):
@@ -665,7 +699,7 @@ def main(argv=None):
                     pass
             except Exception as e:  # a failing leg must not lose the headline line
                 extra[name] = {"error": repr(e)[:300]}
-        for name in ("c2_bf16_from_host", "c2_bf16_predictor", "c2_bf16_sustained_200_steps"):
+        for name in ("c2_bf16_from_host", "c2_bf16_predictor", "c2_bf16_predictor_pinned_source", "c2_bf16_sustained_200_steps"):
             if "value" in extra.get(name, {}):
                 extra[name]["vs_resident_headline"] = round(extra[name]["value"] / fps, 4)
 

@@ -8,6 +8,7 @@ in, rows out, and formats text.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Sequence
 
 import numpy as np
@@ -60,10 +61,14 @@ class _HostRing:
         self.d2h_done = [None] * depth
 
 
-def _stage(dst: torch.Tensor, src: np.ndarray, threads: int = 4):
+def _stage(dst: torch.Tensor, src: np.ndarray, threads: int = 8):
     """Pageable frames -> pinned staging buffer (numpy releases the GIL in the copy, so a few threads reach the host's copy rate)."""
     d = dst.numpy()
     k = src.shape[0]
+    try:
+        threads = max(1, min(threads, len(os.sched_getaffinity(0)), k))
+    except AttributeError:      # pragma: no cover
+        threads = max(1, min(threads, k))
     if k * src[0].nbytes < (8 << 20) or threads <= 1:
         np.copyto(d[:k], src)
         return
@@ -122,6 +127,12 @@ class TrackPredictor:
         LetterBox(scaleFill) (MOTRtrack/predict.py:96-105, data/augment.py:573-576: cv2 INTER_LINEAR, no padding);
         the BGR->RGB / CHW / float / 255 arithmetic of predictor.py:125-133 is fused into the stem kernel.
         uint8 frames stay on the HOST here: `__call__` moves them chunk by chunk through the pinned ring."""
+        if isinstance(im, torch.Tensor) and im.dtype == torch.uint8 and not im.is_cuda:
+            # host uint8 frames handed over as a tensor; a PINNED one (a decoder that writes straight into page-locked memory)
+            # skips the staging copy: its chunks cross the link from where they lie
+            if im.dim() != 4 or im.shape[3] != 3 or not im.is_contiguous():
+                raise ValueError("frame source must be contiguous uint8 [B,H,W,3] BGR (frames of one size)")
+            return im, "u8"
         if isinstance(im, torch.Tensor):
             if im.dim() != 4 or im.shape[1] != 3 or tuple(im.shape[2:]) != self.imgsz:
                 raise ValueError(f"tensor source must be [B,3,{self.imgsz[0]},{self.imgsz[1]}]")
@@ -164,7 +175,7 @@ class TrackPredictor:
             results += self._results_of(eng, eng.result_block.cpu(), k, orig_hw, paths, s)
         return results
 
-    def _run_host_fed(self, eng, x: np.ndarray, orig_hw, paths):
+    def _run_host_fed(self, eng, x, orig_hw, paths):
         """The stream loop of `BasePredictor.stream_inference` (engine/predictor.py:256-344) for host frames, pipelined:
         [stage chunk j+1 into pinned memory + H2D on the copy stream] || [chunk j on the device] || [read chunk j-1's rows].
         The reference does `im.to(device)` from pageable memory and a `.cpu()` per result tensor, all blocking (predictor.py:130,
@@ -175,20 +186,24 @@ class TrackPredictor:
             self._copy_stream = torch.cuda.Stream(device=dev)
         cs, main = self._copy_stream, torch.cuda.current_stream(dev)
         n, B, D = x.shape[0], self.batch, ring.depth
+        pinned_src = isinstance(x, torch.Tensor) and x.is_pinned()
+        xn = x.numpy() if isinstance(x, torch.Tensor) else x
         results: List[TrackResults] = []
         pending = None                                             # (ring index, k, s) of the chunk whose results are in flight
         for j, s in enumerate(range(0, n, B)):
             r = j % D
             k = min(B, n - s)
-            if ring.h2d_done[r] is not None:
-                ring.h2d_done[r].synchronize()                     # the transfer that last read this staging buffer
-            _stage(ring.inp[r], x[s:s + k])
-            if k < B:                                              # ragged tail (per-frame mode only): pad with the last frame
-                ring.inp[r].numpy()[k:] = x[s + k - 1]
+            direct = pinned_src and k == B                         # a whole chunk in page-locked memory: no staging copy
+            if not direct:
+                if ring.h2d_done[r] is not None:
+                    ring.h2d_done[r].synchronize()                 # the transfer that last read this staging buffer
+                _stage(ring.inp[r], xn[s:s + k])
+                if k < B:                                          # ragged tail (per-frame mode only): pad with the last frame
+                    ring.inp[r].numpy()[k:] = xn[s + k - 1]
             with torch.cuda.stream(cs):
                 if ring.compute_done[r] is not None:
                     cs.wait_event(ring.compute_done[r])            # the step that last read this device slot
-                ring.dev_in[r].copy_(ring.inp[r], non_blocking=True)
+                ring.dev_in[r].copy_(x[s:s + B] if direct else ring.inp[r], non_blocking=True)
                 ring.h2d_done[r] = torch.cuda.Event()
                 ring.h2d_done[r].record(cs)
             main.wait_event(ring.h2d_done[r])

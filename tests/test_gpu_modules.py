@@ -352,6 +352,10 @@ def test_predictor_host_ring_equals_resident_frames_bit_for_bit(dt):
     # a second call reuses the ring (events of the previous call still attached to its buffers)
     again = pred(frames[:7])
     assert all(np.array_equal(a.boxes, b.boxes) for a, b in zip(again, got[:7]))
+    # frames that already lie in page-locked memory cross the link from where they are (no staging copy): same results
+    pinned = pred(torch.from_numpy(frames).pin_memory())
+    assert len(pinned) == T and all(np.array_equal(a.boxes, b.boxes) and np.array_equal(a.track_id, b.track_id)
+                                    for a, b in zip(pinned, got) if b.track_id is not None)
     # the packed block is what the separate tensors alias: one copy carries all four
     r2, t2, n2, i2 = eng.unpack_result_block(eng.result_block.cpu())
     assert np.array_equal(r2, eng.rows.cpu().numpy()) and np.array_equal(t2, eng.track_id.cpu().numpy())
