@@ -346,7 +346,7 @@ def main(argv=None):
             torch.cuda.synchronize()
             pipe.forward(slot=0)                          # first call: eager pass + graph capture
             torch.cuda.synchronize()
-            if a.resize_from:
+            if a.resize_from and not a.from_host:
                 # camera-resolution frames resident in HBM (one source slot per engine: the same pixels every step; only their
                 # SIZE matters to the resize kernel), resized on each engine's stream into the input slot its graph then reads
                 from mo_yolo_amd import ops as _ops
@@ -380,15 +380,20 @@ def main(argv=None):
                 copied = [[None] * n_slots for _ in pipe.engines]      # event: the slot's frames have arrived
                 consumed = [[None] * n_slots for _ in pipe.engines]    # event: the step that read the slot has finished
 
+                copy_timing = []                                        # (start, end) timed events around every copy: the link rate as observed
+
                 def enqueue_copy(k, slot):
                     cs = copy_streams[k]
                     with torch.cuda.stream(cs):
                         if consumed[k][slot] is not None:
                             cs.wait_event(consumed[k][slot])
+                        e0 = torch.cuda.Event(enable_timing=True)
+                        e0.record(cs)
                         stage[k][slot].copy_(host[k][slot], non_blocking=True)
-                        ev = torch.cuda.Event()
+                        ev = torch.cuda.Event(enable_timing=True)
                         ev.record(cs)
                         copied[k][slot] = ev
+                        copy_timing.append((e0, ev))
 
                 for k in range(len(pipe.engines)):
                     enqueue_copy(k, 0)
@@ -443,6 +448,11 @@ def main(argv=None):
             link = round(h2d_peak_gbs(dev), 1)
         except Exception as e:  # pragma: no cover
             link = repr(e)
+        if a.from_host:
+            cms = [e0.elapsed_time(e1) for e0, e1 in copy_timing[-2 * a.steps:]]
+            line_extra["host_copies"] = {"copies_timed": len(cms), "bytes_each": int(host[0][0].numel()),
+                                         "ms_each_mean": round(sum(cms) / len(cms), 3), "ms_each_min": round(min(cms), 3),
+                                         "gbs_each_mean": round(host[0][0].numel() / (sum(cms) / len(cms) * 1e-3) / 1e9, 2)}
         line_extra["host_link"] = {"h2d_gbs_in_timed_region": round(fps / world * fb / 1e9, 2), "h2d_peak_gbs_measured": link,
                                    "bytes_per_frame": fb, "spec": "PCIe Gen5 x16, 63 GB/s per direction (MI355X_MICROARCH.md)"}
     if rank == 0 and not a.dry_run:
@@ -571,6 +581,13 @@ def main(argv=None):
             # (a 32-frame window is not the stream mean: frames 8..39 of sequence 0 measure 8.4 % for bf16 -- deterministic, the same
             # on every device -- so the bars are 1.4 x that window and 2 x the fp16 one; eager torch bf16 on this network: 16.6 %)
             bars = {"f32": (1e-4, 1e-3, 1e-3, 0.0), "f16": (5e-3, 0.6, 0.16, 0.03), "bf16": (9e-3, 1.3, 0.4, 0.12)}[dtype_name]
+            # round 4 (VERDICT r3 #3c): where this exact window has a committed measurement (profiles/r03_f_bench_*.json -- the window
+            # is deterministic: same frames, same kernels, no atomics), the bar is 1.5 x THAT measurement, so that a 2 x regression of
+            # the 16-bit path fails:          box      hs     score   births / active
+            measured = {("c2", "bf16"): (4.12e-3, 0.626, 0.140, 0.0849), ("c2", "f16"): (1.00e-3, 0.115, 0.0256, 0.0153),
+                        ("c4", "bf16"): (5.68e-3, 0.697, 0.0693, 0.0403)}.get((cfg_name, dtype_name))
+            if measured is not None:
+                bars = tuple(round(1.5 * v, 5) for v in measured)
             st_ = parity["bench_engine_vs_fp32_engine"]
             parity["bars"] = {"box_matched": bars[0], "hs_matched": bars[1], "score_matched": bars[2], "birth_flip_frac_of_active": bars[3]}
             parity["ok"] = bool(st_["box_max_err_matched"] <= bars[0] and st_["hs_max_err_matched"] <= bars[1]
@@ -631,6 +648,8 @@ def main(argv=None):
                               "live_tracks": [int(v) for v in go["n_tracks"]], "live_tracks_fp32": [int(v) for v in wo["n_tracks"]]})
             eng.reset_sequence()
             bars = {"f32": (1e-4, 1e-3, 1e-3, 0.0), "f16": (5e-3, 0.6, 0.16, 0.03), "bf16": (9e-3, 1.3, 0.4, 0.1)}[dtype_name]
+            if (cfg_name, dtype_name, a.temporal, B) == ("c2", "bf16", 100, 32):     # 1.5 x profiles/r03_f_bench_c2_temporal100.json
+                bars = (4.5e-3, 0.5, 0.184, 0.052)
             frac = flips / max(1, active)
             parity = {"temporal": True, "steps": steps, "detect_rows_vs_fp32": dict(worst, births_flipped=flips, active_rows_reference=active,
                                                                                     birth_flip_frac_of_active=round(frac, 5)),
@@ -684,7 +703,7 @@ def main(argv=None):
                 d = json.loads(lines[-1])
                 extra[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
                                "dtype": d["dtype"], "workload": d["config"]["workload"], "parity": d.get("parity"), "rc": r.returncode}
-                for key in ("from_host", "predictor", "resize_from", "host_link"):
+                for key in ("from_host", "predictor", "resize_from", "host_link", "host_copies"):
                     if key in d["config"]:
                         extra[name][key] = d["config"][key]
                 if d.get("roofline"):

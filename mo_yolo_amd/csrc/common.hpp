@@ -186,6 +186,8 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // gemm_wreg.hip: weight-stationary kernel for K == 256 (MOY_ENOSYS when the shape is not its own)
 int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st);
+// gemm_dma.hip: 256-row tiles, both operands by LDS-DMA, for the matrix-rate-bound products (MOY_ENOSYS when the shape is not its own)
+int gemm_dma_try(const moy_gemm_args* a, hipStream_t st);
 // conv_ws.hip: persistent weight-stationary direct 3x3 convolution (MOY_ENOSYS when the shape is not its own)
 int conv_ws_try(const moy_gemm_args* a, hipStream_t st);
 

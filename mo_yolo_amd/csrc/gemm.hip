@@ -1013,6 +1013,10 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
     const int rc = conv_ws_try(a, st);
     if (rc != MOY_ENOSYS) return rc;
   }
+  if (a->dtype != MOY_F32 && !ln) {          // deep K, N % 128 == 0, enough tiles: 256-row tiles through an LDS-DMA pipeline (gemm_dma.hip)
+    const int rc = gemm_dma_try(a, st);
+    if (rc != MOY_ENOSYS) return rc;
+  }
   if (a->ksize == 3 && a->dtype != MOY_F32) {
     const int rc = a->dtype == MOY_BF16 ? try_conv_direct<bf16_t>(p, a->B, ln, st) : try_conv_direct<f16_t>(p, a->B, ln, st);
     if (rc != MOY_ENOSYS) return rc;

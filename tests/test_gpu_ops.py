@@ -328,6 +328,109 @@ def test_conv3x3_stride2_weight_stationary_kernel(dt, Cin, Cout, B, H, W):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Cin,Cout,s,B,H,W,res", [(128, 256, 2, 40, 76, 136, False), (256, 256, 2, 156, 38, 68, False),
+                                                  (256, 256, 1, 156, 19, 34, True), (192, 256, 1, 10, 77, 135, True),
+                                                  (512, 512, 1, 40, 38, 68, False)])
+def test_conv3x3_large_tile_dma_kernel_bit_identical_to_tiled(dt, Cin, Cout, s, B, H, W, res):
+    """Round 4: the deep 3x3 convolutions (yolo_track.yaml:20-23,35,38; Bottleneck cv2 with its shortcut, block.py:281-283) at launch
+    sizes that take the large-tile LDS-DMA kernel (csrc/gemm_dma.hip: K >= 512, N % 256 == 0, >= 384 tiles of 256 x 256).
+    BIT-identical to the tiled kernel -- same MFMA, same k order -- which runs when the same images are submitted as launches of
+    fewer than 384 tiles; ragged last row tile, tiles that span several images, image borders in both strides, two column tiles,
+    a channel count that is not a power of two, input / residual / output as channel slices of wider buffers; a sample of images
+    against torch fp32.  (The 512 x 128 and 256 x 128 forms are A/B knobs: test_gemm_dma_other_forms_in_a_child_process.)"""
+    x = q(rnd(B, Cin, H, W, seed=1), dt)
+    w = q(rnd(Cout, Cin, 3, 3, seed=2, scale=1 / math.sqrt(9 * Cin)), dt)
+    sc, sh = rnd(Cout, seed=3) * 0.2 + 1, rnd(Cout, seed=4, scale=0.1)
+    Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+    M = B * Ho * Wo
+    bm, bn = (256, 256) if Cout % 256 == 0 else (512, 128)
+    assert (M + bm - 1) // bm * (Cout // bn) >= 384
+    xin = torch.zeros(B * H * W, Cin + 8, device=DEV, dtype=dt)
+    xin[:, :Cin] = x.permute(0, 2, 3, 1).reshape(B * H * W, Cin).to(DEV, dt)
+    rs = q(rnd(M, Cout, seed=5), dt).to(DEV, dt) if res else None
+    rbuf = None
+    if res:
+        rbuf = torch.zeros(M, Cout + 4, device=DEV, dtype=dt)
+        rbuf[:, 4:] = rs
+    out = torch.full((M + 1, Cout + 16), 7.0, device=DEV, dtype=dt)
+    wp = ops.pad_weight(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).to(DEV), dt)
+    kw = dict(ksize=3, stride=s, scale=sc.to(DEV), shift=sh.to(DEV), act=L.ACT_SILU)
+    ops.gemm(xin[:, :Cin], wp, Cout, 9 * Cin, geom=(B, H, W, Ho, Wo, Cin), R=rbuf[:, 4:] if res else None, out=out[:M, 8:8 + Cout], **kw)
+    two = torch.empty(M, Cout, device=DEV, dtype=dt)
+    per = max(1, 300 * bm // (Ho * Wo) // (Cout // bn))                    # < 384 tiles per launch
+    for b0 in range(0, B, per):
+        b1 = min(B, b0 + per)
+        ops.gemm(xin[b0 * H * W:b1 * H * W, :Cin], wp, Cout, 9 * Cin, geom=(b1 - b0, H, W, Ho, Wo, Cin),
+                 R=rbuf[b0 * Ho * Wo:b1 * Ho * Wo, 4:] if res else None, out=two[b0 * Ho * Wo:b1 * Ho * Wo], **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:M, 8:8 + Cout], two), "large-tile DMA kernel differs from the tiled kernel"
+    assert bool((out[M] == 7.0).all()) and bool((out[:, :8] == 7.0).all()) and bool((out[:, 8 + Cout:] == 7.0).all())
+    nb = 2
+    ref = F.silu(F.conv2d(x[:nb], w, None, s, 1) * sc[None, :, None, None] + sh[None, :, None, None])
+    if res:
+        ref = ref + rs[:nb * Ho * Wo].float().cpu().view(nb, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    got = out[:nb * Ho * Wo, 8:8 + Cout].float().cpu().view(nb, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    assert torch.allclose(got, ref, atol=tol(dt, 2e-5, 4e-2 if res else 3e-2), rtol=1e-5)
+    last = F.silu(F.conv2d(x[-1:], w, None, s, 1) * sc[None, :, None, None] + sh[None, :, None, None])
+    if res:
+        last = last + rs[-Ho * Wo:].float().cpu().view(1, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    gl = out[M - Ho * Wo:M, 8:8 + Cout].float().cpu().view(1, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    assert torch.allclose(gl, last, atol=tol(dt, 2e-5, 4e-2 if res else 3e-2), rtol=1e-5)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,act,res", [(100001, 512, 1024, "none", False), (100003, 256, 640, "silu", True), (99000, 256, 2048, "relu", False)])
+def test_gemm_large_tile_dma_kernel_bit_identical_to_tiled(dt, M, N, K, act, res):
+    """The wide 1x1 convolutions of yolo_track.yaml at its own scale (C2f cv2 / SPPF cv2 with K = 640 ... 2048, block.py:129-134,
+    178-182) on the 256-row-tile LDS-DMA kernel: bit-identical to the tiled kernel (the same rows as launches below 384 tiles),
+    against torch fp32, ragged last tile, padded input pitch, output into a channel slice."""
+    x, w = q(rnd(M, K, seed=21), dt), q(rnd(N, K, seed=22, scale=1 / math.sqrt(K)), dt)
+    b = rnd(N, seed=23, scale=0.1)
+    sc = (rnd(N, seed=24) * 0.2 + 1.0) if act == "silu" else None
+    xbuf = torch.zeros(M, K + 64, device=DEV, dtype=dt)
+    xbuf[:, :K] = x.to(DEV, dt)
+    xd = xbuf[:, :K]
+    wd = ops.pad_weight(w.to(DEV), dt)
+    r = q(rnd(M, N, seed=25), dt) if res else None
+    rd = r.to(DEV, dt) if res else None
+    code = {"silu": L.ACT_SILU, "relu": L.ACT_RELU, "none": L.ACT_NONE}[act]
+    kw = dict(shift=b.to(DEV), scale=sc.to(DEV) if sc is not None else None, act=code)
+    out = torch.full((M + 1, N + 32), 7.0, device=DEV, dtype=dt)
+    ops.gemm(xd, wd, N, K, out=out[:M, 8:8 + N], R=rd, **kw)
+    two = torch.empty(M, N, device=DEV, dtype=dt)
+    step = (256 * 300 // (N // 256)) if N % 256 == 0 else (512 * 300 // (N // 128))
+    for m0 in range(0, M, step):
+        m1 = min(M, m0 + step)
+        ops.gemm(xd[m0:m1], wd, N, K, out=two[m0:m1], R=rd[m0:m1] if res else None, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:M, 8:8 + N], two), "large-tile DMA kernel differs from the tiled kernel"
+    assert bool((out[M] == 7.0).all()) and bool((out[:, :8] == 7.0).all()) and bool((out[:, 8 + N:] == 7.0).all())
+    rows = torch.cat([torch.arange(0, 3000), torch.arange(M - 3000, M)])
+    ref = x[rows] @ w.T
+    ref = F.silu(ref * sc + b) if act == "silu" else (F.relu(ref + b) if act == "relu" else ref + b)
+    if res:
+        ref = ref + r[rows]
+    assert torch.allclose(out[:M, 8:8 + N][rows.to(DEV)].float().cpu(), ref, atol=tol(dt, 2e-5, 4e-2), rtol=tol(dt, 1e-5, 1e-2))
+
+
+@pytest.mark.parametrize("form", [1, 2])
+def test_gemm_dma_other_forms_in_a_child_process(form):
+    """The 512 x 128 (form 1) and 256 x 128 (form 2) tilings of csrc/gemm_dma.hip are measured negatives kept as A/B knobs
+    (MOY_GEMM_DMA_FORM, read once per process): one child process per form checks them bit for bit against the tiled kernel
+    (tools/probes/gemm_dma_check.py prints the mismatch count per shape)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MOY_GEMM_DMA_FORM=str(form))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "gemm_dma_check.py"), "n128"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if "mismatches" in ln]
+    assert len(lines) >= 3 and all(" mismatches 0 of" in ln for ln in lines), r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,H,W", [(2, 64, 96), (3, 100, 132), (1, 608, 1088)])
 def test_stem_and_first_downsample_fused(dt, B, H, W):
     """moy_stem_l1_fused = preprocess (BGR->RGB, /255, predictor.py:125-133) + layer 0 + layer 1 (yolo_track.yaml:17-18, Conv + BN +

@@ -99,6 +99,13 @@ def main():
                 n = max(d[o + 8], 1)
                 print(f"    group {g}: work per interval " + " ".join(f"{v / n:.0f}" for v in d[o:o + 4]) + " | at the barrier " +
                       " ".join(f"{v / n:.0f}" for v in d[o + 4:o + 8]) + f"  (cycles per tile, {n} tiles)")
+        elif os.environ.get("MOY_GD_DIAG") == "1" and "3x3" in name:      # diagnostic build of csrc/gemm_dma.hip: section stamps of block 8, waves 0 and 4
+            d = f.out.view(torch.int64).flatten()[:16].cpu().tolist()
+            for g, o in (("wave 0", 0), ("wave 4", 8)):
+                nkk = max(d[o + 6], 1)
+                names = ["reads+dma issue", "vmcnt wait", "barrier A", "mfma", "barrier B"]
+                print(f"    {g}: per k-tile (4 phases): " + ", ".join(f"{nm} {v / nkk:.0f}" for nm, v in zip(names, d[o:o + 5])) +
+                      f" | epilogue {d[o + 5]} | k-tiles {nkk}")
         elif os.environ.get("MOY_CWS_ABL") == "5":      # diagnostic build of csrc/conv_ws.hip: phase stamps of block 0, wave 0
             d = f.out.view(torch.int64).flatten()[:8].cpu().tolist()
             n = max(d[7], 1)
