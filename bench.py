@@ -66,6 +66,7 @@ def parse(argv=None):
     ap.add_argument("--predictor", action="store_true",
                     help="time the PRODUCT entry point instead of the engine: TrackPredictor.__call__ on host uint8 frames (pinned ring in, "
                          "one packed device-to-host copy of the rows out, TrackResults built on the host)")
+    ap.add_argument("--predictor-calls", action="store_true", help="--predictor: one TrackPredictor.__call__ per step instead of one long stream()")
     ap.add_argument("--pinned-source", action="store_true", help="--predictor: the caller's frames already lie in page-locked memory")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="default C2 run at N=1 appends the other workloads (child processes, 20 steps each) under `extra`")
@@ -258,7 +259,7 @@ def main(argv=None):
         B = a.batch or {"c4": 128, "full_c2": 128}.get(cfg_name, 192 if dtype_name == "f32" else 576)
         if a.predictor:
             B = a.batch or 288
-        S = 1 if a.predictor else max(1, a.streams if a.streams is not None else 2)
+        S = max(1, a.streams if a.streams is not None else 2)
     if B % S or (not a.temporal and B % seq_per_gpu):
         raise SystemExit("--batch must be a multiple of --streams and of the sequences per GPU")
     # sequence shard of this rank (sequence i -> rank i mod N, no cross-GPU term)
@@ -319,7 +320,8 @@ def main(argv=None):
             # the product entry point (mo_yolo_amd/predictor.py): host uint8 frames in, TrackResults out
             from mo_yolo_amd.predictor import TrackPredictor
             pipe = None
-            pred = TrackPredictor(arch, sd, imgsz=(cfg["H"], cfg["W"]), dtype=dtype, device=dev, batch=B, graph=not a.no_graph)
+            pred = TrackPredictor(arch, sd, imgsz=(cfg["H"], cfg["W"]), dtype=dtype, device=dev, batch=B, graph=not a.no_graph,
+                                  streams=a.streams if a.streams is not None else 2)
             n_chunks = 6
             host_frames = torch.cat([batch_frames(k % 2).cpu() for k in range(n_chunks)])
             if a.pinned_source:
@@ -328,14 +330,25 @@ def main(argv=None):
                 host_frames = host_frames.numpy()
             pred(host_frames[:B])                                # builds the engine, the ring and the graphs
             eng = next(iter(pred._engines.values()))
-            line_extra["predictor"] = (f"TrackPredictor.__call__ on {n_chunks * B} host frames per step (chunks of {B}), source = "
+            line_extra["predictor"] = ((f"TrackPredictor.__call__ on {n_chunks * B} host frames per step" if a.predictor_calls else
+                                        f"TrackPredictor.stream() over arrays of {n_chunks * B} host frames (one array per step)")
+                                       + f" (chunks of {B}), source = "
                                        + ("one PINNED uint8 tensor (no staging copy)" if a.pinned_source else
                                           "a pageable numpy array (staged into the pinned ring by 8 host threads)")
                                        + " -> H2D on a copy stream -> step -> ONE packed D2H -> TrackResults on the host")
             n_results = [0]
+            if a.predictor_calls:
+                def step(i):
+                    n_results[0] = len(pred(host_frames))           # one __call__ per step: the pipeline fills and drains every time
+            else:
+                def forever():
+                    while True:
+                        yield host_frames
+                results_gen = pred.stream(forever())                # the generator form: the pipeline stays full across the steps
 
-            def step(i):
-                n_results[0] = len(pred(host_frames))
+                def step(i):
+                    for _ in range(n_chunks):
+                        n_results[0] += len(next(results_gen))
             B = n_chunks * B                                     # frames per timed step
         else:
             pipe = StreamedEngines(arch, sd, cfg["H"], cfg["W"], batch=B, streams=S, graph=not a.no_graph, dtype=dtype, device=dev,
@@ -621,42 +634,73 @@ def main(argv=None):
         else:
             engine_check = None
         if a.temporal and not a.no_parity:
-            # carried-query mode (it had no gate): the benched engine and an fp32 engine of the same weights run the
-            # first 3 frames of the first 4 sequences from a reset; per step the detect-query rows are compared by token and
-            # the track memories by live count.  (The mode is spec-parity only, DESIGN.md section 7: the reference branch cannot run.)
-            log("parity gate (temporal): benched engine vs fp32 temporal engine, 3 steps from reset")
-            from mo_yolo_amd.parity import engine_pair_stats
+            # carried-query mode: the benched engine and an fp32 engine of the same weights run the first GATE_T frames of the first 4
+            # sequences from a reset.  Reported AND gated (VERDICT r3 #3a): the tracks of the benched engine scored against the fp32
+            # engine's tracks as ground truth -- HOTA / DetA / AssA by the published definition (ids carry across frames here, so the
+            # association half means something) --, `n_overflow` (active rows beyond the slots: dropped, never silent), and the
+            # detect-query rows of the first 3 steps by token as before.  (Spec parity only, DESIGN.md section 7: the reference's
+            # carried branch cannot run; the fp32 engine itself is held to oracle/temporal_oracle.py by tests/test_gpu_temporal.py.)
+            GATE_T = 24
+            log(f"parity gate (temporal): benched engine vs fp32 temporal engine, {GATE_T} steps from reset")
+            import numpy as np
+            from mo_yolo_amd.parity import _xyxy, agreement_hota, engine_pair_stats
             NB, nm = min(4, B), a.temporal
             ref = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=NB, dtype=torch.float32, device=dev, temporal=a.temporal)
             eng.reset_sequence()
             steps = []
             worst = {"box_max_err_matched": 0.0, "hs_max_err_matched": 0.0, "score_max_err_matched": 0.0}
             flips = active = 0
-            for k in range(n_slots):
-                eng.forward(slot=k)
+            trk_g, trk_w = [[] for _ in range(NB)], [[] for _ in range(NB)]
+            over_g = over_w = 0
+            reps = (B + NB - 1) // NB
+
+            def trk_of(o, b):
+                ids, bx = o["obj_idxes"][b].cpu(), o["boxes"][b].float().cpu()
+                act = ids >= 0
+                return _xyxy(bx[act], cfg["W"], cfg["H"]).numpy().astype("float32"), ids[act].numpy().astype("int64")
+
+            for k in range(GATE_T):
+                fr4 = torch.from_numpy(np.concatenate([s_.frames(k, 1) for s_ in seqs[:NB]])).to(dev)
+                eng.forward(fr4.repeat(reps, 1, 1, 1)[:B].contiguous(), slot=0)      # sequences 0..3 in the first rows of the benched batch
                 torch.cuda.synchronize()
                 go = {kk: v[:NB].clone() for kk, v in eng.outputs().items() if hasattr(v, "shape") and v.shape[:1] == (B,)}
-                wo = {kk: v.clone() for kk, v in ref.forward(eng.inputs[k][:NB]).items() if hasattr(v, "shape") and v.shape[:1] == (NB,)}
+                wo = {kk: v.clone() for kk, v in ref.forward(fr4).items() if hasattr(v, "shape") and v.shape[:1] == (NB,)}
                 torch.cuda.synchronize()
-                cut = lambda o: dict(topk_ind=o["topk_ind"], boxes=o["boxes"][:, nm:], scores=o["scores"][:, nm:],
-                                     obj_idxes=o["obj_idxes"][:, nm:], hs=o["hs"][:, nm:])
-                st = engine_pair_stats(cut(go), cut(wo), arch.nq)
-                for kk in worst:
-                    worst[kk] = max(worst[kk], st[kk])
-                flips += st["births_flipped"]; active += st["active_rows_reference"]
-                steps.append({"step": k, "topk_overlap": st["topk_overlap"], "births_flipped": st["births_flipped"],
-                              "live_tracks": [int(v) for v in go["n_tracks"]], "live_tracks_fp32": [int(v) for v in wo["n_tracks"]]})
+                over_g += int(go["n_overflow"].sum()); over_w += int(wo["n_overflow"].sum())
+                for b in range(NB):
+                    trk_g[b].append(trk_of(go, b)); trk_w[b].append(trk_of(wo, b))
+                if k < 3:
+                    cut = lambda o: dict(topk_ind=o["topk_ind"], boxes=o["boxes"][:, nm:], scores=o["scores"][:, nm:],
+                                         obj_idxes=o["obj_idxes"][:, nm:], hs=o["hs"][:, nm:])
+                    st = engine_pair_stats(cut(go), cut(wo), arch.nq)
+                    for kk in worst:
+                        worst[kk] = max(worst[kk], st[kk])
+                    flips += st["births_flipped"]; active += st["active_rows_reference"]
+                    steps.append({"step": k, "topk_overlap": st["topk_overlap"], "births_flipped": st["births_flipped"],
+                                  "live_tracks": [int(v) for v in go["n_tracks"]], "live_tracks_fp32": [int(v) for v in wo["n_tracks"]]})
             eng.reset_sequence()
+            ag = [agreement_hota(trk_g[b], trk_w[b], device=dev)["published"] for b in range(NB)]
+            ag_min = {m: round(min(x[m] for x in ag), 3) for m in ("HOTA", "DetA", "AssA")}
             bars = {"f32": (1e-4, 1e-3, 1e-3, 0.0), "f16": (5e-3, 0.6, 0.16, 0.03), "bf16": (9e-3, 1.3, 0.4, 0.1)}[dtype_name]
             if (cfg_name, dtype_name, a.temporal, B) == ("c2", "bf16", 100, 32):     # 1.5 x profiles/r03_f_bench_c2_temporal100.json
                 bars = (4.5e-3, 0.5, 0.184, 0.052)
+            # agreement bars (published HOTA / DetA / AssA, minimum over the 4 sequences): 100 - 1.5 x (100 - the committed measurement)
+            hota_bars = {"f32": (99.9, 99.9, 99.9), "f16": (85.0, 80.0, 88.0), "bf16": (65.0, 55.0, 72.0)}[dtype_name]
+            if (cfg_name, dtype_name, a.temporal, B) == ("c2", "bf16", 100, 32):     # measured (deterministic): min over 4 sequences 84.6 / 77.9 / 90.8
+                hota_bars = (76.9, 66.9, 86.2)
             frac = flips / max(1, active)
             parity = {"temporal": True, "steps": steps, "detect_rows_vs_fp32": dict(worst, births_flipped=flips, active_rows_reference=active,
                                                                                     birth_flip_frac_of_active=round(frac, 5)),
-                      "bars": {"box_matched": bars[0], "hs_matched": bars[1], "score_matched": bars[2], "birth_flip_frac_of_active": bars[3]},
+                      "agreement_hota_vs_fp32_temporal_engine": {"frames": GATE_T, "sequences": NB, "per_sequence": ag, "min": ag_min,
+                                                                 "definition": "published HOTA; the benched engine's tracks scored against the fp32 temporal engine's tracks as ground truth"},
+                      "n_overflow": {"benched_engine": over_g, "fp32_engine": over_w, "slots": nm,
+                                     "note": "active rows beyond the track slots are dropped and counted (this throughput configuration saturates its slots: DESIGN.md section 2.4)"},
+                      "bars": {"box_matched": bars[0], "hs_matched": bars[1], "score_matched": bars[2], "birth_flip_frac_of_active": bars[3],
+                               "agreement_HOTA_min": hota_bars[0], "agreement_DetA_min": hota_bars[1], "agreement_AssA_min": hota_bars[2]},
                       "bench_engine": f"{dtype_name} B={B} temporal={a.temporal}", "reference_engine": f"f32 B={NB} temporal={a.temporal}"}
             parity["ok"] = bool(worst["box_max_err_matched"] <= bars[0] and worst["hs_max_err_matched"] <= bars[1]
-                                and worst["score_max_err_matched"] <= bars[2] and frac <= bars[3])
+                                and worst["score_max_err_matched"] <= bars[2] and frac <= bars[3]
+                                and ag_min["HOTA"] >= hota_bars[0] and ag_min["DetA"] >= hota_bars[1] and ag_min["AssA"] >= hota_bars[2])
 
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline (oracle on the host cores)")
@@ -691,6 +735,7 @@ def main(argv=None):
                 ("c2_bf16_from_host_1080p_resize", ["--from-host", "--resize-from", "1080x1920"], 20),
                 ("c2_bf16_predictor", ["--predictor"], 5),
                 ("c2_bf16_predictor_pinned_source", ["--predictor", "--pinned-source"], 5),
+                ("c2_bf16_predictor_one_call_per_step", ["--predictor", "--predictor-calls"], 5),
                 ("c2_bf16_sustained_200_steps", [], 200))
         for name, flags, nsteps in legs:
             log(f"extra leg {name}")
@@ -734,7 +779,7 @@ def main(argv=None):
                     "uint8 frames fed from PINNED HOST memory inside the timed region (copy stream, overlapped)" if a.from_host else
                     "uint8 frames handed to TrackPredictor.__call__ as pageable host arrays inside the timed region")
             if a.predictor:
-                mode = f"{B} frames per call in chunks of {eng.B}, one engine, one stream"
+                mode = f"{B} frames per call in chunks of {eng.B}, {S} engine(s) taking the chunks in turn on {S} HIP stream(s)"
             workload = (f"{a.config.upper()}: {scale} backbone/neck + 6-layer MOTR decoder, {arch.nq} queries, {cfg['W']}x{cfg['H']}, "
                         f"{feed}, {mode}, {len(my_seqs)} sequence(s) per GPU, "
                         f"{'eager' if a.no_graph else 'hipGraph replay'}")

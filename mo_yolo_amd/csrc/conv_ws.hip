@@ -1295,6 +1295,9 @@ static int conv_ws_dispatch(ConvWsParams& p, int B, int C, bool res, hipStream_t
     return res ? launch_conv_ws<T, 32, 32, 16, 2, 3, true>(p, B, st) : launch_conv_ws<T, 32, 32, 16, 2, 3, false>(p, B, st);
   }
   if (C == 64) {
+    static int wn64 = -1;                  // MOY_CWS_WN64=2: two column groups of 32 channels (NT = 2, 4 rows per wave) instead of four of 16
+    if (wn64 < 0) { const char* e = getenv("MOY_CWS_WN64"); wn64 = e ? atoi(e) : 4; }
+    if (wn64 == 2) return res ? launch_conv_ws<T, 64, 64, 16, 2, 2, true>(p, B, st) : launch_conv_ws<T, 64, 64, 16, 2, 3, false>(p, B, st);
     if (sp) return res ? launch_conv_ws<T, 64, 64, 16, 4, 2, true, 1, true>(p, B, st) : launch_conv_ws<T, 64, 64, 16, 4, 3, false, 1, true>(p, B, st);
     return res ? launch_conv_ws<T, 64, 64, 16, 4, 2, true>(p, B, st) : launch_conv_ws<T, 64, 64, 16, 4, 3, false>(p, B, st);
   }

@@ -40,6 +40,7 @@ struct GdParams {
   const void* R; int64_t ldr;
   void* C; int64_t ldc;
   int tiles_n, nblocks;
+  int variant;                      // A/B knob MOY_GD_VARIANT: bit 0 = no stagger between the wave halves, bit 1 = no s_setprio around the MFMA sections
   FastDiv fd_tiles_n, fd_hw, fd_wout;
 };
 
@@ -229,7 +230,8 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GdParams p) {
   issue_half(1, 0); issue_half(1, 1);
   gd_wait_vmcnt<G::GA + G::GB>();
   gd_barrier();
-  if (grp == 1) gd_barrier();                             // waves 4-7 run one barrier behind waves 0-3
+  const bool stagger = !(p.variant & 1), prio = !(p.variant & 2);
+  if (stagger && grp == 1) gd_barrier();                  // waves 4-7 run one barrier behind waves 0-3
 
   u32x4 fa[4][2], fb0[NJ][2], fb1[NJ][2];
   auto read_a = [&](const unsigned char* buf, int mh) {
@@ -247,14 +249,14 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GdParams p) {
         fb[jj][kp] = *reinterpret_cast<const u32x4*>(buf + (nh ? G::RB1 : G::RB0) + jj * 2048 + ((b_frag) ^ (kp * 64)));
   };
   auto mfma_quad = [&](f32x4 (&c)[4][2][NJ], int nh, u32x4 (&fb)[NJ][2]) {
-    __builtin_amdgcn_s_setprio(1);
+    if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kp = 0; kp < 2; ++kp)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) c[i][nh][jj] = gd_mfma<T>(c[i][nh][jj], fb[jj][kp], fa[i][kp]);
-    __builtin_amdgcn_s_setprio(0);
+    if (prio) __builtin_amdgcn_s_setprio(0);
   };
 
   // DIAG: cycles of wave 0 / wave 4 per section, summed over the phases: [0] fragment reads + DMA issue, [1] vmcnt wait, [2] barrier
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GdParams p) {
     gd_barrier();
     stamp(4);
   }
-  if (grp == 0) gd_barrier();                             // barrier counts of the two halves meet again
+  if (stagger && grp == 0) gd_barrier();                  // barrier counts of the two halves meet again
   gd_wait_vmcnt<0>();                                     // dead prefetches still target this block's LDS
   gd_barrier();
   unsigned long long t_loop_end = 0;
@@ -466,6 +468,11 @@ int gemm_dma_try(const moy_gemm_args* a, hipStream_t st) {
     if (a->K < 512 || tiles < 384) return MOY_ENOSYS;
   }
   GdParams p{};
+  {
+    static int variant = -1;
+    if (variant < 0) { const char* e = getenv("MOY_GD_VARIANT"); variant = e ? atoi(e) : 0; }
+    p.variant = variant;
+  }
   p.A = a->A; p.lda = a->lda; p.W = a->W; p.Kpad = (a->K + 63) / 64 * 64;
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.scale = a->scale; p.shift = a->shift; p.act = a->act; p.R = a->R; p.ldr = a->ldr; p.C = a->C; p.ldc = a->ldc;

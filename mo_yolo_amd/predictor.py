@@ -80,45 +80,59 @@ def _stage(dst: torch.Tensor, src: np.ndarray, threads: int = 8):
 
 class TrackPredictor:
     def __init__(self, arch, state_dict, imgsz=(608, 1088), conf=0.25, dtype=torch.float32, device="cuda", batch=1,
-                 graph=False, temporal=0, ring=3):
+                 graph=False, temporal=0, ring=3, streams=1):
         """`temporal` = track slots per sequence (0: the shipped per-frame-reset semantics).  In temporal mode the `batch`
         frames of a chunk are ONE time step of `batch` sequences running in lockstep (source order t0s0, t0s1, ..., t1s0, ...);
         call `reset_sequences()` at the start of new videos (`is_first`, head.py:199-205).
         `ring` = depth of the host-fed pipeline (round 4): pinned staging buffers, device input slots and pinned result
         blocks; chunk j+1 is copied in on a copy stream while chunk j computes, and chunk j's results (ONE packed
-        device-to-host copy: rows | ids | counts) are read on the host while chunk j+1 computes."""
+        device-to-host copy: rows | ids | counts) are read on the host while chunk j+1 computes.
+        `streams` > 1 (per-frame mode only: frames are independent there): that many engines, each on its own HIP
+        stream, take the chunks in turn -- the query-sized decoder launches of one chunk run beside the convolutions of the next
+        (what `StreamedEngines` does for the benchmark); results come back in source order."""
         self.arch, self.sd, self.imgsz, self.conf, self.dtype, self.device = arch, state_dict, tuple(imgsz), conf, dtype, device
         self.batch, self.graph, self.temporal, self.ring = batch, graph, int(temporal), max(2, int(ring))
-        self._engines = {}
-        self._rings = {}
+        self.streams = 1 if self.temporal else max(1, int(streams))
+        self._engines = {}                                 # key -> the first engine of the set (the only one when streams == 1)
+        self._sets = {}                                    # key -> [(engine, ring, compute stream or None = the caller's), ...]
         self._copy_stream = None
 
     def reset_sequences(self, which=None):
-        for eng in self._engines.values():
-            eng.reset_sequence(which)
+        for sets in self._sets.values():
+            for eng, _, _ in sets:
+                eng.reset_sequence(which)
+        for key, eng in self._engines.items():
+            if key not in self._sets:
+                eng.reset_sequence(which)
 
     def _engine(self, fmt, orig_hw=None):
         key = (fmt, tuple(orig_hw or self.imgsz))
         if key not in self._engines:
             H, W = self.imgsz
             resized = fmt == "u8" and key[1] != self.imgsz
-            eng = TrackEngine(self.arch, self.sd, H, W, batch=self.batch, dtype=self.dtype, device=self.device,
-                              input_format=fmt, conf=self.conf, scale_boxes=(fmt == "u8"), orig_hw=key[1], temporal=self.temporal,
-                              n_inputs=1 if resized else self.ring)
-            if self.graph:
-                eng.forward(torch.zeros_like(eng.input))
-                eng.capture()
-                eng.reset_sequence()                      # the warm-up frames must not leave tracks behind
-            self._engines[key] = eng
+            n_eng = self.streams if fmt == "u8" else 1
+            sets = []
+            for i in range(n_eng):
+                eng = TrackEngine(self.arch, self.sd, H, W, batch=self.batch, dtype=self.dtype, device=self.device,
+                                  input_format=fmt, conf=self.conf, scale_boxes=(fmt == "u8"), orig_hw=key[1], temporal=self.temporal,
+                                  n_inputs=1 if resized else self.ring)
+                if self.graph:
+                    eng.forward(torch.zeros_like(eng.input))
+                    eng.capture()
+                    eng.reset_sequence()                  # the warm-up frames must not leave tracks behind
+                ring = None
+                if fmt == "u8":
+                    oh, ow = key[1]
+                    ring = _HostRing(self.ring, (self.batch, oh, ow, 3), torch.uint8, eng.result_block.numel())
+                    # frames of another size land in device staging buffers first and are stretch-resized into the engine's input
+                    ring.dev_in = ([torch.empty(self.batch, oh, ow, 3, dtype=torch.uint8, device=eng.dev) for _ in range(self.ring)]
+                                   if resized else eng.inputs)
+                    ring.compute_done = [None] * self.ring
+                    ring.resized = resized
+                sets.append((eng, ring, torch.cuda.Stream(device=eng.dev) if n_eng > 1 else None))
+            self._engines[key] = sets[0][0]
             if fmt == "u8":
-                oh, ow = key[1]
-                ring = _HostRing(self.ring, (self.batch, oh, ow, 3), torch.uint8, eng.result_block.numel())
-                # frames of another size land in device staging buffers first and are stretch-resized into the engine's input
-                ring.dev_in = ([torch.empty(self.batch, oh, ow, 3, dtype=torch.uint8, device=eng.dev) for _ in range(self.ring)]
-                               if resized else eng.inputs)
-                ring.compute_done = [None] * self.ring
-                ring.resized = resized
-                self._rings[key] = ring
+                self._sets[key] = sets
         return self._engines[key]
 
     def preprocess(self, im):
@@ -163,7 +177,7 @@ class TrackPredictor:
             # would advance the memory, id counter and miss counters of the padded sequences
             raise ValueError(f"temporal mode: the source must hold whole time steps ({self.batch} sequences per step), got {n} frames")
         if fmt == "u8":
-            return self._run_host_fed(eng, x, orig_hw, paths)
+            return [r for chunk in self._host_fed(iter([(x, paths)]), orig_hw) for r in chunk]
         # float tensor source (LoadTensor, data/loaders.py:316-332): already on the device; one packed result copy per chunk
         results: List[TrackResults] = []
         for s in range(0, n, self.batch):
@@ -175,60 +189,108 @@ class TrackPredictor:
             results += self._results_of(eng, eng.result_block.cpu(), k, orig_hw, paths, s)
         return results
 
-    def _run_host_fed(self, eng, x, orig_hw, paths):
-        """The stream loop of `BasePredictor.stream_inference` (engine/predictor.py:256-344) for host frames, pipelined:
-        [stage chunk j+1 into pinned memory + H2D on the copy stream] || [chunk j on the device] || [read chunk j-1's rows].
+    @torch.no_grad()
+    def stream(self, batches):
+        """The generator form of the stream loop (`BasePredictor.stream_inference`, engine/predictor.py:256-344, is a generator over
+        the dataset): `batches` yields uint8 frame arrays [n, H, W, 3] of ONE frame size (or `(frames, paths)` pairs); one list of
+        TrackResults is yielded per chunk of `batch` frames, in source order, a few chunks behind the input -- the pipeline
+        (staging, H2D, the engines, the packed D2H) stays full ACROSS the arrays, which a sequence of `__call__`s cannot do."""
+        first = None
+        it = iter(batches)
+
+        def norm():
+            nonlocal first
+            for item in it:
+                frames, paths = item if isinstance(item, tuple) else (item, None)
+                x, fmt = self.preprocess(frames)
+                if fmt != "u8":
+                    raise ValueError("stream() takes host uint8 frames")
+                hw = tuple(x.shape[1:3])
+                if first is None:
+                    first = hw
+                elif hw != first:
+                    raise ValueError("stream(): every array must hold frames of the first array's size")
+                if self.temporal and x.shape[0] % self.batch:
+                    raise ValueError(f"temporal mode: every array must hold whole time steps ({self.batch} sequences per step)")
+                yield x, paths
+
+        gen = norm()
+        try:
+            head = next(gen)
+        except StopIteration:
+            return
+        self._engine("u8", first)
+
+        def chain():
+            yield head
+            yield from gen
+
+        yield from self._host_fed(chain(), first)
+
+    def _host_fed(self, arrays, orig_hw):
+        """[stage chunk j+1 into pinned memory + H2D on the copy stream] || [chunk j on the device] || [read chunk j-1's rows].
         The reference does `im.to(device)` from pageable memory and a `.cpu()` per result tensor, all blocking (predictor.py:130,
-        predict.py:27-76)."""
-        ring = self._rings[("u8", tuple(orig_hw))]
-        dev = eng.dev
+        predict.py:27-76).  `arrays` yields (frames, paths); yields one list of TrackResults per chunk, in source order."""
+        from collections import deque
+        sets = self._sets[("u8", tuple(orig_hw))]
+        S = len(sets)
+        dev = sets[0][0].dev
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=dev)
-        cs, main = self._copy_stream, torch.cuda.current_stream(dev)
-        n, B, D = x.shape[0], self.batch, ring.depth
-        pinned_src = isinstance(x, torch.Tensor) and x.is_pinned()
-        xn = x.numpy() if isinstance(x, torch.Tensor) else x
-        results: List[TrackResults] = []
-        pending = None                                             # (ring index, k, s) of the chunk whose results are in flight
-        for j, s in enumerate(range(0, n, B)):
-            r = j % D
-            k = min(B, n - s)
-            direct = pinned_src and k == B                         # a whole chunk in page-locked memory: no staging copy
-            if not direct:
-                if ring.h2d_done[r] is not None:
-                    ring.h2d_done[r].synchronize()                 # the transfer that last read this staging buffer
-                _stage(ring.inp[r], xn[s:s + k])
-                if k < B:                                          # ragged tail (per-frame mode only): pad with the last frame
-                    ring.inp[r].numpy()[k:] = xn[s + k - 1]
-            with torch.cuda.stream(cs):
-                if ring.compute_done[r] is not None:
-                    cs.wait_event(ring.compute_done[r])            # the step that last read this device slot
-                ring.dev_in[r].copy_(x[s:s + B] if direct else ring.inp[r], non_blocking=True)
-                ring.h2d_done[r] = torch.cuda.Event()
-                ring.h2d_done[r].record(cs)
-            main.wait_event(ring.h2d_done[r])
-            if ring.resized:
-                ops.resize_linear_u8(ring.dev_in[r], self.imgsz, out=eng.input)
-                eng.forward(None)
-            else:
-                eng.forward(None, slot=r)
-            ring.compute_done[r] = torch.cuda.Event()
-            ring.compute_done[r].record(main)
-            if ring.d2h_done[r] is not None:
-                ring.d2h_done[r].synchronize()
-            ring.out[r].copy_(eng.result_block, non_blocking=True)     # ONE device-to-host copy per chunk
-            ring.d2h_done[r] = torch.cuda.Event()
-            ring.d2h_done[r].record(main)
-            if pending is not None:
-                pr, pk, ps = pending
-                ring.d2h_done[pr].synchronize()
-                results += self._results_of(eng, ring.out[pr], pk, orig_hw, paths, ps)
-            pending = (r, k, s)
-        if pending is not None:
-            pr, pk, ps = pending
-            ring.d2h_done[pr].synchronize()
-            results += self._results_of(eng, ring.out[pr], pk, orig_hw, paths, ps)
-        return results
+        cs, caller = self._copy_stream, torch.cuda.current_stream(dev)
+        B, D = self.batch, sets[0][1].depth
+        pending = deque()                                          # chunks whose results are in flight, in source order
+
+        def collect():
+            e_, ring_, pr, pk, ps, pp = pending.popleft()
+            ring_.d2h_done[pr].synchronize()
+            return self._results_of(e_, ring_.out[pr], pk, orig_hw, pp, ps)
+
+        j = 0
+        for x, paths in arrays:
+            n = x.shape[0]
+            pinned_src = isinstance(x, torch.Tensor) and x.is_pinned()
+            xn = x.numpy() if isinstance(x, torch.Tensor) else x
+            for s in range(0, n, B):
+                e, ring, own = sets[j % S]
+                main = own if own is not None else caller          # this chunk's compute stream
+                r = (j // S) % D
+                j += 1
+                k = min(B, n - s)
+                direct = pinned_src and k == B                     # a whole chunk in page-locked memory: no staging copy
+                if not direct:
+                    if ring.h2d_done[r] is not None:
+                        ring.h2d_done[r].synchronize()             # the transfer that last read this staging buffer
+                    _stage(ring.inp[r], xn[s:s + k])
+                    if k < B:                                      # ragged tail (per-frame mode only): pad with the last frame
+                        ring.inp[r].numpy()[k:] = xn[s + k - 1]
+                with torch.cuda.stream(cs):
+                    if ring.compute_done[r] is not None:
+                        cs.wait_event(ring.compute_done[r])        # the step that last read this device slot
+                    ring.dev_in[r].copy_(x[s:s + B] if direct else ring.inp[r], non_blocking=True)
+                    ring.h2d_done[r] = torch.cuda.Event()
+                    ring.h2d_done[r].record(cs)
+                if ring.d2h_done[r] is not None:
+                    ring.d2h_done[r].synchronize()                 # (its rows were handed out at least D chunks ago)
+                with torch.cuda.stream(main):
+                    if own is not None:
+                        main.wait_stream(caller)                   # whatever the caller queued before (weights, resets)
+                    main.wait_event(ring.h2d_done[r])
+                    if ring.resized:
+                        ops.resize_linear_u8(ring.dev_in[r], self.imgsz, out=e.input)
+                        e.forward(None)
+                    else:
+                        e.forward(None, slot=r)
+                    ring.compute_done[r] = torch.cuda.Event()
+                    ring.compute_done[r].record(main)
+                    ring.out[r].copy_(e.result_block, non_blocking=True)     # ONE device-to-host copy per chunk
+                    ring.d2h_done[r] = torch.cuda.Event()
+                    ring.d2h_done[r].record(main)
+                pending.append((e, ring, r, k, s, paths))
+                while len(pending) > S:                            # keep S chunks computing while the host reads the oldest one's rows
+                    yield collect()
+        while pending:
+            yield collect()
 
 
 class DetectionPredictor:

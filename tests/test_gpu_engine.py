@@ -1,6 +1,8 @@
 """GPU parity of the whole per-frame step (TrackEngine over libmoyolo.so) against the CPU oracle and
 the committed reference goldens, seam by seam.  fp32 engine: decoder logits within 1e-3 (the
 north-star bar), ids/rows exact given the same query order.  bf16 engine: stated looser bars."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -12,6 +14,16 @@ from oracle import track_oracle as O
 from tests._util import fixture, frames_u8, golden, net_input
 
 DEV = "cuda"
+
+# Absolute bars (round 4, VERDICT r3 #3c): 1.5 x what THIS test measures on its fixture frames (deterministic: same frames, same
+# kernels, no atomics; the values are printed on every run):   (box, decoder output, score -- max abs error over rows matched by
+# token --, births flipped on matched rows, top-k overlap)
+MEASURED_16 = {
+    ("tiny", torch.bfloat16): (1.47e-3, 0.183, 0.0505, 1, 0.9867), ("c2", torch.bfloat16): (2.64e-3, 0.298, 0.1158, 10, 0.9758),
+    ("c2", torch.float16): (9.6e-4, 0.0741, 0.0205, 0, 0.9967), ("c4", torch.bfloat16): (2.75e-3, 0.350, 0.0449, 1, 0.982),
+    ("c4", torch.float16): (4.9e-4, 0.091, 0.0105, 0, 0.998), ("full", torch.bfloat16): (2.82e-3, 0.260, 0.0539, 1, 0.9667),
+    ("full", torch.float16): (1.7e-4, 0.0213, 0.0043, 0, 1.0),
+}
 
 
 def nhwc_to_nchw(view, B, hw):
@@ -193,7 +205,8 @@ def test_engine_bench_scale_kernel_paths_vs_small_batch():
             assert st["topk_overlap"] > 0.9, st
             for k in ("box_max_err_matched", "hs_max_err_matched", "score_max_err_matched"):
                 assert st[k] <= 3.0 * sf[k] + 1e-6, (dt, k, st, sf)    # (two noise realisations: sqrt(2) in rms, more in the max)
-            assert sf["box_max_err_matched"] < BARS_16[dt][0] and sf["hs_max_err_matched"] < BARS_16[dt][1], (dt, sf)
+            mb, mh = MEASURED_16[("c2", dt)][:2]                      # (six fixture frames here, four there: 2 x instead of 1.5 x)
+            assert sf["box_max_err_matched"] < 2.0 * mb and sf["hs_max_err_matched"] < 2.0 * mh, (dt, sf)
 
 
 def test_engine_fp16_c5_batched_sequences_graph():
@@ -241,13 +254,6 @@ def _eager_16bit_oracle(cfg, arch, sd, x_u8, dt):
     return dict(topk_ind=r["topk_ind"].cpu(), boxes=r["dec_bboxes"].float().cpu(), scores=sc, obj_idxes=O.assign_ids(sc), hs=r["hs"].float().cpu())
 
 
-# absolute bars = 2 x the stream measurements of profiles/parity_r03_*.json (2 x 600 frames at C2, 2 x 96 at C4):
-#   (box, decoder output, score, births flipped / active rows, top-k overlap)
-# (births: on the FIXTURE frames the calibration parks the rows it moved exactly at the edge of the threshold bands, 0.125 in the
-# logit = one sigma of the bf16 logit noise, so more of them flip there than on a stream: 0.083 measured at C2 against 0.037)
-BARS_16 = {torch.bfloat16: (9e-3, 1.3, 0.4, 0.12, 0.95), torch.float16: (5e-3, 0.6, 0.16, 0.02, 0.99)}
-
-
 @pytest.mark.parametrize("name,dt", [("tiny", torch.bfloat16), ("c2", torch.bfloat16), ("c2", torch.float16), ("c4", torch.bfloat16),
                                      ("c4", torch.float16), ("full", torch.bfloat16), ("full", torch.float16)])
 def test_engine_16bit_within_the_budget_of_the_arithmetic_type(name, dt):
@@ -279,10 +285,10 @@ def test_engine_16bit_within_the_budget_of_the_arithmetic_type(name, dt):
     assert st["births_flipped"] <= sy["births_flipped"] + 1, (st, sy)
     assert st["topk_overlap"] >= sy["topk_overlap"] - max(0.005, 1.5 / arch.nq), (st, sy)     # (1.5 tokens: nq = 60 at "full")
     assert tk["tokens_id_equal_frac"] >= ty["tokens_id_equal_frac"] - 0.02, (tk, ty)
-    bars = BARS_16[dt]
-    assert st["box_max_err_matched"] < bars[0] and st["hs_max_err_matched"] < bars[1] and st["score_max_err_matched"] < bars[2], st
-    assert st["birth_flip_frac_of_active"] <= bars[3], st
-    assert st["topk_overlap"] > bars[4] - 1.5 / arch.nq, st
+    mb, mh, ms, mf, mo = MEASURED_16[(name, dt)]
+    assert st["box_max_err_matched"] <= 1.5 * mb and st["hs_max_err_matched"] <= 1.5 * mh and st["score_max_err_matched"] <= 1.5 * ms, st
+    assert st["births_flipped"] <= max(1, math.ceil(1.5 * mf)), st
+    assert 1.0 - st["topk_overlap"] <= 1.5 * (1.0 - mo) + 1.0 / arch.nq, st
     if dt == torch.float16 and name in ("c2", "c4"):
         # the fixtures keep every score 0.03 away from the birth / miss thresholds (0.125 in the logit; fp16 moves a logit by 0.014):
         # no birth may flip on a matched row.  The id NUMBERS follow the encoder-score order of the active tokens, which no
@@ -395,8 +401,11 @@ def test_agreement_hota_against_the_oracle_tracks():
         print(f"[agreement-HOTA vs oracle tracks, {dt}] {res[dt]}")
     for kind in ("compat", "published"):
         assert res[torch.float32][kind] == {"HOTA": 100.0, "DetA": 100.0, "AssA": 100.0}, res[torch.float32]
-        assert res[torch.float16][kind]["DetA"] >= 90.0, res[torch.float16]
-        assert res[torch.bfloat16][kind]["DetA"] >= 75.0, res[torch.bfloat16]
+        # measured (deterministic): fp16 HOTA 85.3 / DetA 99.1 / AssA 73.5, bf16 45.8 / 79.4 / 26.5.  Bars = 100 - 1.5 x (100 - measured)
+        # where that is tighter than round 3's (DetA bf16: kept at 75); the association half of the per-frame mode is a RANK
+        # comparison (one flipped birth renumbers every later row of its frame), so its bf16 bar is a floor, not a quality claim
+        assert res[torch.float16][kind]["DetA"] >= 98.6 and res[torch.float16][kind]["AssA"] >= 60.0 and res[torch.float16][kind]["HOTA"] >= 78.0, res[torch.float16]
+        assert res[torch.bfloat16][kind]["DetA"] >= 75.0 and res[torch.bfloat16][kind]["AssA"] >= 15.0, res[torch.bfloat16]
 
 
 def test_side_state_copy_filter_and_fsqm_vs_oracle():

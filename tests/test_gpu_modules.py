@@ -317,8 +317,8 @@ def test_predictor_stretch_resizes_foreign_frame_sizes():
                                [[float(v) for v in l.split()] for l in w.txt_lines()], atol=1e-5)
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_predictor_host_ring_equals_resident_frames_bit_for_bit(dt):
+@pytest.mark.parametrize("dt,streams", [(torch.float32, 1), (torch.bfloat16, 1), (torch.bfloat16, 2)])
+def test_predictor_host_ring_equals_resident_frames_bit_for_bit(dt, streams):
     """the host-fed pipeline (pageable frames -> pinned ring -> H2D on a copy stream -> input slot j % ring ->
     step -> ONE packed device-to-host copy) returns exactly what the engine computes on frames already resident in HBM: same
     rows, same ids, same counts, bit for bit, over more chunks than the ring is deep and with a ragged tail
@@ -327,7 +327,8 @@ def test_predictor_host_ring_equals_resident_frames_bit_for_bit(dt):
     cfg, arch, sd = fixture("tiny")
     Bc, T = 3, 17                                                       # 6 chunks through a ring of 3; the last holds 2 frames
     frames = SyntheticSequence(2, cfg["H"], cfg["W"]).frames(0, T)
-    pred = TrackPredictor(arch, sd, imgsz=(cfg["H"], cfg["W"]), conf=0.25, batch=Bc, graph=True, dtype=dt, ring=3)
+    pred = TrackPredictor(arch, sd, imgsz=(cfg["H"], cfg["W"]), conf=0.25, batch=Bc, graph=True, dtype=dt, ring=3, streams=streams)
+    # (streams = 2: two engines take the chunks in turn, each on its own HIP stream; results in source order)
     got = pred(frames, paths=[f"f{t}" for t in range(T)])
     assert len(got) == T and [r.path for r in got] == [f"f{t}" for t in range(T)]
     eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=Bc, dtype=dt, orig_hw=(cfg["H"], cfg["W"]))
@@ -352,6 +353,12 @@ def test_predictor_host_ring_equals_resident_frames_bit_for_bit(dt):
     # a second call reuses the ring (events of the previous call still attached to its buffers)
     again = pred(frames[:7])
     assert all(np.array_equal(a.boxes, b.boxes) for a, b in zip(again, got[:7]))
+    # the generator form keeps the pipeline full across arrays (a ragged chunk in mid-stream included): same results, same order
+    parts = [frames[:5], (frames[5:11], [f"g{t}" for t in range(5, 11)]), frames[11:]]
+    streamed = [r for chunk in pred.stream(parts) for r in chunk]
+    assert len(streamed) == T and [r.path for r in streamed[5:11]] == [f"g{t}" for t in range(5, 11)]
+    assert all(np.array_equal(a.boxes, b.boxes) and (a.track_id is None) == (b.track_id is None)
+               and (a.track_id is None or np.array_equal(a.track_id, b.track_id)) for a, b in zip(streamed, got))
     # frames that already lie in page-locked memory cross the link from where they are (no staging copy): same results
     pinned = pred(torch.from_numpy(frames).pin_memory())
     assert len(pinned) == T and all(np.array_equal(a.boxes, b.boxes) and np.array_equal(a.track_id, b.track_id)
