@@ -385,8 +385,12 @@ def main(argv=None):
                 hs, ws = (int(v) for v in a.resize_from.lower().split("x")) if a.resize_from else (cfg["H"], cfg["W"])
                 line_extra["from_host"] = f"pinned ring, {ws}x{hs} uint8 BGR frames, {hs * ws * 3 / 1e6:.2f} MB per frame"
                 g7 = torch.Generator(device="cpu").manual_seed(7)
-                host = [[(torch.randint(0, 256, (pipe.Bs, hs, ws, 3), dtype=torch.uint8, generator=g7) if a.resize_from
-                          else e.inputs[k].cpu()).pin_memory() for k in range(n_slots)] for e in pipe.engines]
+                if a.resize_from:    # camera-resolution frames: ONE pinned buffer per engine serves its three slots (only the bytes' SIZE
+                    # matters to the copy and to the resize kernel; 10.7 GB of random bytes would take the leg half a minute to draw)
+                    one = [torch.randint(0, 256, (pipe.Bs, hs, ws, 3), dtype=torch.uint8, generator=g7).pin_memory() for _ in pipe.engines]
+                    host = [[one[i]] * n_slots for i in range(len(pipe.engines))]
+                else:
+                    host = [[e.inputs[k].cpu().pin_memory() for k in range(n_slots)] for e in pipe.engines]
                 stage = [[torch.empty(pipe.Bs, hs, ws, 3, dtype=torch.uint8, device=dev) for _ in range(n_slots)] if a.resize_from
                          else e.inputs for e in pipe.engines]
                 copy_streams = [torch.cuda.Stream(device=dev) for _ in pipe.engines]
@@ -735,7 +739,6 @@ def main(argv=None):
                 ("c2_bf16_from_host_1080p_resize", ["--from-host", "--resize-from", "1080x1920"], 20),
                 ("c2_bf16_predictor", ["--predictor"], 5),
                 ("c2_bf16_predictor_pinned_source", ["--predictor", "--pinned-source"], 5),
-                ("c2_bf16_predictor_one_call_per_step", ["--predictor", "--predictor-calls"], 5),
                 ("c2_bf16_sustained_200_steps", [], 200))
         for name, flags, nsteps in legs:
             log(f"extra leg {name}")

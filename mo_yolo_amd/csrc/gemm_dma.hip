@@ -75,6 +75,18 @@ __device__ __forceinline__ f32x4 gd_mfma<f16_t>(f32x4 acc, u32x4 w, u32x4 a) {
 // WR wave rows x WC = 8 / WR wave columns; a wave owns 128 rows x 32 * NJ columns.  (WR, NJ) = (2, 2): 256 x 256 block tile, 128 KB of
 // LDS; (4, 2): 512 x 128 (the N = 128 convolutions: the same wave tile, all 160 KB of LDS); (2, 1): 256 x 128 (64-column wave tiles:
 // measured slower than the tiled kernel, kept for MOY_GEMM_DMA=2 only).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <typename T>
+__device__ __forceinline__ f32x16 gd_mfma32(f32x16 acc, u32x4 w, u32x4 a);
+template <>
+__device__ __forceinline__ f32x16 gd_mfma32<bf16_t>(f32x16 acc, u32x4 w, u32x4 a) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x16 gd_mfma32<f16_t>(f32x16 acc, u32x4 w, u32x4 a) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
+}
+
 template <int WR, int NJ>
 struct GdGeom {
   static constexpr int WC = 8 / WR;
@@ -89,12 +101,16 @@ struct GdGeom {
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
-template <typename T, int WR, int NJ, int KS, int ACT>
+template <typename T, int WR, int NJ, int KS, int ACT, int MF = 16>
 __device__ __forceinline__ void gd_epilogue(const GdParams& p, f32x4 (&acc)[2][4][2][NJ], unsigned char* smem, int m0, int n0, int wr, int wc,
                                             int r, int q, int tid);
 
-template <typename T, int WR, int NJ, int KS, int DIAG = 0>   // DIAG 1: s_memtime stamps per phase section (MOY_GD_DIAG=1; the build's outputs are garbage by design)
+// MF = 16: v_mfma_f32_16x16x32 (the shipped form: bit-identical to the tiled kernel); MF = 32: v_mfma_f32_32x32x16 (VERDICT r3 #1b; A/B knob
+// MOY_GD_MFMA32=1, NJ = 2 only): the same fragment reads per k-tile (8 + 4 per quadrant), half the MFMA instructions, another summation
+// order inside an instruction -- equal to the tiled kernel up to fp32 rounding, not bit for bit.
+template <typename T, int WR, int NJ, int KS, int DIAG = 0, int MF = 16>   // DIAG 1: s_memtime stamps per phase section (MOY_GD_DIAG=1; the build's outputs are garbage by design)
 __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GdParams p) {
+  static_assert(MF == 16 || (MF == 32 && NJ == 2), "the 32x32x16 form needs 32-column quadrants");
   using G = GdGeom<WR, NJ>;
   constexpr int WC = G::WC;
   constexpr uint32_t OOB = 0x80000000u;
@@ -215,7 +231,8 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GdParams p) {
   const int a_frag = wr * 8192 + r * 128 + fsw;           // + RA(mh) + i*2048, ^ 64 for the second k panel
   const int b_frag = wc * (16 * NJ) * 128 + r * 128 + fsw;   // + RB(nh) + jj*2048
 
-  f32x4 acc[2][4][2][NJ];
+  f32x4 acc[2][4][2][NJ];                                  // MF 16: [m half][16-row block][n half][16-column block]
+  f32x16 acc32[2][2][2];                                  // MF 32: [m half][32-row block][n half]
 #pragma unroll
   for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -224,6 +241,14 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GdParams p) {
       for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) acc[mh][i][nh][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[mh][ib][nh][e] = 0.f;
 
   // ---- prologue: k-tile 0 complete + the first two half-tiles of k-tile 1 (what the steady-state schedule has in flight at P1)
   issue_half(0, 0); issue_half(0, 1); issue_half(0, 2); issue_half(0, 3);
@@ -233,29 +258,58 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GdParams p) {
   const bool stagger = !(p.variant & 1), prio = !(p.variant & 2);
   if (stagger && grp == 1) gd_barrier();                  // waves 4-7 run one barrier behind waves 0-3
 
+  // MF 32: lane l holds row l & 31 of a 32-row block and the 16-byte chunk 2 ks + (l >> 5) of k-step ks (16 k each): the chunk XOR
+  // ((row >> 1) & 7) leaves ks in bits 5-6 of the byte offset
+  const int l31 = lane & 31, h32 = lane >> 5;
+  const int fsw32 = ((h32 ^ (l31 >> 1)) & 7) << 4;
+  const int a_frag32 = wr * 8192 + l31 * 128 + fsw32;     // + RA(mh) + ib*4096, ^ (ks * 32)
+  const int b_frag32 = wc * 32 * 128 + l31 * 128 + fsw32; // + RB(nh)
+
   u32x4 fa[4][2], fb0[NJ][2], fb1[NJ][2];
   auto read_a = [&](const unsigned char* buf, int mh) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int kp = 0; kp < 2; ++kp)
-        fa[i][kp] = *reinterpret_cast<const u32x4*>(buf + (mh ? G::RA1 : G::RA0) + i * 2048 + ((a_frag) ^ (kp * 64)));
-  };
-  auto read_b = [&](const unsigned char* buf, int nh, u32x4 (&fb)[NJ][2]) {
-#pragma unroll
-    for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-      for (int kp = 0; kp < 2; ++kp)
-        fb[jj][kp] = *reinterpret_cast<const u32x4*>(buf + (nh ? G::RB1 : G::RB0) + jj * 2048 + ((b_frag) ^ (kp * 64)));
-  };
-  auto mfma_quad = [&](f32x4 (&c)[4][2][NJ], int nh, u32x4 (&fb)[NJ][2]) {
-    if (prio) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kp = 0; kp < 2; ++kp)
+    if constexpr (MF == 16) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) c[i][nh][jj] = gd_mfma<T>(c[i][nh][jj], fb[jj][kp], fa[i][kp]);
+        for (int kp = 0; kp < 2; ++kp)
+          fa[i][kp] = *reinterpret_cast<const u32x4*>(buf + (mh ? G::RA1 : G::RA0) + i * 2048 + ((a_frag) ^ (kp * 64)));
+    } else {
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          fa[ib * 2 + (ks >> 1)][ks & 1] = *reinterpret_cast<const u32x4*>(buf + (mh ? G::RA1 : G::RA0) + ib * 4096 + ((a_frag32) ^ (ks * 32)));
+    }
+  };
+  auto read_b = [&](const unsigned char* buf, int nh, u32x4 (&fb)[NJ][2]) {
+    if constexpr (MF == 16) {
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp)
+          fb[jj][kp] = *reinterpret_cast<const u32x4*>(buf + (nh ? G::RB1 : G::RB0) + jj * 2048 + ((b_frag) ^ (kp * 64)));
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        fb[ks >> 1][ks & 1] = *reinterpret_cast<const u32x4*>(buf + (nh ? G::RB1 : G::RB0) + ((b_frag32) ^ (ks * 32)));
+    }
+  };
+  auto mfma_quad = [&](int mh, int nh, u32x4 (&fb)[NJ][2]) {
+    if (prio) __builtin_amdgcn_s_setprio(1);
+    if constexpr (MF == 16) {
+#pragma unroll
+      for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) acc[mh][i][nh][jj] = gd_mfma<T>(acc[mh][i][nh][jj], fb[jj][kp], fa[i][kp]);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+          acc32[mh][ib][nh] = gd_mfma32<T>(acc32[mh][ib][nh], fb[ks >> 1][ks & 1], fa[ib * 2 + (ks >> 1)][ks & 1]);
+    }
     if (prio) __builtin_amdgcn_s_setprio(0);
   };
 
@@ -283,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GdParams p) {
     stamp(1);
     gd_barrier();
     stamp(2);
-    mfma_quad(acc[0], 0, fb0);
+    mfma_quad(0, 0, fb0);
     stamp(3);
     gd_barrier();
     stamp(4);
@@ -293,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GdParams p) {
     stamp(0);
     gd_barrier();
     stamp(2);
-    mfma_quad(acc[0], 1, fb1);
+    mfma_quad(0, 1, fb1);
     stamp(3);
     gd_barrier();
     stamp(4);
@@ -303,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GdParams p) {
     stamp(0);
     gd_barrier();
     stamp(2);
-    mfma_quad(acc[1], 1, fb1);
+    mfma_quad(1, 1, fb1);
     stamp(3);
     gd_barrier();
     stamp(4);
@@ -314,7 +368,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GdParams p) {
     stamp(1);
     gd_barrier();
     stamp(2);
-    mfma_quad(acc[1], 0, fb0);
+    mfma_quad(1, 0, fb0);
     stamp(3);
     gd_barrier();
     stamp(4);
@@ -325,10 +379,26 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GdParams p) {
   unsigned long long t_loop_end = 0;
   if constexpr (DIAG == 1) t_loop_end = __builtin_amdgcn_s_memtime();
 
+  if constexpr (MF == 32) {
+    // the 32 x 32 accumulator of lane l: column (pixel) l & 31, rows (channels) 8 g + 4 (l >> 5) + e for register 4 g + e -- the same
+    // "4 consecutive channels of one pixel" cells as the 16 x 16 form, so the epilogue is shared: acc[mh][i][nh][jj] of lane (r, q) is
+    // re-addressed through pixel / channel offsets instead of moved between lanes
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x16 c = acc32[mh][ib][nh];
+            acc[mh][ib * 2 + (g >> 1)][nh][g & 1] = f32x4{c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
+          }
+  }
   switch (p.act) {
-    case MOY_ACT_SILU: gd_epilogue<T, WR, NJ, KS, MOY_ACT_SILU>(p, acc, smem, m0, n0, wr, wc, r, q, tid); break;
-    case MOY_ACT_RELU: gd_epilogue<T, WR, NJ, KS, MOY_ACT_RELU>(p, acc, smem, m0, n0, wr, wc, r, q, tid); break;
-    default: gd_epilogue<T, WR, NJ, KS, MOY_ACT_NONE>(p, acc, smem, m0, n0, wr, wc, r, q, tid); break;
+    case MOY_ACT_SILU: gd_epilogue<T, WR, NJ, KS, MOY_ACT_SILU, MF>(p, acc, smem, m0, n0, wr, wc, r, q, tid); break;
+    case MOY_ACT_RELU: gd_epilogue<T, WR, NJ, KS, MOY_ACT_RELU, MF>(p, acc, smem, m0, n0, wr, wc, r, q, tid); break;
+    default: gd_epilogue<T, WR, NJ, KS, MOY_ACT_NONE, MF>(p, acc, smem, m0, n0, wr, wc, r, q, tid); break;
   }
   if constexpr (DIAG == 1) {
     __builtin_amdgcn_sched_barrier(0);
@@ -343,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const GdParams p) {
   }
 }
 
-template <typename T, int WR, int NJ, int KS, int ACT>
+template <typename T, int WR, int NJ, int KS, int ACT, int MF>
 __device__ __forceinline__ void gd_epilogue(const GdParams& p, f32x4 (&acc)[2][4][2][NJ], unsigned char* smem, int m0, int n0, int wr, int wc,
                                             int r, int q, int tid) {
   using G = GdGeom<WR, NJ>;
@@ -352,44 +422,51 @@ __device__ __forceinline__ void gd_epilogue(const GdParams& p, f32x4 (&acc)[2][4
   const bool has_sc = p.scale != nullptr, has_sh = p.shift != nullptr;
   const float* scp = has_sc ? p.scale : reinterpret_cast<const float*>(p.W);
   const float* shp = has_sh ? p.shift : reinterpret_cast<const float*>(p.W);
+  const int lane = tid & 63, l31 = lane & 31, h32 = lane >> 5;
+  // cell (mh, i, nh, jj) of this lane = 4 consecutive output channels nl .. nl+3 of tile row ml
+  //   MF 16: row wr*128 + mh*64 + i*16 + r,                     channels wc*32NJ + nh*16NJ + jj*16 + 4q
+  //   MF 32: row wr*128 + mh*64 + (i >> 1)*32 + (lane & 31),    channels wc*64 + nh*32 + 8 ((i & 1)*2 + jj) + 4 (lane >> 5)
 #pragma unroll
   for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-      const int nl = wc * (32 * NJ) + nh * (16 * NJ) + jj * 16 + q * 4;     // 4 consecutive output channels of this lane
-      f32x4 sc = *reinterpret_cast<const f32x4*>(scp + n0 + nl);
-      f32x4 sh = *reinterpret_cast<const f32x4*>(shp + n0 + nl);
-      if (!has_sc) sc = f32x4{1.f, 1.f, 1.f, 1.f};
-      if (!has_sh) sh = f32x4{0.f, 0.f, 0.f, 0.f};
-      u32x2 res[2][4];
-      if (Rg) {
+    for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+      for (int ip = 0; ip < 2; ++ip) {
+        const int nl = MF == 16 ? wc * (32 * NJ) + nh * (16 * NJ) + jj * 16 + q * 4 : wc * 64 + nh * 32 + 8 * (ip * 2 + jj) + 4 * h32;
+        f32x4 sc = *reinterpret_cast<const f32x4*>(scp + n0 + nl);
+        f32x4 sh = *reinterpret_cast<const f32x4*>(shp + n0 + nl);
+        if (!has_sc) sc = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (!has_sh) sh = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x2 res[2][2];
+        if (Rg) {
+#pragma unroll
+          for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih) {
+              const int ml = wr * 128 + mh * 64 + (MF == 16 ? (ih * 2 + ip) * 16 + r : ih * 32 + l31);
+              res[mh][ih] = *reinterpret_cast<const u32x2*>(Rg + (int64_t)min(m0 + ml, p.M - 1) * p.ldr + n0 + nl);
+            }
+        }
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int m = min(m0 + wr * 128 + mh * 64 + i * 16 + r, p.M - 1);
-            res[mh][i] = *reinterpret_cast<const u32x2*>(Rg + (int64_t)m * p.ldr + n0 + nl);
+          for (int ih = 0; ih < 2; ++ih) {
+            const int i = ih * 2 + ip;
+            f32x4 v = acc[mh][i][nh][jj] * sc + sh;
+            if (ACT == MOY_ACT_SILU) { v.x = siluf_(v.x); v.y = siluf_(v.y); v.z = siluf_(v.z); v.w = siluf_(v.w); }
+            else if (ACT == MOY_ACT_RELU) { v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f}); }
+            if (Rg) {
+              // the activation's last multiply must round to fp32 BEFORE the residual is added (the tiled kernel parks the value in
+              // LDS in between): without the pin hipcc contracts x * sigmoid(x) + r into one fma and 1 output in 80 000 moves by an ulp
+              asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+              v += f32x4{DT<T>::lo(res[mh][ih].x), DT<T>::hi(res[mh][ih].x), DT<T>::lo(res[mh][ih].y), DT<T>::hi(res[mh][ih].y)};
+            }
+            const int ml = wr * 128 + mh * 64 + (MF == 16 ? i * 16 + r : ih * 32 + l31);
+            // tile image [BM][BN] of T, the 16-byte chunk index XORed with the row: the 16 rows of a lane group fall on 16 slots
+            unsigned char* cell = smem + ml * ROWB + ((((nl >> 3) ^ (ml & 15)) & (CPR - 1)) << 4) + (nl & 7) * 2;
+            *reinterpret_cast<u32x2*>(cell) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
           }
       }
-#pragma unroll
-      for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          f32x4 v = acc[mh][i][nh][jj] * sc + sh;
-          if (ACT == MOY_ACT_SILU) { v.x = siluf_(v.x); v.y = siluf_(v.y); v.z = siluf_(v.z); v.w = siluf_(v.w); }
-          else if (ACT == MOY_ACT_RELU) { v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f}); }
-          if (Rg) {
-            // the activation's last multiply must round to fp32 BEFORE the residual is added (the tiled kernel parks the value in
-            // LDS in between): without the pin hipcc contracts x * sigmoid(x) + r into one fma and 1 output in 80 000 moves by an ulp
-            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-            v += f32x4{DT<T>::lo(res[mh][i].x), DT<T>::hi(res[mh][i].x), DT<T>::lo(res[mh][i].y), DT<T>::hi(res[mh][i].y)};
-          }
-          const int ml = wr * 128 + mh * 64 + i * 16 + r;
-          // tile image [BM][BN] of T, the 16-byte chunk index XORed with the row: the 16 rows of a lane group fall on 16 slots
-          unsigned char* cell = smem + ml * ROWB + ((((nl >> 3) ^ (ml & 15)) & (CPR - 1)) << 4) + (nl & 7) * 2;
-          *reinterpret_cast<u32x2*>(cell) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
-        }
-    }
   __syncthreads();
   // whole rows out: thread -> (row, 16-byte chunk); a wave instruction covers 64 / CPR rows of ROWB contiguous bytes
   constexpr int RPP = 512 / CPR, NPASS = G::BM / RPP;
@@ -408,15 +485,20 @@ __device__ __forceinline__ void gd_epilogue(const GdParams& p, f32x4 (&acc)[2][4
   }
 }
 
-template <typename T, int WR, int NJ, int KS, int DIAG = 0>
+template <typename T, int WR, int NJ, int KS, int DIAG = 0, int MF = 16>
 static int gd_launch(GdParams& p, hipStream_t st) {
   using G = GdGeom<WR, NJ>;
-  if constexpr (DIAG == 0 && std::is_same<T, bf16_t>::value && NJ == 2 && KS == 3) {
+  if constexpr (DIAG == 0 && MF == 16 && WR == 2 && NJ == 2) {
+    static int mf32 = -1;                  // MOY_GD_MFMA32=1: v_mfma_f32_32x32x16 (A/B knob; results equal up to fp32 rounding, not bit for bit)
+    if (mf32 < 0) { const char* e = getenv("MOY_GD_MFMA32"); mf32 = e ? atoi(e) : 0; }
+    if (mf32 == 1) return gd_launch<T, WR, NJ, KS, 0, 32>(p, st);
+  }
+  if constexpr (DIAG == 0 && MF == 16 && std::is_same<T, bf16_t>::value && NJ == 2 && KS == 3) {
     static int diag = -1;
     if (diag < 0) diag = garbage_mode_env("MOY_GD_DIAG");
     if (diag == 1) return gd_launch<T, WR, NJ, KS, 1>(p, st);
   }
-  auto kern = gemm_dma_kernel<T, WR, NJ, KS, DIAG>;
+  auto kern = gemm_dma_kernel<T, WR, NJ, KS, DIAG, MF>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) return MOY_ELAUNCH;

@@ -14,7 +14,7 @@ B="python3 bench.py"
 run_line() {   # name, args...
   local name=$1; shift
   echo "[profile_round] bench $name: $*"
-  timeout -k 10 420 $B "$@" 2> $out/bench_$name.log | tail -1 > $out/bench_$name.json && cut -c1-300 $out/bench_$name.json
+  timeout -k 10 600 $B "$@" 2> $out/bench_$name.log | tail -1 > $out/bench_$name.json && cut -c1-300 $out/bench_$name.json
 }
 if [ "$stage" != "prof" ]; then
 run_line c2_bf16 --dump-launches $out/launches_c2_bf16.json &&
@@ -22,11 +22,13 @@ run_line c2_f16 --dtype f16 --no-cpu-baseline --dump-launches $out/launches_c2_f
 run_line c4_bf16 --config c4 --no-cpu-baseline --dump-launches $out/launches_c4_bf16.json &&
 run_line c5_f16 --config c5 --no-cpu-baseline &&
 run_line c2_temporal100 --temporal 100 --batch 32 --no-cpu-baseline &&
-run_line c2_bf16_1stream --batch 288 --streams 1 --no-cpu-baseline || exit 1
+run_line c2_bf16_1stream --batch 288 --streams 1 --no-cpu-baseline &&
+run_line c2_f32 --dtype f32 --no-cpu-baseline --no-extra-legs --dump-launches $out/launches_c2_f32.json &&
+run_line full_bf16 --config full --no-cpu-baseline --no-extra-legs --dump-launches $out/launches_full_bf16.json || exit 1
 fi
 [ "$stage" = "lines" ] && exit 0
 echo "[profile_round] rocprofv3 kernel stats (default run, 2 streams)" &&
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_default -- python3 bench.py --no-cpu-baseline --no-parity --no-launch-table --steps 10 --warmup 2 > $out/trace_default.log 2>&1 &&
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_default -- python3 bench.py --no-cpu-baseline --no-parity --no-launch-table --no-extra-legs --steps 10 --warmup 2 > $out/trace_default.log 2>&1 &&
 echo "[profile_round] rocprofv3 kernel stats (288 frames, 1 stream)" &&
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_1stream -- python3 bench.py --batch 288 --streams 1 --no-cpu-baseline --no-parity --steps 10 --warmup 2 > $out/trace_1stream.log 2>&1 &&
 echo "[profile_round] PMC FETCH_SIZE" &&
