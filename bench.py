@@ -503,7 +503,7 @@ def main(argv=None):
             tp = os.path.join(ROOT, "profiles", "traffic_by_launch.json")
             if os.path.exists(tp):
                 prof = json.load(open(tp))
-            traffic = prof.get("launches", prof).get(m["name"], {}).get("hbm_bytes")
+            traffic = prof.get("launches", prof).get(m["name"], {}).get("hbm_bytes") if dtype_name == "bf16" else None   # (measured on the bf16 plan)
             roof = {"bound": "hbm", "kernel": m["name"], "launch_index": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_ms": round(per[dom], 4), "share_of_step": round(per[dom] / sum(per), 4),

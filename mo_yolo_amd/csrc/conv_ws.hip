@@ -30,6 +30,9 @@
 #ifndef MOY_CWS_PREGEOM
 #define MOY_CWS_PREGEOM 0         // measured (C = 128, 288 frames): the loop top shrinks 1 900 -> 560 cycles per tile, the kernel 244 -> 241 us at
 #endif                            // 38x68 and 96 -> 101 us at 19x34: the cycles reappear as barrier waits (the younger wave of each SIMD is the critical path)
+#ifndef MOY_CWS_FRAGBASE
+#define MOY_CWS_FRAGBASE 1        // round 4: fragment addresses = one of 8 per-lane bases (^ a constant) + an immediate offset, see conv_ws_kernel
+#endif
 #ifndef MOY_CWS_HOIST_128
 #define MOY_CWS_HOIST_128 0       // measured: 255 VGPRs, 247.3 vs 247.1 us -- nothing (hipcc re-derives the values anyway); 81 spills with the residual
 #endif
@@ -266,6 +269,20 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_ws_kernel(const ConvWsParam
   __syncthreads();
 
   const int pix0 = wm * MT * PW + r;      // patch pixel of this lane for output row 0 of the wave, tap column 0
+  // Round 4: fragment read addresses without per-read arithmetic.  The pixel of a read is pix0 + D with D = (row)*PW + kx a compile-time
+  // constant, its swizzle term depends on the pixel only through (pix & 7) = (r + e) & 7 with e = D & 7 (wm*MT*PW is a multiple of 8), and
+  // (cc*4 + q) ^ s = (cc*4) ^ (q ^ s): so address = (F[e] ^ cc*64) + D*C*2 with EIGHT per-lane registers F[e] = set base + pix0*C*2 +
+  // ((q ^ swz(r + e)) << 4) -- one v_xor per read for cc != 0, none for cc = 0, D in the instruction's offset field.  The lock-step loop
+  // spent 464 integer instructions per tile on these addresses beside its 288 MFMAs.
+  static_assert((MT * PW) % 8 == 0, "the swizzle phase of a wave's first row must not depend on the wave");
+  // Measured (288 frames, same device, two interleaved rounds): C = 128 253 -> 237 us (-6.5 %), C = 64 254 -> 263 us (+3.7 %: there the
+  // compiler already shared most of the address arithmetic across the unrolled reads and the eight extra registers cost more) -- so C = 128 only.
+  constexpr bool FRAGBASE = MOY_CWS_FRAGBASE && C == 128;
+  uint32_t fbase[8];
+  if constexpr (FRAGBASE) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fbase[e] = (uint32_t)(pix0 * (C * 2) + (((q ^ cws_swz<C>(r + e)) & (CPP - 1)) << 4));
+  }
   int set = 0;
   // ABL == 5: diagnostic build, s_memtime stamps at the phase boundaries of wave 0 (sums over the block's tiles go to the start
   // of the output tensor of block 0: the build's outputs are garbage by design)
@@ -321,8 +338,13 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_ws_kernel(const ConvWsParam
           u32x4 a[RG + 2];
 #pragma unroll
           for (int y = 0; y < RG + 2; ++y) {
-            const int pix = pixv + (g * RG + y) * PW + kx;
-            a[y] = *reinterpret_cast<const u32x4*>(patch + pix * (C * 2) + (((cc * 4 + q) ^ cws_swz<C>(pix)) * 16));
+            if constexpr (FRAGBASE) {
+              const int D = (g * RG + y) * PW + kx;            // compile-time after unrolling
+              a[y] = *reinterpret_cast<const u32x4*>(smem + ((fbase[D & 7] ^ (uint32_t)(cc * 64)) + (uint32_t)(D * (C * 2))));
+            } else {
+              const int pix = pixv + (g * RG + y) * PW + kx;
+              a[y] = *reinterpret_cast<const u32x4*>(patch + pix * (C * 2) + (((cc * 4 + q) ^ cws_swz<C>(pix)) * 16));
+            }
           }
 #pragma unroll
           for (int y = 0; y < RG; ++y)
@@ -379,6 +401,11 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_ws_kernel(const ConvWsParam
     __syncthreads();
     stamp(6);                              // barrier
     if (++set == NBUF) set = 0;
+    if constexpr (FRAGBASE) {
+      const uint32_t step = set ? (uint32_t)G::SETB : (uint32_t)(-(NBUF - 1) * G::SETB);   // wave-uniform: the bases follow the buffer set
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fbase[e] += step;
+    }
   }
   if constexpr (ABL == 5) {
     if (blockIdx.x == 0 && tid == 0) {
