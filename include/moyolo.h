@@ -70,6 +70,8 @@ const char* moy_strerror(int code);
  *   C[m * ldc + n] = v              (dtype T, or fp32 when out_f32 != 0)
  *   C == NULL is allowed when the fused narrow head (dot_*) is given: only dot_out is produced (enc_score_head over all
  *   S tokens without materialising enc_output for them, head.py:1036-1042; the selected rows are recomputed afterwards).
+ * 16-bit launches with N % 256 == 0, K >= 512, K % 64 == 0 (3x3: Cin % 64 == 0) and >= 384 tiles of 256 x 256 run the large-tile
+ * LDS-DMA kernel (csrc/gemm_dma.hip): results bit-identical to the tiled kernel.
  * 16-bit launches with K == 256, N % 256 == 0 and M >= 65536 run a weight-stationary kernel (csrc/gemm_wreg.hip), with
  * results bit-identical to the tiled kernel in store mode; its score mode evaluates the LayerNorm statistics in one pass
  * (E[v^2] - mean^2), i.e. equal up to fp32 rounding.
