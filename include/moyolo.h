@@ -137,6 +137,10 @@ typedef struct moy_gemm_args {
    * neither read nor written.  MOY_ENOSYS when the shape does not take the weight-stationary score kernel. */
   int32_t run_levels, run_period;
   int32_t run_tok0[4], run_pitch[4], run_len[4], run_rows[4];
+  /* round 4: the rows of A may be numbered differently from the rows the scores are written to (A = one pyramid level's own
+   * [B, h*w, C] tensor, scores = the level-major [B, S] token raster): A row = b * run_a_period + (token - run_a_off).
+   * run_a_period == 0: the same numbering (A row = score row). */
+  int32_t run_a_period, run_a_off;
 } moy_gemm_args;
 
 int moy_gemm(const moy_gemm_args* args, void* stream);
@@ -455,6 +459,18 @@ int moy_detect_decode(const void* box, int64_t ld_box, const void* cls, int64_t 
  *   (pass gain 1, pads 0, clip <= 0 to skip).  A <= 16384. */
 int moy_nms(const float* y, int B, int nc, int A, float conf_thres, float iou_thres, int max_det, float max_wh, float gain,
             float pad_x, float pad_y, float clip_w, float clip_h, float* rows, int32_t* n_rows, void* stream);
+
+/* Round 4: input_proj (head.py:838-839, 1012-1029: Conv1x1 + BN, no activation) folded into its consumers -- the value projection
+ * and the enc_output score pass take each pyramid level's own tensor with composed weights, and the projected features
+ * ("feats") are only formed for the nq SELECTED tokens of a frame (features[batch_ind, topk_ind], head.py:1096):
+ * moy_level_rows: token (index into the level-major [S] raster of a frame) -> level[m] and, per level j, rows[j][m] = the token's
+ *   row in level j's [B, hw_j, C] tensor if the token lies in level j, else 0 (a dummy row for that level's gathered product).
+ * moy_level_select: dst T [M, 256] = G[level[m]][m, :] + shift[level[m]][:] rounded once (G fp32 [n_levels][M, ldg]: the per-level
+ *   products, shift fp32 [n_levels][256]: the BN shifts); rows whose token is masked (valid[tok_local[m]] == 0) are zero. */
+int moy_level_rows(const int32_t* tok_local, int B, int nq, int n_levels, const int32_t* level_hw, int32_t* rows, int32_t* level,
+                   void* stream);
+int moy_level_select(const float* G, int64_t level_stride, int64_t ldg, const int32_t* level, const float* shift,
+                     const int32_t* tok_local, const uint8_t* valid, int M, int N, void* dst, int64_t ldd, int dtype, void* stream);
 
 /* Elementwise helpers. */
 /* dst T [M, N] (ldd) = src T [rows[m], :] (lds): row gather (features[batch_ind, topk_ind], head.py:1096). N % 8 == 0. */

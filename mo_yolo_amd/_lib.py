@@ -30,6 +30,7 @@ class GemmArgs(C.Structure):
         ("pre", vp), ("ld_pre", i64), ("pre_h", i32), ("pre_w", i32), ("a2_cols", i32),
         ("plane_cols", i32), ("plane_stride", i64),
         ("run_levels", i32), ("run_period", i32), ("run_tok0", i32 * 4), ("run_pitch", i32 * 4), ("run_len", i32 * 4), ("run_rows", i32 * 4),
+        ("run_a_period", i32), ("run_a_off", i32),
     ]
 
 
@@ -106,6 +107,8 @@ SIGNATURES = {
     "moy_detect_decode": (C.c_int, [vp, i64, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp, C.c_int, vp]),
     "moy_nms": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, f32, f32, C.c_int, f32, f32, f32, f32, f32, f32, vp, vp, vp]),
     "moy_gather_rows": (C.c_int, [vp, i64, vp, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
+    "moy_level_rows": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "moy_level_select": (C.c_int, [vp, i64, i64, vp, vp, vp, vp, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
     "moy_cast_f32_to": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
     "moy_sigmoid_f32": (C.c_int, [vp, C.c_int, vp, vp]),
     "moy_msda_prep": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]),

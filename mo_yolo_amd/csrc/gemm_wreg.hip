@@ -51,6 +51,7 @@ struct WregParams {   // ngroups = N / (columns per block)
   // score mode with ROW RUNS (moy_gemm_args.run_*, round 3): only the rows b * run_period + tok0[l] + y * pitch[l] + x are visited
   // (compact row c -> b = c / run_nv, v = c % run_nv -> level l by the compact starts -> (y, x) by the run length)
   int run_levels, run_period, run_nv, run_mv;          // run_mv = (M / run_period) * run_nv compact rows
+  int run_a_period, run_a_off;                         // A row = b * run_a_period + token - run_a_off (== score row when run_a_period == run_period, run_a_off == 0)
   int run_cstart[4], run_len[4], run_tok0[4], run_pitch[4];
   FastDiv fd_nv, fd_len[4];
   // score mode (LN = true): LayerNorm statistics + the narrow head of the normalised row, nothing else is written
@@ -124,7 +125,7 @@ constexpr int wreg_lds_bytes() {
 // the prologue, bit 4 s_memtime stamps per phase at the head of C
 template <typename T, int BM, int NBUF, int OCC, bool LN, int NW, int WC, int K, int ABL = 0, bool PRE = false>
 __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParams p) {
-  static_assert((NW == 4 || NW == 8) && (!LN || (NW == 4 && WC == 64 && K == 256)), "score mode: 4 waves x 64 columns, K = 256");
+  static_assert((NW == 4 || NW == 8) && (!LN || (NW == 4 && WC == 64 && (K == 256 || K == 128))), "score mode: 4 waves x 64 columns, K = 256 or 128");
   static_assert((WC == 32 || WC == 64) && K % 64 == 0 && K <= 512, "column width per wave / reduction length");
   constexpr int BNB = NW * WC;             // output columns per block
   constexpr int MT = BM / 16;              // row sub-tiles per wave (every wave covers all BM rows)
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
   const uint32_t row_bytes = (uint32_t)(p.lda * 2);
   // compact row -> row of A (score mode with row runs): arithmetic only -- a table lookup from global memory would put
   // compiler-visible loads into the vector-memory queue that the counted waits of the DMA ring bookkeep by hand
-  auto run_row = [&](int c) {
+  auto run_row = [&](int c, bool a_side = false) {
     const int b = (int)fdiv((uint32_t)c, p.fd_nv);
     const int v = c - b * p.run_nv;
     int cs = 0, len = p.run_len[0], tok0 = p.run_tok0[0], pitch = p.run_pitch[0];
@@ -230,14 +231,15 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
     }
     const uint32_t vv = (uint32_t)(v - cs);
     const uint32_t y = (uint32_t)(((uint64_t)__umulhi(vv, mg) + vv) >> shf);
-    return b * p.run_period + tok0 + (int)y * pitch + (int)(vv - y * (uint32_t)len);
+    const int tok = tok0 + (int)y * pitch + (int)(vv - y * (uint32_t)len);
+    return a_side ? b * p.run_a_period + tok - p.run_a_off : b * p.run_period + tok;
   };
   auto issue_tile = [&](int tile, int buf) {
     const int m0 = min(tile, p.ntiles - 1) * BM;                   // over-fetch tiles past the end re-read the last one
     if (LN && p.run_levels) {
 #pragma unroll
       for (int jj = 0; jj < IPW; ++jj) {
-        const int row = run_row(min(m0 + drow[jj], p.run_mv - 1));
+        const int row = run_row(min(m0 + drow[jj], p.run_mv - 1), true);
         glds16(Ab, (uint32_t)row * row_bytes + dcol[jj], lds_w + buf * TILE_BYTES + jj * 1024);   // (M * lda * 2 < 4 GiB: checked by the host)
       }
       return;
@@ -327,7 +329,18 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
     constexpr int k = decltype(kc)::value, i = k / (NT / 2), t = k % (NT / 2);
     const bool live = !(ABL & 2);
     const int rr = i * 16 + r;
-    if (WC == 64 && p.plane_cols == 32) {
+    if (WC == 64 && p.plane_cols == 32 && p.c_rpb) {
+      // head planes AND an output row remap (round 4: the value projection of ONE pyramid level straight from that level's own
+      // tensor -- rows (b, i) of the level land at token b * S + off + i of the plane; `C` already points at row `off`): per-lane
+      // row offsets into a descriptor that spans the plane
+      T* cb = static_cast<T*>(p.C) + (int64_t)((ncol >> 5) + t) * p.plane_stride;
+      const auto rsC = __builtin_amdgcn_make_buffer_rsrc(cb, 0, 0x7fffffffu, 0x00020000);       // (plane bytes < 1 GiB: checked by the host)
+      const int m = m0 + rr;
+      const int bq = (int)fdiv((uint32_t)m, p.fd_rpb);
+      const uint32_t mo = (uint32_t)(bq * p.c_bstride + (m - bq * p.c_rpb));
+      const uint32_t vo = (live && m < p.M) ? mo * 64u + q * 16 : 0x80000000u;
+      __builtin_amdgcn_raw_buffer_store_b128(pk[i][t], rsC, vo, 0, 0);
+    } else if (WC == 64 && p.plane_cols == 32) {
       // head planes [plane][row][32]: pair-group t of the wave IS plane 2w + t; a store instruction = 16 rows x 64 B = 1 KB contiguous
       T* cb = static_cast<T*>(p.C) + (int64_t)((ncol >> 5) + t) * p.plane_stride + (int64_t)(live ? m0 : 0) * 32;
       const int64_t left = live ? (int64_t)(p.M - m0) * 64 : 0;
@@ -621,10 +634,11 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   // themselves are the tiled kernel's job
   const bool score = a->ln_g && !a->C;
   if (score) {
-    if (a->K != 256 || a->N != 256 || a->dot_n < 1 || a->dot_n > WREG_MAXDOT || a->act != MOY_ACT_NONE || a->c_rows_per_batch) return MOY_ENOSYS;
+    if ((a->K != 256 && a->K != 128) || a->N != 256 || a->dot_n < 1 || a->dot_n > WREG_MAXDOT || a->act != MOY_ACT_NONE || a->c_rows_per_batch) return MOY_ENOSYS;
     if (a->a_mask && (a->mask_period < 64 || a->mask_period > 262144)) return MOY_ENOSYS;
     if (a->run_levels) {
       if (a->a_mask || a->run_levels > 4 || a->run_period <= 0 || (a->M % a->run_period) || (int64_t)a->M * a->lda * 2 > 0xffffffffLL) return MOY_ENOSYS;
+      if (a->run_a_period < 0 || (a->run_a_period && a->run_levels != 1)) return MOY_EINVAL;     // a separate A numbering: one level per launch
       for (int l = 0; l < a->run_levels; ++l)
         if (a->run_len[l] <= 0 || a->run_rows[l] <= 0 || a->run_pitch[l] < a->run_len[l] || a->run_tok0[l] < 0 ||
             a->run_tok0[l] + (a->run_rows[l] - 1) * a->run_pitch[l] + a->run_len[l] > a->run_period)
@@ -643,11 +657,15 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   }
   static int kgen = -1;                    // MOY_WREG_KGEN=0: only the K = 256 forms (A/B runs)
   if (kgen < 0) { const char* e = getenv("MOY_WREG_KGEN"); kgen = e ? atoi(e) : 1; }
-  const bool general = a->K != 256 || a->c_rows_per_batch || is128 || seeded;       // the 32-columns-per-wave forms
+  // the value-projection form (8 waves x 64 columns, head planes of 32) also exists for K = 128 and with the output row remap
+  // (round 4: one launch per pyramid level, straight from that level's tensor)
+  const bool valueform = a->plane_cols == 32 && (a->K == 256 || a->K == 128) && (a->N % 512) == 0 && !is128 && !seeded && !score;
+  const bool general = !valueform && !score && (a->K != 256 || a->c_rows_per_batch || is128 || seeded);       // the 32-columns-per-wave forms
   if (general && (!kgen || a->plane_cols)) return MOY_ENOSYS;
   if (a->c_rows_per_batch) {               // per-lane 32-bit byte offsets into the remapped C
     const int64_t rows = ((int64_t)a->M / a->c_rows_per_batch + 1) * a->c_batch_stride;
     if (rows * a->ldc * 2 > 0x7fffffffLL) return MOY_ENOSYS;
+    if (a->plane_cols && !valueform) return MOY_ENOSYS;
   }
   if (a->M < 65536) return MOY_ENOSYS;     // persistent row-tile walk: needs many tiles per block
   if ((a->lda % 8) || !aligned16(a->A) || !aligned16(a->W)) return MOY_ENOSYS;
@@ -683,7 +701,10 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
       }
       p.run_nv = nv; p.fd_nv = make_fastdiv((uint32_t)nv);
       p.run_mv = (a->M / a->run_period) * nv;
+      p.run_a_period = a->run_a_period ? a->run_a_period : a->run_period;
+      p.run_a_off = a->run_a_period ? a->run_a_off : 0;
     }
+    if (a->K == 128) return a->dtype == MOY_BF16 ? launch_wreg<bf16_t, 32, 3, 2, true, 4, 64, 128>(p, st) : launch_wreg<f16_t, 32, 3, 2, true, 4, 64, 128>(p, st);
     return a->dtype == MOY_BF16 ? launch_wreg<bf16_t, 32, 3, 2, true>(p, st) : launch_wreg<f16_t, 32, 3, 2, true>(p, st);
   }
   static int variant = -1;
@@ -693,6 +714,8 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   // block per CU fits); 8 waves x 512 columns, BM 32 / 3 buffers, one block per CU: 6 % faster than the first (same device) -- half as
   // many blocks re-fetch an activation tile that has left the L2.  (Those variants left the tree in round 3; MOY_WREG_VARIANT=2
   // keeps the 4-wave form selectable for A/B runs.)
+  if (a->K == 128)      // (valueform: N % 512 == 0, head planes)
+    return a->dtype == MOY_BF16 ? launch_wreg<bf16_t, 32, 3, 1, false, 8, 64, 128>(p, st) : launch_wreg<f16_t, 32, 3, 1, false, 8, 64, 128>(p, st);
   if (a->dtype == MOY_BF16) {
     if (variant == 2 || a->N % 512) return launch_wreg<bf16_t, 32, 3, 2>(p, st);
     // timing-only builds of the value-projection form (tools/probes/wreg_ablate.py): see the kernel's ABL comment

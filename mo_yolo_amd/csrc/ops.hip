@@ -1539,6 +1539,39 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
   *reinterpret_cast<u32x4*>(dst + (long)m * ldd + c) = *reinterpret_cast<const u32x4*>(src + (long)rows[m] * lds_ + c);
 }
 
+// Round 4 (input_proj folded into its consumers): the selected tokens of a frame come from any pyramid level.  level_rows: token ->
+// its level and its row in that level's own [B, h*w, C] tensor (0 = a dummy row for the other levels' gathers).  level_select: of the
+// per-level fp32 products of a row keep the one of the row's level, add that level's BN shift, round once; rows of masked tokens are
+// zero (valid_mask * feats, head.py:1039).
+struct LevelTable { int n; int off[5]; int hw[4]; };
+__global__ __launch_bounds__(256) void level_rows_kernel(const int32_t* __restrict__ tok_local, int B, int nq, LevelTable lv,
+                                                         int32_t* __restrict__ rows, int32_t* __restrict__ level) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= B * nq) return;
+  const int b = m / nq, tok = tok_local[m];
+  int l = 0;
+#pragma unroll
+  for (int j = 1; j < 4; ++j)
+    if (j < lv.n && tok >= lv.off[j]) l = j;
+  level[m] = l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (j < lv.n) rows[(long)j * B * nq + m] = j == l ? b * lv.hw[j] + tok - lv.off[j] : 0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void level_select_kernel(const float* __restrict__ G, int64_t level_stride, int64_t ldg,
+                                                           const int32_t* __restrict__ level, const float* __restrict__ shift,
+                                                           const int32_t* __restrict__ tok_local, const uint8_t* __restrict__ valid,
+                                                           int M, int NC, T* __restrict__ dst, int64_t ldd) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)M * NC) return;
+  const int m = (int)(t / NC), c = (int)(t % NC) * 4;
+  const int l = level[m];
+  f32x4 v = *reinterpret_cast<const f32x4*>(G + l * level_stride + (long)m * ldg + c) + *reinterpret_cast<const f32x4*>(shift + l * 256 + c);
+  if (valid && !valid[tok_local[m]]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+  DT<T>::store4(dst + (long)m * ldd + c, v);
+}
+
 __global__ __launch_bounds__(256) void sigmoid_kernel(const float* __restrict__ in, int n, float* __restrict__ out) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t < n) out[t] = sigmoidf_(in[t]);
@@ -2072,6 +2105,37 @@ extern "C" int moy_gather_rows(const void* src, int64_t lds_, const int32_t* row
                        M, NC, static_cast<T*>(dst), ldd);
     return launch_status();
   })
+}
+
+extern "C" int moy_level_rows(const int32_t* tok_local, int B, int nq, int n_levels, const int32_t* level_hw, int32_t* rows,
+                              int32_t* level, void* stream) {
+  if (!tok_local || !level_hw || !rows || !level || B <= 0 || nq <= 0 || n_levels < 1 || n_levels > 4) return MOY_EINVAL;
+  LevelTable lv{};
+  lv.n = n_levels;
+  for (int l = 0; l < n_levels; ++l) {
+    if (level_hw[l] <= 0) return MOY_EINVAL;
+    lv.hw[l] = level_hw[l];
+    lv.off[l + 1] = lv.off[l] + level_hw[l];
+  }
+  hipLaunchKernelGGL(level_rows_kernel, dim3(nblk((long)B * nq)), dim3(256), 0, static_cast<hipStream_t>(stream), tok_local, B, nq, lv, rows,
+                     level);
+  return launch_status();
+}
+
+extern "C" int moy_level_select(const float* G, int64_t level_stride, int64_t ldg, const int32_t* level, const float* shift,
+                                const int32_t* tok_local, const uint8_t* valid, int M, int N, void* dst, int64_t ldd, int dtype,
+                                void* stream) {
+  if (!G || !level || !shift || !dst || M <= 0 || N != 256 || (ldg % 4) || (ldd % 4) || !aligned16(G) || !aligned16(shift)) return MOY_EINVAL;
+  if (valid && !tok_local) return MOY_EINVAL;
+  if (dtype != MOY_BF16 && dtype != MOY_F16) return MOY_ENOSYS;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == MOY_BF16)
+    hipLaunchKernelGGL((level_select_kernel<bf16_t>), dim3(nblk((long)M * (N / 4))), dim3(256), 0, st, G, level_stride, ldg, level, shift,
+                       tok_local, valid, M, N / 4, static_cast<bf16_t*>(dst), ldd);
+  else
+    hipLaunchKernelGGL((level_select_kernel<f16_t>), dim3(nblk((long)M * (N / 4))), dim3(256), 0, st, G, level_stride, ldg, level, shift,
+                       tok_local, valid, M, N / 4, static_cast<f16_t*>(dst), ldd);
+  return launch_status();
 }
 
 extern "C" int moy_sigmoid_f32(const float* in, int n, float* out, void* stream) {

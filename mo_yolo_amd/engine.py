@@ -135,7 +135,7 @@ class TrackEngine:
 
     def _gemm(self, A: View, Wt, N, K, C_: View, M, *, ksize=1, stride=1, geom=None, scale=None, shift=None, act=0,
               A2: View | None = None, a_rows=None, a_mask=None, mask_period=0, R: View | None = None, ln=None,
-              out_f32=False, c_rpb=0, c_bstride=0, dot=None, pre=None, a2_cols=0, planes=None):
+              out_f32=False, c_rpb=0, c_bstride=0, dot=None, pre=None, a2_cols=0, planes=None, runs=None, meta_scale=1.0):
         a = L.GemmArgs()
         a.A, a.lda = A.ptr, A.ld
         a.A2 = A2.ptr if A2 is not None else None
@@ -168,6 +168,10 @@ class TrackEngine:
         if pre is not None:
             pt, ph, pw = pre
             a.pre, a.ld_pre, a.pre_h, a.pre_w = pt.data_ptr(), pt.stride(0), ph, pw
+        if runs is not None:    # score pass over the valid rectangle of ONE level read from that level's own tensor (moy_gemm_args.run_*)
+            a.run_levels, a.run_period = 1, runs["period"]
+            a.run_tok0[0], a.run_pitch[0], a.run_len[0], a.run_rows[0] = runs["tok0"], runs["pitch"], runs["len"], runs["rows"]
+            a.run_a_period, a.run_a_off = runs["a_period"], runs["a_off"]
         self._keep.append(a)
         esz = 4 if self.dtype == torch.float32 else 2
         if geom is not None:
@@ -176,7 +180,8 @@ class TrackEngine:
             a_elems = M * K * (2 if A2 is not None else 1)
         alg = (a_elems + N * K) * esz + (M * N * (4 if out_f32 else esz) if C_ is not None else 0) + (M * N * esz if R is not None else 0)
         tag = f"gemm{ksize}x{ksize}" + ("s2" if stride == 2 else "") + ("+ln" if ln is not None else "")
-        self._add(self.lib.moy_gemm, C.byref(a), meta=dict(name=f"{tag} M{M} N{N} K{K}", bytes=alg, flops=2 * M * N * K))
+        self._add(self.lib.moy_gemm, C.byref(a), meta=dict(name=f"{tag} M{M} N{N} K{K}", bytes=int(alg * meta_scale),
+                                                            flops=int(2 * M * N * K * meta_scale)))
 
     # conv + BN + SiLU on channels-last views
     def _conv(self, p, x: View, hw_in, cin, cout, k, s, out: View, R: View | None = None, act=L.ACT_SILU, up_src=None):
@@ -420,22 +425,29 @@ class TrackEngine:
         d = f"model.{nlayers}.decoder"
         hd, nq, nc, S, nl = arch.hd, arch.nq, arch.nc, self.S, arch.nl
         assert hd == 256 and arch.nh == 8 and arch.ndp == 4, "kernels are specialised to hd 256 / 8 heads / 4 points"
-        feats = View(self._buf(B * S, hd))
-        off = 0
-        for li, ((src_view, src_hw), (h_, w_)) in enumerate(zip(head_src, self.shapes)):
-            assert tuple(src_hw) == (h_, w_)
-            cin = arch.head_ch[li]
-            Wt = self._weight(sd[f"{d}.input_proj.{li}.0.weight"].reshape(hd, cin))
-            scale, shift = self._bn(f"{d}.input_proj.{li}.1")
-            dst = View(feats.buf[off:], 0, hd) if off else feats
-            self._gemm(src_view, Wt, hd, cin, dst, B * h_ * w_, scale=scale, shift=shift, c_rpb=h_ * w_, c_bstride=S)
-            off += h_ * w_
-        self.feats = feats
-
         # anchors / valid mask are input independent: host precompute with the reference formula
         anchors, valid = _generate_anchors(self.shapes)
         self.anchors = self._dev(anchors[0])                        # [S, 4] (+inf at masked tokens)
         self.valid = self._dev(valid[0, :, 0].to(torch.uint8))     # [S]
+        for (src_view, src_hw), hw_ in zip(head_src, self.shapes):
+            assert tuple(src_hw) == tuple(hw_)
+        # Round 4: input_proj (Conv1x1 + BN, NO activation: head.py:838-839) is a linear map between two linear consumers, so at bench
+        # scale it is folded into them -- value projection and score pass read each level's own tensor with composed weights, the
+        # projected features exist only for the nq selected tokens (`_fold_plan` says when; MOY_FOLD_PROJ=0 keeps the classic plan)
+        fold = self._fold_plan(head_src, valid[0, :, 0])
+        self.fold_proj = fold is not None
+        feats = None
+        if fold is None:
+            feats = View(self._buf(B * S, hd))
+            off = 0
+            for li, ((src_view, src_hw), (h_, w_)) in enumerate(zip(head_src, self.shapes)):
+                cin = arch.head_ch[li]
+                Wt = self._weight(sd[f"{d}.input_proj.{li}.0.weight"].reshape(hd, cin))
+                scale, shift = self._bn(f"{d}.input_proj.{li}.1")
+                dst = View(feats.buf[off:], 0, hd) if off else feats
+                self._gemm(src_view, Wt, hd, cin, dst, B * h_ * w_, scale=scale, shift=shift, c_rpb=h_ * w_, c_bstride=S)
+                off += h_ * w_
+        self.feats = feats
 
         # value projections of all decoder layers in ONE GEMM over the S tokens: feats is layer
         # invariant (transformer.py:700-706 passes the same `feats` to every layer)
@@ -450,7 +462,18 @@ class TrackEngine:
             # 128 contiguous bytes and the GEMM's stores are contiguous runs
             self.value_planes = self._buf(ndl * arch.nh * B * S, dh)
             value = [(View(self.value_planes[i * arch.nh * B * S:(i * arch.nh + 1) * B * S]), B * S * dh) for i in range(ndl)]
-            self._gemm(feats, self._weight(Wv), ndl * hd, hd, value[0][0], B * S, shift=self._dev(bv), planes=(dh, B * S * dh))
+            if fold is None:
+                self._gemm(feats, self._weight(Wv), ndl * hd, hd, value[0][0], B * S, shift=self._dev(bv), planes=(dh, B * S * dh))
+            else:
+                # value = (P . Wp^T * s + t) . Wv^T + bv = P . (Wv diag(s) Wp)^T + (Wv t + bv): one launch per level, rows (b, i) of the
+                # level -> token b*S + off + i of every head plane (output row remap)
+                off = 0
+                for li, ((src_view, _), (h_, w_)) in enumerate(zip(head_src, self.shapes)):
+                    Wc = (Wv.double() @ fold["sWp"][li]).float()
+                    bc = (Wv.double() @ fold["t"][li] + bv.double()).float()
+                    self._gemm(src_view, self._weight(Wc), ndl * hd, arch.head_ch[li], View(self.value_planes[off:]), B * h_ * w_,
+                               shift=self._dev(bc), planes=(dh, B * S * dh), c_rpb=h_ * w_, c_bstride=S)
+                    off += h_ * w_
         elif vmode == "1":      # A/B: one contiguous [B*S, hd] matrix per layer
             self.value_planes = self._buf(ndl * B * S, hd)
             value = [(View(self.value_planes[i * B * S:(i + 1) * B * S]), dh) for i in range(ndl)]
@@ -469,7 +492,25 @@ class TrackEngine:
         self.scores_all = self._buf(B * S, nc, torch.float32)
         wsc, bsc = self._dev(sd[d + ".enc_score_head.weight"]), self._dev(sd[d + ".enc_score_head.bias"])
         fuse_score = nc <= 8     # enc_score_head rides on the LayerNorm epilogue
-        if fuse_score:
+        if fold is not None:
+            # score pass per level over its valid rectangle, from the level's own tensor: LN((P . Wp^T * s + t) . We^T + be) . w + b with
+            # composed weights; a masked token's feature row is zero (head.py:1039), so its score is the constant of LN(be): written once
+            We, be = sd[d + ".enc_output.0.weight"].double(), sd[d + ".enc_output.0.bias"].double()
+            const = torch.nn.functional.layer_norm(be.float()[None], (hd,), sd[d + ".enc_output.1.weight"], sd[d + ".enc_output.1.bias"], 1e-5)
+            const = const @ sd[d + ".enc_score_head.weight"].t() + sd[d + ".enc_score_head.bias"]
+            self.scores_all.copy_(const.to(self.dev).expand(B * S, nc))
+            off = 0
+            for li, ((src_view, _), (h_, w_)) in enumerate(zip(head_src, self.shapes)):
+                y0, y1, x0, x1 = fold["rect"][li]
+                Wc = (We @ fold["sWp"][li]).float()
+                bc = (We @ fold["t"][li] + be).float()
+                nv = (y1 - y0 + 1) * (x1 - x0 + 1)
+                self._gemm(src_view, self._weight(Wc), hd, arch.head_ch[li], None, B * S, shift=self._dev(bc), ln=ln_enc,
+                           dot=(wsc, bsc, self.scores_all), meta_scale=nv / S,
+                           runs=dict(period=S, tok0=off + y0 * w_ + x0, pitch=w_, len=x1 - x0 + 1, rows=y1 - y0 + 1, a_period=h_ * w_, a_off=off))
+                self.meta[-1]["name"] += f" level {li} valid-runs {nv}/{h_ * w_}"
+                off += h_ * w_
+        elif fuse_score:
             self._gemm(feats, Wt_enc, hd, hd, None, B * S, shift=bias_enc, a_mask=self.valid, mask_period=S, ln=ln_enc,
                        dot=(wsc, bsc, self.scores_all))
             self._score_runs(valid[0, :, 0])
@@ -520,8 +561,32 @@ class TrackEngine:
         refs = [self._buf(Md, 4, torch.float32) for _ in range(2)]
         # enc_output of the selected tokens = the decoder's content queries (head.py:1104-1113)
         sel = embed[0] if not n_max else View(self._buf(M, hd))
-        self._gemm(feats, Wt_enc, hd, hd, sel, M, shift=bias_enc, a_rows=self.topk_global, a_mask=self.valid, mask_period=S,
-                   ln=ln_enc)
+        if fold is None:
+            self._gemm(feats, Wt_enc, hd, hd, sel, M, shift=bias_enc, a_rows=self.topk_global, a_mask=self.valid, mask_period=S,
+                       ln=ln_enc)
+        else:
+            # the projected features of the nq selected tokens only: token -> (level, row in the level's tensor); one gathered product per
+            # level (fp32, BN scale applied), the row's own level kept + its BN shift, rounded once; masked tokens -> zero rows
+            nl_ = len(self.shapes)
+            self.sel_rows_lvl = torch.zeros(nl_, M, device=self.dev, dtype=torch.int32)
+            self.sel_level = torch.zeros(M, device=self.dev, dtype=torch.int32)
+            hw_c = (C.c_int32 * nl_)(*[h_ * w_ for h_, w_ in self.shapes])
+            self._keep.append(hw_c)
+            self._add(lib.moy_level_rows, self.topk_local.data_ptr(), B, nq, nl_, hw_c, self.sel_rows_lvl.data_ptr(), self.sel_level.data_ptr(),
+                      meta=dict(name=f"level_rows M{M}", bytes=M * (4 + 4 * nl_ + 4), flops=0))
+            G = self._buf(nl_ * M, hd, torch.float32)
+            shifts = self._dev(torch.stack([t_.float() for t_ in fold["t"]]))
+            for li, (src_view, _) in enumerate(head_src):
+                cin = arch.head_ch[li]
+                Wt = self._weight(sd[f"{d}.input_proj.{li}.0.weight"].reshape(hd, cin))
+                self._gemm(src_view, Wt, hd, cin, View(G[li * M:(li + 1) * M]), M, scale=self._dev(fold["s"][li].float()),
+                           a_rows=self.sel_rows_lvl[li], out_f32=True)
+            fsel = View(self._buf(M, hd))
+            self._add(lib.moy_level_select, G.data_ptr(), M * hd, hd, self.sel_level.data_ptr(), shifts.data_ptr(), self.topk_local.data_ptr(),
+                      self.valid.data_ptr(), M, hd, fsel.ptr, fsel.ld, code,
+                      meta=dict(name=f"level_select M{M}", bytes=M * hd * (4 + self._esz) + M * 8, flops=0))
+            self.feats_selected = fsel
+            self._gemm(fsel, Wt_enc, hd, hd, sel, M, shift=bias_enc, ln=ln_enc)
         self.features = sel              # [B*nq, 256]: rows of enc_output at the selected tokens, in query order
         self.refer_logit = self._buf(M, 4, torch.float32)
         bbox_mlp(d + ".enc_bbox_head", sel, None, 2, self.anchors, self.topk_local, self.refer_logit)
@@ -831,6 +896,44 @@ class TrackEngine:
         tid = a[lay["o_tid"]:lay["o_nr"]].view(np.int64).reshape(B, R)
         n_ids = a[lay["o_ni"]:lay["o_ni"] + 4 * B].view(np.int32)
         return rows, tid, n_rows, n_ids
+
+    def _fold_plan(self, head_src, valid_host):
+        """Conditions of the folded head (round 4) and its host-side constants, or None for the classic plan.  Folded when: a 16-bit engine
+        at a batch where every per-level launch takes the weight-stationary kernel (B * h*w >= 65536 on the smallest level: the
+        tiled kernel has neither the row runs nor the second row numbering), head-plane value layout, <= 4 classes (the fused narrow
+        head), level widths of 128 / 256 channels, a valid mask that is one rectangle per level."""
+        arch, B, sd = self.arch, self.B, self.sd
+        if self.dtype == torch.float32 or os.environ.get("MOY_FOLD_PROJ", "1") == "0" or os.environ.get("MOY_VALUE_PLANES", "2") != "2":
+            return None
+        if os.environ.get("MOY_SCORE_RUNS", "1") == "0" or os.environ.get("MOY_GEMM_WREG", "1") == "0" or arch.nc > 4 or arch.hd != 256:
+            return None
+        if any(c not in (128, 256) for c in arch.head_ch) or any(B * h_ * w_ < 65536 for h_, w_ in self.shapes):
+            return None
+        if any((v.ld % 8) or (v.ptr % 16) for v, _ in head_src):
+            return None
+        d = f"model.{len(arch.layers)}.decoder"
+        v = valid_host.bool()
+        rect, off = [], 0
+        for (h_, w_) in self.shapes:
+            m = v[off:off + h_ * w_].view(h_, w_)
+            ys, xs = m.any(1).nonzero().flatten(), m.any(0).nonzero().flatten()
+            if len(ys) == 0:
+                return None
+            y0, y1, x0, x1 = int(ys[0]), int(ys[-1]), int(xs[0]), int(xs[-1])
+            full = torch.zeros_like(m)
+            full[y0:y1 + 1, x0:x1 + 1] = True
+            if not torch.equal(full, m):
+                return None
+            rect.append((y0, y1, x0, x1))
+            off += h_ * w_
+        s_, t_, sWp = [], [], []
+        for li in range(len(self.shapes)):
+            p = f"{d}.input_proj.{li}.1"
+            scale = (sd[p + ".weight"] / torch.sqrt(sd[p + ".running_var"] + BN_EPS)).double()
+            shift = sd[p + ".bias"].double() - sd[p + ".running_mean"].double() * scale
+            Wp = sd[f"{d}.input_proj.{li}.0.weight"].reshape(arch.hd, arch.head_ch[li]).double()
+            s_.append(scale); t_.append(shift); sWp.append(scale[:, None] * Wp)
+        return dict(rect=rect, s=s_, t=t_, sWp=sWp)
 
     def _score_runs(self, valid_host):
         """Round 3: the score pass over the VALID tokens only.  A masked token's enc_output feature is LN(enc_output.bias) whatever

@@ -47,7 +47,7 @@ def pad_weight(w2d: torch.Tensor, dtype) -> torch.Tensor:
 
 def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shift=None, act=L.ACT_NONE, A2=None,
          a_rows=None, a_mask=None, mask_period=0, R=None, ln=None, out_f32=False, M=None, c_rpb=0, c_bstride=0,
-         dot=None, store=True, pre=None, a2_cols=0, planes=None):
+         dot=None, store=True, pre=None, a2_cols=0, planes=None, runs=None, dot_out=None):
     """See moy_gemm.  store=False (with dot): C = NULL, only the fused head's output is produced (returned as (None, dot_out)).
     A: 2-D row-major view [rows, >=Cin] (channels-last pixels or tokens)."""
     _need_gpu(A, Wp)
@@ -94,10 +94,15 @@ def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shi
     a.a2_cols = a2_cols
     if planes is not None:   # (plane_cols, plane_stride in elements): `out` is the first plane [M, plane_cols]
         a.plane_cols, a.plane_stride = planes
-    dot_out = None
+    if runs is not None:     # score pass over row runs: dict(period, levels=[(tok0, pitch, len, rows), ...], a_period=0, a_off=0)
+        a.run_levels, a.run_period = len(runs["levels"]), runs["period"]
+        for i, (t0, pit, ln_, rw) in enumerate(runs["levels"]):
+            a.run_tok0[i], a.run_pitch[i], a.run_len[i], a.run_rows[i] = t0, pit, ln_, rw
+        a.run_a_period, a.run_a_off = runs.get("a_period", 0), runs.get("a_off", 0)
     if dot is not None:     # (w fp32 [n, 256], b fp32 [n]) fused behind the LayerNorm
         dw, db = dot
-        dot_out = torch.empty(M, dw.shape[0], device=A.device, dtype=torch.float32)
+        if dot_out is None:
+            dot_out = torch.empty(M, dw.shape[0], device=A.device, dtype=torch.float32)
         a.dot_w, a.dot_b, a.dot_out, a.dot_n = dw.data_ptr(), db.data_ptr(), dot_out.data_ptr(), dw.shape[0]
     L.check(L.lib().moy_gemm(C.byref(a), _st()), "moy_gemm")
     return out if dot is None else (out, dot_out)

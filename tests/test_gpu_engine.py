@@ -209,6 +209,57 @@ def test_engine_bench_scale_kernel_paths_vs_small_batch():
             assert sf["box_max_err_matched"] < 2.0 * mb and sf["hs_max_err_matched"] < 2.0 * mh, (dt, sf)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_engine_folded_input_proj_plan_vs_classic_plan(dt, monkeypatch):
+    """Round 4: at bench scale (every pyramid level >= 65536 rows per launch: B >= 102 at the C2 shape) input_proj (Conv1x1 + BN, no
+    activation, head.py:838-839) is folded into its two linear consumers -- value projection and score pass read P3/P4/P5 directly
+    with composed weights, the projected features exist for the nq selected tokens only.  Same function, one rounding fewer (the
+    bf16 feature map is never formed), so the folded engine must sit at least as close to fp32 as the classic plan does, and the two
+    16-bit plans must agree with each other as two noise realisations do (previous test's argument)."""
+    from mo_yolo_amd.parity import engine_pair_stats
+    cfg, arch, sd = fixture("c2")
+    B = 104
+    fr = torch.from_numpy(frames_u8(cfg, 0, B)).to(DEV)
+    monkeypatch.setenv("MOY_FOLD_PROJ", "0")
+    classic = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt)
+    monkeypatch.setenv("MOY_FOLD_PROJ", "1")
+    folded = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt)
+    assert folded.fold_proj and not classic.fold_proj and folded.feats is None
+    assert sum("valid-runs" in m["name"] for m in folded.meta) == 3 and not any("level_" in m["name"] for m in classic.meta)
+    oc = {k: v.clone() for k, v in classic.forward(fr).items()}
+    of = {k: v.clone() for k, v in folded.forward(fr).items()}
+    torch.cuda.synchronize()
+    S, nq = folded.S, arch.nq
+    # the value maps and the score logits of ALL tokens: composed 16-bit weights against (16-bit weights o 16-bit features)
+    vc, vf = classic.value_planes.float(), folded.value_planes.float()
+    sc, sf_ = classic.scores_all, folded.scores_all
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    assert float((vc - vf).abs().max()) <= 16 * eps * float(vc.abs().max()), (float((vc - vf).abs().max()), float(vc.abs().max()))
+    assert float((sc - sf_).abs().max()) <= 16 * eps * max(1.0, float(sc.abs().max())), float((sc - sf_).abs().max())
+    # the selected tokens' projected features: fp32 product rounded once, against the classic plan's feature map rows
+    tk = of["topk_ind"].long()
+    rows = (torch.arange(B, device=DEV)[:, None] * S + tk).flatten()
+    fc = classic.feats.tensor().float()[rows]
+    ff = folded.feats_selected.tensor().float()
+    assert float((fc - ff).abs().max()) <= 2 * eps * max(1.0, float(fc.abs().max()))
+    f32 = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=2, dtype=torch.float32)
+    worst = {"c": {}, "f": {}, "cf": {}}
+    for t0 in range(0, B, 2):
+        r = f32.forward(fr[t0:t0 + 2])
+        torch.cuda.synchronize()
+        sub = lambda o: {k: v[t0:t0 + 2] for k, v in o.items() if hasattr(v, "shape") and v.shape[:1] == (B,)}
+        for key, st in (("c", engine_pair_stats(sub(oc), r, nq)), ("f", engine_pair_stats(sub(of), r, nq)),
+                        ("cf", engine_pair_stats(sub(of), sub(oc), nq))):
+            for k in ("box_max_err_matched", "hs_max_err_matched", "score_max_err_matched"):
+                worst[key][k] = max(worst[key].get(k, 0.0), st[k])
+            worst[key]["topk_overlap"] = min(worst[key].get("topk_overlap", 1.0), st["topk_overlap"])
+    print(f"[fold] {dt}: classic vs fp32 {worst['c']}  folded vs fp32 {worst['f']}  folded vs classic {worst['cf']}")
+    for k in ("box_max_err_matched", "hs_max_err_matched", "score_max_err_matched"):
+        assert worst["f"][k] <= 1.5 * worst["c"][k] + 1e-6, (k, worst)           # (max over 104 frames of two noise realisations)
+        assert worst["cf"][k] <= 3.0 * worst["c"][k] + 1e-6, (k, worst)
+    assert worst["f"]["topk_overlap"] >= worst["c"]["topk_overlap"] - 0.02 and worst["cf"]["topk_overlap"] > 0.9, worst
+
+
 def test_engine_fp16_c5_batched_sequences_graph():
     """Config C5: fp16 activations/weights (the reference's own `half` switch, predictor.py:131), frames of
     4 sequences batched into one hipGraph-captured step; boxes/scores vs the oracle per sequence."""

@@ -172,6 +172,62 @@ def test_gemm_score_only_layernorm_head(dt, M, nc):
     assert torch.allclose(y.float().cpu(), ref, atol=tol(dt, 3e-5, 4e-2))
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("K", [128, 256])
+def test_gemm_value_planes_per_level_with_row_remap(dt, K):
+    """Round 4: the value projection of ONE pyramid level straight from that level's own [B, h*w, K] tensor (input_proj folded into
+    the weights): N = 1536 into head planes of 32 columns WITH the output row remap -- row (b, i) of the level lands at token
+    b * S + off + i of every plane (transformer.py:255-257 over head.py:1012-1029).  M >= 65536 takes the weight-stationary value
+    form (8 waves x 64 columns; K = 128 is new); it must equal the tiled kernel (the same rows as launches below 65536 rows, whole
+    frames each) bit for bit, leave every other row of the planes alone, and agree with torch fp32."""
+    B, hw, S, off, N = 70, 1000, 1300, 200, 1536
+    M = B * hw
+    x, w = q(rnd(M, K, seed=51), dt), q(rnd(N, K, seed=52, scale=1 / math.sqrt(K)), dt)
+    b = rnd(N, seed=53, scale=0.1)
+    xd, wd = x.to(DEV, dt), ops.pad_weight(w.to(DEV), dt)
+    planes = torch.full((N // 32, B * S + 3, 32), 7.0, device=DEV, dtype=dt)
+    stride = (B * S + 3) * 32
+    ops.gemm(xd, wd, N, K, out=planes[0, off:off + M], shift=b.to(DEV), planes=(32, stride), c_rpb=hw, c_bstride=S)
+    two = torch.full((N // 32, B * S + 3, 32), 7.0, device=DEV, dtype=dt)
+    per = 60                                                            # 60 000 rows per launch: the tiled kernel
+    for b0 in range(0, B, per):
+        b1 = min(B, b0 + per)
+        ops.gemm(xd[b0 * hw:b1 * hw], wd, N, K, out=two[0, b0 * S + off:b0 * S + off + (b1 - b0) * hw], shift=b.to(DEV),
+                 planes=(32, stride), c_rpb=hw, c_bstride=S)
+    torch.cuda.synchronize()
+    assert torch.equal(planes, two), "value form with row remap differs from the tiled kernel"
+    got = planes[:, :B * S].reshape(N // 32, B, S, 32)
+    assert bool((got[:, :, :off] == 7.0).all()) and bool((got[:, :, off + hw:] == 7.0).all()) and bool((planes[:, B * S:] == 7.0).all())
+    ref = (x @ w.T + b).view(B, hw, N // 32, 32).permute(2, 0, 1, 3)
+    assert torch.allclose(got[:, :, off:off + hw].float().cpu(), ref, atol=tol(dt), rtol=tol(dt, 1e-5, 1e-2))
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("K", [128, 256])
+def test_gemm_score_pass_per_level_runs_with_own_row_numbering(dt, K):
+    """Round 4: the score pass (enc_output + LayerNorm + enc_score_head, head.py:1036-1042, no feature output) of ONE pyramid level
+    over the level's valid rectangle, reading that level's own [B, h*w, K] tensor (A row = b * h*w + token - off) while the scores go
+    to the level-major [B, S] raster (row b * S + token): `run_a_period` / `run_a_off`.  Against torch fp32; rows outside the run
+    keep what the buffer held."""
+    B, h, w_, S, off, N, nc = 40, 50, 60, 5000, 700, 256, 1
+    hw = h * w_
+    y0, y1, x0, x1 = 0, h - 1, 0, 32                                  # the valid rectangle (every row, the first 33 columns)
+    x, wt = q(rnd(B * hw, K, seed=61), dt), q(rnd(N, K, seed=62, scale=1 / math.sqrt(K)), dt)
+    b, g, be = rnd(N, seed=63, scale=0.1), rnd(N, seed=64) * 0.2 + 1.0, rnd(N, seed=65, scale=0.1)
+    dw, db = rnd(nc, N, seed=66, scale=0.1), rnd(nc, seed=67)
+    xd, wd = x.to(DEV, dt), ops.pad_weight(wt.to(DEV), dt)
+    scores = torch.full((B * S, nc), -5.0, device=DEV)
+    runs = dict(period=S, levels=[(off + y0 * w_ + x0, w_, x1 - x0 + 1, y1 - y0 + 1)], a_period=hw, a_off=off)
+    ops.gemm(xd, wd, N, K, M=B * S, shift=b.to(DEV), ln=(g.to(DEV), be.to(DEV)), dot=(dw.to(DEV), db.to(DEV)), store=False, runs=runs,
+             dot_out=scores)
+    torch.cuda.synchronize()
+    ref = (F.layer_norm(x @ wt.T + b, (N,), g, be, 1e-5) @ dw.T + db).view(B, h, w_, nc)
+    got = scores.cpu().view(B, S, nc)
+    lvl = got[:, off:off + hw].view(B, h, w_, nc)
+    assert torch.allclose(lvl[:, y0:y1 + 1, x0:x1 + 1], ref[:, y0:y1 + 1, x0:x1 + 1], atol=tol(dt, 5e-5, 5e-2))
+    assert bool((lvl[:, :, x1 + 1:] == -5.0).all()) and bool((got[:, :off] == -5.0).all()) and bool((got[:, off + hw:] == -5.0).all())
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_upsampled_accumulator_seed(dt):
     """Conv1x1(Concat[Upsample2x(u), s]) == GEMM over s seeded with the nearest-2x rows of the half-resolution product W_u.u
