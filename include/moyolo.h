@@ -472,6 +472,14 @@ int moy_level_rows(const int32_t* tok_local, int B, int nq, int n_levels, const 
 int moy_level_select(const float* G, int64_t level_stride, int64_t ldg, const int32_t* level, const float* shift,
                      const int32_t* tok_local, const uint8_t* valid, int M, int N, void* dst, int64_t ldd, int dtype, void* stream);
 
+/* Round 4: compute-unit budget of the calling host THREAD's following launches.  The persistent kernels behind moy_gemm (the
+ * weight-stationary 1x1 / value / score kernel, the weight-stationary 3x3 convolution) size their grids for `n_cus` compute units
+ * instead of the device's; 0 = the whole device (the default).  Results never depend on it.  The engine uses it to run the
+ * write-bound value projection of the P3 level on one half of the chip beside the matrix-rate-bound P4 / P5 branch of the neck on
+ * the other (two branches of the hipGraph; engine.py `_plan_fork`, measured by tools/probes/cu_share.py).  The reference has no
+ * counterpart: its launch geometry is cuDNN's / cuBLAS's own.  Returns the previous budget. */
+int moy_set_cu_limit(int n_cus);
+
 /* Elementwise helpers. */
 /* dst T [M, N] (ldd) = src T [rows[m], :] (lds): row gather (features[batch_ind, topk_ind], head.py:1096). N % 8 == 0. */
 int moy_gather_rows(const void* src, int64_t lds, const int32_t* rows, int M, int N, void* dst, int64_t ldd, int dtype,

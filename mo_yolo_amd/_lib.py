@@ -109,6 +109,7 @@ SIGNATURES = {
     "moy_gather_rows": (C.c_int, [vp, i64, vp, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
     "moy_level_rows": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "moy_level_select": (C.c_int, [vp, i64, i64, vp, vp, vp, vp, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
+    "moy_set_cu_limit": (C.c_int, [C.c_int]),
     "moy_cast_f32_to": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
     "moy_sigmoid_f32": (C.c_int, [vp, C.c_int, vp, vp]),
     "moy_msda_prep": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]),

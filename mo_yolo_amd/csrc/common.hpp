@@ -203,4 +203,19 @@ inline int garbage_mode_env(const char* name) {
   return v;
 }
 
+// moy_set_cu_limit(n) (per host thread) or MOY_CU_LIMIT=<n> (read at every launch; probes): the persistent kernels (gemm_wreg,
+// conv_ws) size their grids for n compute units instead of the device's.  Results do not depend on it (the row-tile walk is the
+// same); used by the engine's forked value projection and by the CU-partition measurements of tools/probes/cu_share.py.
+int& cu_limit_slot();
+inline int cu_limit(int n) {
+  int v = cu_limit_slot();
+  if (v <= 0) {
+    const char* e = getenv("MOY_CU_LIMIT");
+    v = e ? atoi(e) : 0;
+  }
+  v = v / 8 * 8;
+  if (v >= 8 && v < n) n = v;
+  return n;
+}
+
 }  // namespace moy

@@ -679,7 +679,7 @@ static int launch_conv_ws_pipe(ConvWsParams& p, int B, hipStream_t st) {
   p.fd_timg = make_fastdiv((uint32_t)p.tiles_img);
   p.fd_tx = make_fastdiv((uint32_t)p.tiles_x);
   p.per_xcd = (p.ntiles + 7) / 8;
-  p.bpx = cws_num_cus() / 8 * OCC;
+  p.bpx = cu_limit(cws_num_cus()) / 8 * OCC;
   if (p.bpx < 1) p.bpx = 1;
   if (p.bpx > p.per_xcd) p.bpx = p.per_xcd;
   hipLaunchKernelGGL(kern, dim3(8 * p.bpx), dim3(512), LDS, st, p);
@@ -1041,7 +1041,7 @@ static int launch_conv_ws_pp(ConvWsParams& p, int B, hipStream_t st) {
   p.fd_timg = make_fastdiv((uint32_t)p.tiles_img);
   p.fd_tx = make_fastdiv((uint32_t)p.tiles_x);
   p.per_xcd = (p.ntiles + 7) / 8;
-  p.bpx = cws_num_cus() / 8;
+  p.bpx = cu_limit(cws_num_cus()) / 8;
   if (p.bpx < 1) p.bpx = 1;
   if (p.bpx > p.per_xcd) p.bpx = p.per_xcd;
   hipLaunchKernelGGL(kern, dim3(8 * p.bpx), dim3(512), LDS, st, p);
@@ -1247,7 +1247,7 @@ static int launch_conv_s2(ConvS2Params& p, int B, hipStream_t st) {
   p.fd_timg = make_fastdiv((uint32_t)p.tiles_img);
   p.fd_tx = make_fastdiv((uint32_t)p.tiles_x);
   p.per_xcd = (p.ntiles + 7) / 8;
-  p.bpx = cws_num_cus() / 8;
+  p.bpx = cu_limit(cws_num_cus()) / 8;
   if (p.bpx < 1) p.bpx = 1;
   if (p.bpx > p.per_xcd) p.bpx = p.per_xcd;
   hipLaunchKernelGGL(kern, dim3(8 * p.bpx), dim3(512), LDS, st, p);
@@ -1286,7 +1286,7 @@ static int launch_conv_ws(ConvWsParams& p, int B, hipStream_t st) {
   p.fd_timg = make_fastdiv((uint32_t)p.tiles_img);
   p.fd_tx = make_fastdiv((uint32_t)p.tiles_x);
   p.per_xcd = (p.ntiles + 7) / 8;
-  p.bpx = cws_num_cus() / 8 * OCC;         // resident blocks per XCD
+  p.bpx = cu_limit(cws_num_cus()) / 8 * OCC;         // resident blocks per XCD
   if (p.bpx < 1) p.bpx = 1;
   if (p.bpx > p.per_xcd) p.bpx = p.per_xcd;
   hipLaunchKernelGGL(kern, dim3(8 * p.bpx), dim3(512), G::LDS, st, p);

@@ -923,6 +923,20 @@ static int dispatch_tile(GemmParams& p, bool ln, hipStream_t st) {
 
 using namespace moy;
 
+namespace moy {
+int& cu_limit_slot() {
+  static thread_local int v = 0;
+  return v;
+}
+}  // namespace moy
+
+extern "C" int moy_set_cu_limit(int n_cus) {
+  int& v = moy::cu_limit_slot();
+  const int prev = v;
+  v = n_cus > 0 ? n_cus : 0;
+  return prev;
+}
+
 extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->W) return MOY_EINVAL;
   if (!a->C && !(a->ln_g && a->dot_n > 0 && a->dot_out)) return MOY_EINVAL;   // rows may be dropped only when the fused head is the output

@@ -586,7 +586,7 @@ static int launch_wreg(WregParams& p, hipStream_t st) {
       return MOY_ELAUNCH;
     attr_lds = lds;
   }
-  const int slots = wreg_num_cus() / 8 * OCC;          // resident blocks per XCD
+  const int slots = cu_limit(wreg_num_cus()) / 8 * OCC;          // resident blocks per XCD
   p.ntiles = ((p.run_levels ? p.run_mv : p.M) + BM - 1) / BM;
   p.ngroups = p.N / (NW * WC);
   p.lanes = slots / p.ngroups;

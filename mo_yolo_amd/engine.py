@@ -97,6 +97,7 @@ class TrackEngine:
         self._graphs: Dict[int, object] = {}
         with torch.no_grad():
             self._build()
+        self._plan_fork()
 
     # ------------------------------------------------------------------ helpers
     def _dev(self, t, dtype=None):
@@ -295,8 +296,10 @@ class TrackEngine:
                 cons = [arch.layers[c] for c in consumers.get(cat.i, [])]
                 return (up.kind == "Upsample" and consumers.get(up.i, []) == [cat.i] and len(cons) == 1 and cons[0].kind == "C2f"
                         and os.environ.get("MOY_FUSE_UPSAMPLE", "1") != "0")
+            self._layer_first_step: Dict[int, int] = {}
             for Ls in arch.layers:
                 p = f"model.{Ls.i}"
+                self._layer_first_step[Ls.i] = len(self._steps)
                 x = outv[Ls.src[0]] if Ls.src[0] >= 0 else None
                 hin = hw[Ls.src[0]] if Ls.src[0] >= 0 else (H, W)
                 if Ls.kind == "Conv" and Ls.i == 0 and self._fuse_stem_l1(consumers):
@@ -473,6 +476,8 @@ class TrackEngine:
                     bc = (Wv.double() @ fold["t"][li] + bv.double()).float()
                     self._gemm(src_view, self._weight(Wc), ndl * hd, arch.head_ch[li], View(self.value_planes[off:]), B * h_ * w_,
                                shift=self._dev(bc), planes=(dh, B * S * dh), c_rpb=h_ * w_, c_bstride=S)
+                    if li == 0:
+                        self._value_p3_step = len(self._steps) - 1
                     off += h_ * w_
         elif vmode == "1":      # A/B: one contiguous [B*S, hd] matrix per layer
             self.value_planes = self._buf(ndl * B * S, hd)
@@ -897,6 +902,32 @@ class TrackEngine:
         n_ids = a[lay["o_ni"]:lay["o_ni"] + 4 * B].view(np.int32)
         return rows, tid, n_rows, n_ids
 
+    def _plan_fork(self):
+        """Round 4, CU partition inside the plan -- MEASURED AND LEFT OFF (MOY_FORK_VALUE=<units> switches it on).
+        tools/probes/cu_share.py: the write-bound P3 value projection (9.9 GB per 288 frames) keeps 72 % of its rate on HALF of the
+        compute units and a chain of eight P4-level 3x3 convs keeps 65 % of its rate on the other half, so side by side that pair
+        finishes in 0.82 of its back-to-back time (0.95 as two whole-chip streams).  The plan itself has no such partner for the
+        launch: between the moment layer 15 has produced P3 and the first deformable sampling there are 1.7 ms of mixed launches (two
+        such convs; the rest 1x1 products that are bandwidth bound themselves and P5-level launches that do not fill even half a
+        chip), and a pair shorter than ~1.4 ms of conv work measures >= 1.0 in the probe too.  In the engine: 41.00 ms (plan order)
+        vs 41.07 ms (forked, 128 | 128 units) per 288-frame pass eagerly on one stream, 37.52 vs 38.32 ms per 2 x 288 frames from the
+        hipGraphs of bench.py (112 and 144 units: 37.94, 38.49).  The fork stays as a switch with its bit-identity test; the two
+        free-running engines of StreamedEngines remain the overlap mechanism."""
+        self._fork = None
+        L_ = int(os.environ.get("MOY_FORK_VALUE", "0"))
+        step = getattr(self, "_value_p3_step", None)
+        first = getattr(self, "_layer_first_step", {})
+        if L_ <= 0 or step is None or not getattr(self, "fold_proj", False) or 16 not in first:
+            return
+        join = next((i for i, m in enumerate(self.meta) if m["name"].startswith("msda")), None)
+        after = first[16] - 1
+        if join is None or not (0 <= after < step < join):
+            return
+        ncu = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        L_ = max(8, min(ncu - 8, L_ * ncu // 256)) // 8 * 8
+        self._side_stream = torch.cuda.Stream(device=self.dev)
+        self._fork = dict(side=step, after=after, join=join, side_cus=L_, main_cus=ncu - L_)
+
     def _fold_plan(self, head_src, valid_host):
         """Conditions of the folded head (round 4) and its host-side constants, or None for the classic plan.  Folded when: a 16-bit engine
         at a batch where every per-level launch takes the weight-stationary kernel (B * h*w >= 65536 on the smallest level: the
@@ -1011,15 +1042,41 @@ class TrackEngine:
 
     # ------------------------------------------------------------------ run
     def run_steps(self, start=0, stop=None, slot=0):
-        """Enqueue launches [start, stop) on the current stream, reading the frames from input slot `slot`."""
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        """Enqueue launches [start, stop) on the current stream, reading the frames from input slot `slot`.
+        A call that covers the whole forked segment (`self._fork`, see `_plan_fork`) issues the side launch on the engine's side
+        stream between two events -- also under graph capture, where the pair becomes two parallel branches of the hipGraph; a call
+        over a part of the plan (per-launch timing, forward_with_topk) runs every launch in plan order on the whole chip."""
+        cur = torch.cuda.current_stream()
+        st = C.c_void_p(cur.cuda_stream)
         stem = getattr(self, "_stem_step", -1) if slot else -1
-        for i, (fn, args) in enumerate(self._steps[start:stop], start):
-            if i == stem:
-                args = (self.inputs[slot].data_ptr(),) + args[1:]
-            rc = fn(*args, st)
-            if rc != 0:
-                L.check(rc, fn.__name__)
+        fk = getattr(self, "_fork", None)
+        n = len(self._steps)
+        if fk is not None and not (start <= fk["after"] and (stop is None or stop >= n or stop > fk["join"])):
+            fk = None
+        try:
+            for i, (fn, args) in enumerate(self._steps[start:stop], start):
+                if fk is not None:
+                    if i == fk["side"]:
+                        continue                                   # issued at the fork point
+                    if i == fk["join"]:
+                        cur.wait_stream(self._side_stream)
+                        self.lib.moy_set_cu_limit(0)
+                if i == stem:
+                    args = (self.inputs[slot].data_ptr(),) + args[1:]
+                rc = fn(*args, st)
+                if rc != 0:
+                    L.check(rc, fn.__name__)
+                if fk is not None and i == fk["after"]:
+                    self._side_stream.wait_stream(cur)
+                    self.lib.moy_set_cu_limit(fk["side_cus"])                 # (grid size of the persistent kernels, this thread's next launches)
+                    sfn, sargs = self._steps[fk["side"]]
+                    rc = sfn(*sargs, C.c_void_p(self._side_stream.cuda_stream))
+                    if rc != 0:
+                        L.check(rc, sfn.__name__)
+                    self.lib.moy_set_cu_limit(fk["main_cus"])
+        finally:
+            if fk is not None:
+                self.lib.moy_set_cu_limit(0)
 
     def forward(self, frames: torch.Tensor | None = None, slot: int = 0):
         """frames: uint8 [B,H,W,3] BGR (input_format 'u8') or float32 [B,3,H,W] RGB in [0,1] ('f32'),

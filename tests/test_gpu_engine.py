@@ -260,6 +260,39 @@ def test_engine_folded_input_proj_plan_vs_classic_plan(dt, monkeypatch):
     assert worst["f"]["topk_overlap"] >= worst["c"]["topk_overlap"] - 0.02 and worst["cf"]["topk_overlap"] > 0.9, worst
 
 
+def test_engine_forked_value_projection_bit_identical_eager_and_graph(monkeypatch):
+    """Round 4: the P3 value projection on a side stream / half of the compute units beside the P4 / P5 branch of the neck
+    (engine.py `_plan_fork`; moy_set_cu_limit only changes how many persistent blocks walk the same row tiles): outputs, value
+    planes and scores bit-identical to the plan on one stream, eagerly and replayed from the hipGraph (two parallel branches)."""
+    cfg, arch, sd = fixture("c2")
+    B = 104
+    fr = torch.from_numpy(frames_u8(cfg, 0, B)).to(DEV)
+    monkeypatch.setenv("MOY_FORK_VALUE", "0")
+    plain = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=torch.bfloat16)
+    monkeypatch.setenv("MOY_FORK_VALUE", "128")
+    forked = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=torch.bfloat16)
+    assert plain._fork is None and forked._fork is not None and forked.fold_proj
+    fk = forked._fork
+    assert forked.meta[fk["side"]]["name"].startswith("gemm1x1") and "N1536" in forked.meta[fk["side"]]["name"]
+    assert fk["after"] < fk["side"] < fk["join"] and forked.meta[fk["join"]]["name"].startswith("msda")
+    keys = ("scores", "boxes", "obj_idxes", "topk_ind", "hs", "rows", "n_rows")
+    op = {k: v.clone() for k, v in plain.forward(fr).items()}
+    vp, sp = plain.value_planes.clone(), plain.scores_all.clone()
+    of = {k: v.clone() for k, v in forked.forward(fr).items()}
+    torch.cuda.synchronize()
+    assert torch.equal(vp, forked.value_planes) and torch.equal(sp, forked.scores_all)
+    for k in keys:
+        assert torch.equal(op[k], of[k]), k
+    forked.value_planes.zero_()
+    forked.capture()
+    og = forked.forward(fr)
+    torch.cuda.synchronize()
+    assert torch.equal(vp, forked.value_planes)
+    for k in keys:
+        assert torch.equal(op[k], og[k]), ("graph", k)
+    assert forked.lib.moy_set_cu_limit(0) == 0          # the budget is back to the whole device after a pass
+
+
 def test_engine_fp16_c5_batched_sequences_graph():
     """Config C5: fp16 activations/weights (the reference's own `half` switch, predictor.py:131), frames of
     4 sequences batched into one hipGraph-captured step; boxes/scores vs the oracle per sequence."""
