@@ -396,7 +396,7 @@ static int launch_c2f(C2fParams& p, hipStream_t st) {
   p.tiles_x = (p.Wd + p.TW - 1) / p.TW;
   p.nstrips = p.B * p.tiles_x;
   p.fd_tx = make_fastdiv((uint32_t)p.tiles_x);
-  p.bpx = c2f_num_cus() / 8;
+  p.bpx = cu_limit(c2f_num_cus()) / 8;
   if (p.bpx < 1) p.bpx = 1;
   const int nb = 8 * p.bpx, nty = (p.H + C2F_TH - 1) / C2F_TH;
   p.nfull = p.nstrips / nb;

@@ -124,7 +124,7 @@ constexpr int wreg_lds_bytes() {
 // ABL (timing-only builds, MOY_WREG_ABL, garbage results): bit 0 no MFMAs, bit 1 output stores dropped, bit 2 no activation DMA past
 // the prologue, bit 4 s_memtime stamps per phase at the head of C
 template <typename T, int BM, int NBUF, int OCC, bool LN, int NW, int WC, int K, int ABL = 0, bool PRE = false>
-__global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParams p) {
+__global__ __launch_bounds__(64 * NW, (NW == 8 && OCC == 2) ? 4 : OCC) void gemm_wreg_kernel(const WregParams p) {
   static_assert((NW == 4 || NW == 8) && (!LN || (NW == 4 && WC == 64 && (K == 256 || K == 128))), "score mode: 4 waves x 64 columns, K = 256 or 128");
   static_assert((WC == 32 || WC == 64) && K % 64 == 0 && K <= 512, "column width per wave / reduction length");
   constexpr int BNB = NW * WC;             // output columns per block
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
     constexpr int k = decltype(kc)::value, i = k / (NT / 2), t = k % (NT / 2);
     const bool live = !(ABL & 2);
     const int rr = i * 16 + r;
-    if (WC == 64 && p.plane_cols == 32 && p.c_rpb) {
+    if (p.plane_cols == 32 && p.c_rpb) {
       // head planes AND an output row remap (round 4: the value projection of ONE pyramid level straight from that level's own
       // tensor -- rows (b, i) of the level land at token b * S + off + i of the plane; `C` already points at row `off`): per-lane
       // row offsets into a descriptor that spans the plane
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wreg_kernel(const WregParam
       const uint32_t mo = (uint32_t)(bq * p.c_bstride + (m - bq * p.c_rpb));
       const uint32_t vo = (live && m < p.M) ? mo * 64u + q * 16 : 0x80000000u;
       __builtin_amdgcn_raw_buffer_store_b128(pk[i][t], rsC, vo, 0, 0);
-    } else if (WC == 64 && p.plane_cols == 32) {
+    } else if (p.plane_cols == 32) {
       // head planes [plane][row][32]: pair-group t of the wave IS plane 2w + t; a store instruction = 16 rows x 64 B = 1 KB contiguous
       T* cb = static_cast<T*>(p.C) + (int64_t)((ncol >> 5) + t) * p.plane_stride + (int64_t)(live ? m0 : 0) * 32;
       const int64_t left = live ? (int64_t)(p.M - m0) * 64 : 0;
@@ -595,13 +595,29 @@ static int launch_wreg(WregParams& p, hipStream_t st) {
   return launch_status();
 }
 
+// Row-tile height of the 32-columns-per-wave forms: MOY_WREG_BM=32|64|128 overrides the per-shape choice (A/B runs; a height whose
+// activation ring does not fit falls back to the next smaller one).
+static int wreg_bm_env() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MOY_WREG_BM"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
 // 8 waves x 32 columns = 256 columns per block, any K in {128, 256, 384, 512}: the 1x1 convs / input_proj with 256 outputs
 template <typename T>
 static int launch_wreg_k(WregParams& p, int K, hipStream_t st) {
+  const int bm = wreg_bm_env();
   switch (K) {
-    case 128: return launch_wreg<T, 32, 3, 1, false, 8, 32, 128>(p, st);
-    case 256: return launch_wreg<T, 32, 3, 1, false, 8, 32, 256>(p, st);
-    case 384: return launch_wreg<T, 32, 3, 1, false, 8, 32, 384>(p, st);
+    case 128:
+      if (bm == 128) return launch_wreg<T, 128, 3, 1, false, 8, 32, 128>(p, st);
+      if (bm == 64) return launch_wreg<T, 64, 3, 1, false, 8, 32, 128>(p, st);
+      return launch_wreg<T, 32, 3, 1, false, 8, 32, 128>(p, st);
+    case 256:
+      if (bm >= 64) return launch_wreg<T, 64, 3, 1, false, 8, 32, 256>(p, st);
+      return launch_wreg<T, 32, 3, 1, false, 8, 32, 256>(p, st);
+    case 384:
+      if (bm >= 64) return launch_wreg<T, 64, 3, 1, false, 8, 32, 384>(p, st);
+      return launch_wreg<T, 32, 3, 1, false, 8, 32, 384>(p, st);
     case 512: return launch_wreg<T, 32, 3, 1, false, 8, 32, 512>(p, st);
     default: return MOY_ENOSYS;
   }
@@ -610,10 +626,17 @@ static int launch_wreg_k(WregParams& p, int K, hipStream_t st) {
 // 4 waves x 32 columns = 128 columns per block, two blocks per CU: the 1x1 convs with 128 outputs (C2f cv1 / cv2 at the P3 level)
 template <typename T>
 static int launch_wreg_n128(WregParams& p, int K, hipStream_t st) {
+  const int bm = wreg_bm_env();
   switch (K) {
-    case 128: return launch_wreg<T, 32, 3, 2, false, 4, 32, 128>(p, st);
-    case 192: return launch_wreg<T, 32, 3, 2, false, 4, 32, 192>(p, st);
-    case 256: return launch_wreg<T, 32, 3, 2, false, 4, 32, 256>(p, st);
+    case 128:
+      if (bm >= 64) return launch_wreg<T, 64, 3, 2, false, 4, 32, 128>(p, st);
+      return launch_wreg<T, 32, 3, 2, false, 4, 32, 128>(p, st);
+    case 192:
+      if (bm >= 64) return launch_wreg<T, 64, 3, 2, false, 4, 32, 192>(p, st);
+      return launch_wreg<T, 32, 3, 2, false, 4, 32, 192>(p, st);
+    case 256:
+      if (bm >= 64) return launch_wreg<T, 64, 2, 2, false, 4, 32, 256>(p, st);
+      return launch_wreg<T, 32, 3, 2, false, 4, 32, 256>(p, st);
     default: return MOY_ENOSYS;
   }
 }
@@ -714,8 +737,37 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   // block per CU fits); 8 waves x 512 columns, BM 32 / 3 buffers, one block per CU: 6 % faster than the first (same device) -- half as
   // many blocks re-fetch an activation tile that has left the L2.  (Those variants left the tree in round 3; MOY_WREG_VARIANT=2
   // keeps the 4-wave form selectable for A/B runs.)
+  if (a->K == 128 && a->dtype == MOY_BF16) {      // A/B forms of the K = 128 value launch (MOY_WREG_V128; bf16 only)
+    static int v128 = -1;
+    if (v128 < 0) { const char* e = getenv("MOY_WREG_V128"); v128 = e ? atoi(e) : 0; }
+    switch (v128) {
+      case 1: return launch_wreg<bf16_t, 32, 3, 2, false, 8, 64, 128>(p, st);     // two blocks per CU
+      case 2: return launch_wreg<bf16_t, 32, 4, 2, false, 8, 64, 128>(p, st);     // ... and a deeper ring
+      case 3: return launch_wreg<bf16_t, 32, 5, 1, false, 8, 64, 128>(p, st);     // one block, ring of 5
+      case 4: return launch_wreg<bf16_t, 64, 3, 1, false, 8, 64, 128>(p, st);     // 64-row tiles
+      case 5: return launch_wreg<bf16_t, 64, 3, 2, false, 8, 64, 128>(p, st);     // 64-row tiles, two blocks per CU
+      case 6: return launch_wreg<bf16_t, 64, 2, 1, false, 8, 64, 128>(p, st);     // 64-row tiles, ring of 2
+      case 7: return launch_wreg<bf16_t, 64, 4, 1, false, 8, 64, 128>(p, st);     // 64-row tiles, ring of 4
+      case 9: return launch_wreg<bf16_t, 32, 3, 1, false, 8, 64, 128>(p, st);     // 32-row tiles (the form before the measurement)
+      case 10: return launch_wreg<bf16_t, 128, 3, 1, false, 8, 32, 128>(p, st);   // 32 columns per wave (one plane), 128-row tiles
+      case 11: return launch_wreg<bf16_t, 64, 3, 1, false, 8, 32, 128>(p, st);    // 32 columns per wave, 64-row tiles
+      default: break;
+    }
+  }
+  if (a->K == 256 && a->dtype == MOY_BF16) {      // A/B forms of the K = 256 value launches (MOY_WREG_V256; bf16 only)
+    static int v256 = -1;
+    if (v256 < 0) { const char* e = getenv("MOY_WREG_V256"); v256 = e ? atoi(e) : 0; }
+    switch (v256) {
+      case 1: return launch_wreg<bf16_t, 64, 3, 1, false, 8, 32, 256>(p, st);     // 32 columns per wave (one plane), 64-row tiles
+      case 2: return launch_wreg<bf16_t, 32, 3, 1, false, 8, 32, 256>(p, st);     // 32 columns per wave, 32-row tiles
+      default: break;
+    }
+  }
+  // round 4, measured (tools/probes/cu_share.py --value-only, 288 frames of the P3 level, 9.9 GB): 32-row tiles 2.53 ms, two blocks
+  // per CU (spills) 5.4, ring of 5 2.53, 64-ROW TILES 1.93 ms = 5.1 TB/s -- a plane's run per tile is 4 KB instead of 2 KB and
+  // the barrier / DMA-issue cadence per byte halves
   if (a->K == 128)      // (valueform: N % 512 == 0, head planes)
-    return a->dtype == MOY_BF16 ? launch_wreg<bf16_t, 32, 3, 1, false, 8, 64, 128>(p, st) : launch_wreg<f16_t, 32, 3, 1, false, 8, 64, 128>(p, st);
+    return a->dtype == MOY_BF16 ? launch_wreg<bf16_t, 64, 3, 1, false, 8, 64, 128>(p, st) : launch_wreg<f16_t, 64, 3, 1, false, 8, 64, 128>(p, st);
   if (a->dtype == MOY_BF16) {
     if (variant == 2 || a->N % 512) return launch_wreg<bf16_t, 32, 3, 2>(p, st);
     // timing-only builds of the value-projection form (tools/probes/wreg_ablate.py): see the kernel's ABL comment

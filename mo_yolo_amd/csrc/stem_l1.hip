@@ -318,7 +318,7 @@ static int launch_stem_l1(StemL1Params& p, hipStream_t st) {
   p.fd_timg = make_fastdiv((uint32_t)p.tiles_img);
   p.fd_tx = make_fastdiv((uint32_t)p.tiles_x);
   p.per_xcd = (p.ntiles + 7) / 8;
-  p.bpx = sl1_num_cus() / 8 * 2;           // two resident blocks per CU
+  p.bpx = cu_limit(sl1_num_cus()) / 8 * 2;           // two resident blocks per CU
   if (p.bpx > p.per_xcd) p.bpx = p.per_xcd;
   if (p.bpx < 1) p.bpx = 1;
   hipLaunchKernelGGL(kern, dim3(8 * p.bpx), dim3(512), LDS, st, p);

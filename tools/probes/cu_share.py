@@ -35,6 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--frames", type=int, default=288)
+    ap.add_argument("--value-only", action="store_true", help="time the value launch alone on the whole chip and exit (A/B of MOY_WREG_V128 forms)")
     a = ap.parse_args()
     B = a.frames
     g = torch.Generator(device="cpu").manual_seed(1)
@@ -52,6 +53,20 @@ def main():
     def value():
         ops.gemm(x3, wv, 1536, 128, out=planes[0, :B * hw3], shift=bv, planes=(32, B * S * 32), c_rpb=hw3, c_bstride=S)
 
+    if a.value_only:
+        value()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ts = []
+        for _ in range(5):
+            e0.record()
+            for _ in range(10):
+                value()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / 10)
+        print("value_ms", os.environ.get("MOY_WREG_V128", "0"), [round(t, 4) for t in ts], flush=True)
+        return
     w128 = ops.pad_weight(rnd(128, 128, scale=0.1).to(DEV), DT)
     sc, sh = (rnd(128) * 0.2 + 1).to(DEV), rnd(128, scale=0.1).to(DEV)
     y3 = torch.empty(B * hw3, 128, device=DEV, dtype=DT)
