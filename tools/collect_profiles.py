@@ -35,9 +35,16 @@ if os.path.exists(f"{src}/traffic_step.json") and os.path.exists(f"{src}/traffic
                                         source=f"profiles/{tag}_b288_hbm_traffic_step.json: {st['formula']}; {st['steps']} passes of the "
                                                f"plan at {st['frames_per_step']} frames, one engine, one stream, eager launches")
     rows = json.load(open(f"{src}/traffic.json"))
-    for r in rows:          # the dominant launch: value projection = the 8-wave x 512-column weight-stationary GEMM, grid 122880
-        if "gemm_wreg_kernel" in r["kernel"] and "8, 64, 256" in r["kernel"] and r["grid"] == "122880":
-            doc["launches"]["gemm1x1 M3907008 N1536 K256"] = dict(
+    for r in rows:
+        # the dominant launch.  Round 4 (input_proj folded): the value projection of the P3 level, K = 128, 64-row tiles -- the only
+        # dispatch of that template per pass.  Rounds 2-3: one value projection over all tokens, K = 256 (kept for old trace dirs).
+        key = None
+        if "gemm_wreg_kernel" in r["kernel"] and "64, 3, 1, false, 8, 64, 128" in r["kernel"] and r["grid"] == "122880":
+            key = "gemm1x1 M2976768 N1536 K128"
+        elif "gemm_wreg_kernel" in r["kernel"] and "32, 3, 1, false, 8, 64, 256" in r["kernel"] and r["grid"] == "122880" and r["dispatches"] == 5:
+            key = "gemm1x1 M3907008 N1536 K256"
+        if key:
+            doc["launches"][key] = dict(
                 hbm_bytes=r["hbm_bytes"], source=f"profiles/{tag}_b288_hbm_traffic_pmc.json ({r['kernel'][:70]}, grid {r['grid']}, "
                 f"{r['dispatches']} dispatches): (2*FETCH_SIZE + WRITE_SIZE)*1024, fetch {r['fetch_kb_raw']:.0f} KB raw, write {r['write_kb']:.0f} KB")
     json.dump(doc, open(tp, "w"), indent=1)
