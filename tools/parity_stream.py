@@ -192,6 +192,7 @@ def main():
     o["note"] = ("frames of the free-running stream, NOT the margin fixtures: adjacent encoder scores of unconstrained frames come as close "
                  "as 1e-6 relative, so two correct fp32 evaluations rank a few near-ties differently (topk_equal < frames) and ids, which "
                  "the reference hands out in query order (head.py:1232-1237), permute with them; the rows themselves agree (matched by token)")
+    doc["plan"] = {k: {"input_proj_folded": bool(getattr(e, "fold_proj", False)), "launches": e.num_launches} for k, e in engines.items()}
     doc["f32_engine_vs_cpu_oracle"] = o
     doc["agreement_hota_vs_f32_engine"] = agree
     doc["hota_vs_synthetic_scene"] = hota
