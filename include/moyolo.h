@@ -141,6 +141,15 @@ typedef struct moy_gemm_args {
    * [B, h*w, C] tensor, scores = the level-major [B, S] token raster): A row = b * run_a_period + (token - run_a_off).
    * run_a_period == 0: the same numbering (A row = score row). */
   int32_t run_a_period, run_a_off;
+  /* round 4, optional POST 1x1 conv: the conv's ONLY consumer is a 1x1 Conv (C2f.cv1 behind a down-sampling Conv:
+   * yolo_track.yaml:19-20, block.py:225-235 `self.cv1(x)`), applied to every finished output tile while it sits on chip:
+   *     C [M, post_n] = post_act( (act(conv(A)) rounded to the storage type) . post_W^T * post_scale + post_shift )
+   * so the conv's own output never reaches HBM.  post_W: storage type, [post_n][ceil64(N)] like W.  Supported by the stride-2
+   * weight-stationary kernel for Cin = 64, N = post_n = 128, SiLU twice; every other shape: MOY_ENOSYS (never ignored). */
+  const void* post_W;
+  const float* post_scale;
+  const float* post_shift;
+  int32_t post_n, post_act;
 } moy_gemm_args;
 
 int moy_gemm(const moy_gemm_args* args, void* stream);

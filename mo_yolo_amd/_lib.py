@@ -31,6 +31,7 @@ class GemmArgs(C.Structure):
         ("plane_cols", i32), ("plane_stride", i64),
         ("run_levels", i32), ("run_period", i32), ("run_tok0", i32 * 4), ("run_pitch", i32 * 4), ("run_len", i32 * 4), ("run_rows", i32 * 4),
         ("run_a_period", i32), ("run_a_off", i32),
+        ("post_W", vp), ("post_scale", vp), ("post_shift", vp), ("post_n", i32), ("post_act", i32),
     ]
 
 

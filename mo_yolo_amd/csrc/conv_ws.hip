@@ -1065,9 +1065,17 @@ struct ConvS2Params {
   int Hin, Win, Hout, Wout;
   int tiles_x, tiles_img, ntiles, per_xcd, bpx;
   FastDiv fd_timg, fd_tx;
+  // POST forms (round 4, moy_gemm_args.post_*): the conv's only consumer is a 1x1 conv (C2f.cv1 behind a down-sampling Conv,
+  // yolo_track.yaml:19-20 over block.py:225-235), applied to the finished tile while it sits in LDS: C = SiLU(BN2(tile . W2^T))
+  const void* W2; int Kpad2;
+  const float* scale2; const float* shift2;
 };
 
-template <typename T, int C, int N, int TH, int WN, int NBUF>
+//   POST: the tile, rounded to T exactly where the unfused plan stored it, is the B operand of a second product with the N x N
+//   weights of the consumer (16 output columns per wave in registers, k ascending in 32-wide panels as every other kernel of
+//   the library sums it): BN + SiLU again into a SECOND staging tile, which the unchanged store code writes out.  The conv's own
+//   output never reaches HBM.
+template <typename T, int C, int N, int TH, int WN, int NBUF, bool POST = false>
 __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvS2Params p) {
   constexpr int PW = 33, PH = 2 * TH + 1, NPIX = PH * PW, CPP = C / 8, NCP = N / 8, TPX = TH * 16;
   constexpr int PIECES = (NPIX * CPP + 63) / 64, IPW = (PIECES + 7) / 8;
@@ -1078,7 +1086,8 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvS2Params p) {
   constexpr int RG = MT < 4 ? MT : 4;
   constexpr uint32_t OOB = 0x80000000u;
   static_assert(TH % WM == 0 && (N / 16) % WN == 0 && TPX * NCP % 512 == 0 && MT % RG == 0, "tile vs waves");
-  static_assert(NBUF * SETB + STGB + 1024 <= 160 * 1024, "LDS budget");
+  static_assert(NBUF * SETB + (POST ? 2 : 1) * STGB + 1024 <= 160 * 1024, "LDS budget");
+  static_assert(!POST || (WM == 1 && N % 32 == 0), "POST: every wave sees all rows of the tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1093,7 +1102,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvS2Params p) {
   const int n_mine = (t_limit - t_first + p.bpx - 1) / p.bpx;
 
   const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);
-  const uint32_t scratch = lds_base + NBUF * SETB + STGB;
+  const uint32_t scratch = lds_base + NBUF * SETB + (POST ? 2 : 1) * STGB;
   const T* __restrict__ Ag = static_cast<const T*>(p.A);
   T* __restrict__ Cg = static_cast<T*>(p.C);
   const int64_t img_a = (int64_t)p.Hin * p.Win * p.lda, img_c = (int64_t)p.Hout * p.Wout * p.ldc;
@@ -1142,6 +1151,20 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvS2Params p) {
           wf[j][tap][cc] = *reinterpret_cast<const u32x4*>(Wg + (int64_t)(n + r) * p.Kpad + tap * C + cc * 32 + q * 8);
       sc[j] = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n + q * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
       sh[j] = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  constexpr int KP2 = N / 32;
+  [[maybe_unused]] u32x4 w2f[POST ? NT : 1][POST ? KP2 : 1];
+  [[maybe_unused]] f32x4 sc2[POST ? NT : 1], sh2[POST ? NT : 1];
+  if constexpr (POST) {
+    const T* W2g = static_cast<const T*>(p.W2);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = (wn * NT + j) * 16;
+#pragma unroll
+      for (int cc = 0; cc < KP2; ++cc) w2f[j][cc] = *reinterpret_cast<const u32x4*>(W2g + (int64_t)(n + r) * p.Kpad2 + cc * 32 + q * 8);
+      sc2[j] = p.scale2 ? *reinterpret_cast<const f32x4*>(p.scale2 + n + q * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+      sh2[j] = p.shift2 ? *reinterpret_cast<const f32x4*>(p.shift2 + n + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
   const int s_px = tid / NCP, s_c = tid % NCP;
@@ -1208,6 +1231,43 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvS2Params p) {
       }
     }
     __syncthreads();
+    const unsigned char* stg_out = stg;
+    if constexpr (POST) {
+      // second product on the finished tile: rows = its TPX pixels, k = its N channels (chunk (cc*4 + q) ^ (pixel & 15) of the row)
+      unsigned char* stg2 = stg + STGB;
+      f32x4 acc2[MT][NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cc = 0; cc < KP2; ++cc) {
+        u32x4 a2[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int opx = i * 16 + r;
+          a2[i] = *reinterpret_cast<const u32x4*>(stg + opx * (N * 2) + (((cc * 4 + q) ^ (opx & (NCP - 1))) * 16));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc2[i][j] = cws_mfma<T>(acc2[i][j], w2f[j][cc], a2[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int ch = (wn * NT + j) * 16 + q * 4;
+#pragma unroll
+        for (int y = 0; y < MT; ++y) {
+          f32x4 v = acc2[y][j] * sc2[j] + sh2[j];
+          v.x = siluf_(v.x); v.y = siluf_(v.y); v.z = siluf_(v.z); v.w = siluf_(v.w);
+          const int opx = y * 16 + r;
+          unsigned char* cell = stg2 + opx * (N * 2) + ((((ch >> 3) ^ (opx & (NCP - 1))) * 16) + ((ch >> 2) & 1) * 8);
+          *reinterpret_cast<u32x2*>(cell) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+        }
+      }
+      __syncthreads();
+      stg_out = stg2;
+    }
     {
       const Tile t = tile_of(it);
       const auto rsC = __builtin_amdgcn_make_buffer_rsrc(Cg + (int64_t)t.b * img_c, 0, (uint32_t)(img_c * 2), 0x00020000);
@@ -1215,7 +1275,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvS2Params p) {
       const bool xok = t.x0 + s_tx < p.Wout;
       u32x4 vv[NPASS];
 #pragma unroll
-      for (int k = 0; k < NPASS; ++k) vv[k] = *reinterpret_cast<const u32x4*>(stg + s_lds + k * PASS_LDS);
+      for (int k = 0; k < NPASS; ++k) vv[k] = *reinterpret_cast<const u32x4*>(stg_out + s_lds + k * PASS_LDS);
 #pragma unroll
       for (int k = 0; k < NPASS; ++k) {
         const bool ok = xok && t.y0 + s_ty + k * PASS_ROWS < p.Hout;
@@ -1229,11 +1289,11 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvS2Params p) {
   cws_wait_vmcnt<0>();
 }
 
-template <typename T, int C, int N, int TH, int WN, int NBUF>
+template <typename T, int C, int N, int TH, int WN, int NBUF, bool POST = false>
 static int launch_conv_s2(ConvS2Params& p, int B, hipStream_t st) {
   constexpr int PIECES = ((2 * TH + 1) * 33 * (C / 8) + 63) / 64;
-  constexpr int LDS = NBUF * PIECES * 1024 + TH * 16 * N * 2 + 1024;
-  auto kern = conv_s2_kernel<T, C, N, TH, WN, NBUF>;
+  constexpr int LDS = NBUF * PIECES * 1024 + (POST ? 2 : 1) * TH * 16 * N * 2 + 1024;
+  auto kern = conv_s2_kernel<T, C, N, TH, WN, NBUF, POST>;
   static bool attr_set = false;
   if (!attr_set) {
     if (LDS > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -1348,6 +1408,10 @@ int conv_ws_try(const moy_gemm_args* a, hipStream_t st) {
     const int C = a->Cin, N = a->N;
     const bool l1 = C == 32 && N == 64, l3 = C == 64 && N == 128;
     if (!s2 || !(l1 || l3) || a->K != 9 * C || a->R) return MOY_ENOSYS;
+    // a 1x1 consumer folded into the launch (post_*): the 64 -> 128 form only, N x N weights, SiLU
+    if (a->post_W && (!l3 || a->post_n != N || a->post_act != MOY_ACT_SILU || !aligned16(a->post_W) ||
+                      (a->post_scale && !aligned16(a->post_scale)) || (a->post_shift && !aligned16(a->post_shift))))
+      return MOY_ENOSYS;
     if (a->ln_g || a->out_f32 || a->c_rows_per_batch || a->pre || a->plane_cols || a->dot_n || !a->C) return MOY_ENOSYS;
     if ((a->lda % 8) || (a->ldc % 8) || !aligned16(a->A) || !aligned16(a->C) || !aligned16(a->W)) return MOY_ENOSYS;
     if ((a->scale && !aligned16(a->scale)) || (a->shift && !aligned16(a->shift))) return MOY_ENOSYS;
@@ -1359,10 +1423,14 @@ int conv_ws_try(const moy_gemm_args* a, hipStream_t st) {
     ConvS2Params q{};
     q.A = a->A; q.lda = a->lda; q.W = a->W; q.Kpad = (a->K + 63) / 64 * 64; q.scale = a->scale; q.shift = a->shift;
     q.C = a->C; q.ldc = a->ldc; q.Hin = a->Hin; q.Win = a->Win; q.Hout = a->Hout; q.Wout = a->Wout;
+    if (a->post_W) {
+      q.W2 = a->post_W; q.Kpad2 = (N + 63) / 64 * 64; q.scale2 = a->post_scale; q.shift2 = a->post_shift;
+      return a->dtype == MOY_BF16 ? launch_conv_s2<bf16_t, 64, 128, 4, 8, 2, true>(q, a->B, st) : launch_conv_s2<f16_t, 64, 128, 4, 8, 2, true>(q, a->B, st);
+    }
     if (a->dtype == MOY_BF16) return l1 ? launch_conv_s2<bf16_t, 32, 64, 8, 4, 3>(q, a->B, st) : launch_conv_s2<bf16_t, 64, 128, 4, 8, 2>(q, a->B, st);
     return l1 ? launch_conv_s2<f16_t, 32, 64, 8, 4, 3>(q, a->B, st) : launch_conv_s2<f16_t, 64, 128, 4, 8, 2>(q, a->B, st);
   }
-  if (a->stride != 1) return MOY_ENOSYS;
+  if (a->stride != 1 || a->post_W) return MOY_ENOSYS;
   const int C = a->Cin;
   if ((C != 32 && C != 64 && C != 128) || a->N != C || a->K != 9 * C) return MOY_ENOSYS;
   if (a->ln_g || a->out_f32 || a->c_rows_per_batch || a->pre || a->plane_cols || a->dot_n || !a->C) return MOY_ENOSYS;

@@ -1018,6 +1018,7 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
   // section 4): an LDS-DMA ring (global_load_lds, 1-2 blocks/CU), weights-resident-in-LDS with
   // activations straight to registers (16 rows x 64 B request shape), prefetch distance 2, a persistent
   // tile loop, a direct-from-register epilogue.  They are not kept in the tree.
+  if (a->post_W && (a->ksize != 3 || a->dtype == MOY_F32 || ln || a->post_n <= 0)) return MOY_ENOSYS;   // (never ignored)
   if (a->ksize == 1 && a->dtype != MOY_F32) {
     const int rc = gemm_wreg_try(a, st);
     if (rc != MOY_ENOSYS) return rc;
@@ -1027,6 +1028,7 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
     const int rc = conv_ws_try(a, st);
     if (rc != MOY_ENOSYS) return rc;
   }
+  if (a->post_W) return MOY_ENOSYS;          // the folded 1x1 consumer exists in the stride-2 weight-stationary kernel only: the caller launches it separately
   if (a->dtype != MOY_F32 && !ln) {          // deep K, N % 128 == 0, enough tiles: 256-row tiles through an LDS-DMA pipeline (gemm_dma.hip)
     const int rc = gemm_dma_try(a, st);
     if (rc != MOY_ENOSYS) return rc;

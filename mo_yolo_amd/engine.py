@@ -136,7 +136,7 @@ class TrackEngine:
 
     def _gemm(self, A: View, Wt, N, K, C_: View, M, *, ksize=1, stride=1, geom=None, scale=None, shift=None, act=0,
               A2: View | None = None, a_rows=None, a_mask=None, mask_period=0, R: View | None = None, ln=None,
-              out_f32=False, c_rpb=0, c_bstride=0, dot=None, pre=None, a2_cols=0, planes=None, runs=None, meta_scale=1.0):
+              out_f32=False, c_rpb=0, c_bstride=0, dot=None, pre=None, a2_cols=0, planes=None, runs=None, meta_scale=1.0, post=None):
         a = L.GemmArgs()
         a.A, a.lda = A.ptr, A.ld
         a.A2 = A2.ptr if A2 is not None else None
@@ -173,19 +173,27 @@ class TrackEngine:
             a.run_levels, a.run_period = 1, runs["period"]
             a.run_tok0[0], a.run_pitch[0], a.run_len[0], a.run_rows[0] = runs["tok0"], runs["pitch"], runs["len"], runs["rows"]
             a.run_a_period, a.run_a_off = runs["a_period"], runs["a_off"]
+        n_out = N
+        if post is not None:    # (W2, scale2, shift2, n2, act2): the conv's only consumer, a 1x1 conv, applied to the finished tiles on chip
+            a.post_W, a.post_scale, a.post_shift, a.post_n, a.post_act = post[0].data_ptr(), post[1].data_ptr(), post[2].data_ptr(), post[3], post[4]
+            n_out = post[3]
         self._keep.append(a)
         esz = 4 if self.dtype == torch.float32 else 2
         if geom is not None:
             a_elems = geom[0] * geom[1] * geom[2] * geom[5]      # every input pixel read once
         else:
             a_elems = M * K * (2 if A2 is not None else 1)
-        alg = (a_elems + N * K) * esz + (M * N * (4 if out_f32 else esz) if C_ is not None else 0) + (M * N * esz if R is not None else 0)
-        tag = f"gemm{ksize}x{ksize}" + ("s2" if stride == 2 else "") + ("+ln" if ln is not None else "")
-        self._add(self.lib.moy_gemm, C.byref(a), meta=dict(name=f"{tag} M{M} N{N} K{K}", bytes=int(alg * meta_scale),
-                                                            flops=int(2 * M * N * K * meta_scale)))
+        alg = (a_elems + N * K) * esz + (M * n_out * (4 if out_f32 else esz) if C_ is not None else 0) + (M * N * esz if R is not None else 0)
+        tag = f"gemm{ksize}x{ksize}" + ("s2" if stride == 2 else "") + ("+ln" if ln is not None else "") + ("+1x1" if post is not None else "")
+        fl = 2 * M * N * K + (2 * M * N * n_out if post is not None else 0)
+        if post is not None:
+            alg += N * n_out * esz
+        self._add(self.lib.moy_gemm, C.byref(a), meta=dict(name=f"{tag} M{M} N{N} K{K}", bytes=int(alg * meta_scale), flops=int(fl * meta_scale)))
 
     # conv + BN + SiLU on channels-last views
-    def _conv(self, p, x: View, hw_in, cin, cout, k, s, out: View, R: View | None = None, act=L.ACT_SILU, up_src=None):
+    def _conv(self, p, x: View, hw_in, cin, cout, k, s, out: View, R: View | None = None, act=L.ACT_SILU, up_src=None, post=None):
+        """post = prefix of a 1x1 Conv that is this 3x3 conv's only consumer: folded into the launch (`out` then takes ITS output);
+        returns False -- nothing planned -- when the library has no fused form for the shape (the launch is tried once, now)."""
         """up_src = (u view, (h, w), cu): the conv's input is Concat[Upsample2x(u), x] (u at half resolution, cu channels first)."""
         sd = self.sd
         w = sd[p + ".conv.weight"]
@@ -208,6 +216,20 @@ class TrackEngine:
             return hw_in
         Hout, Wout = (Hin + 2 - 3) // s + 1, (Win + 2 - 3) // s + 1
         Wt = self._weight(w.permute(0, 2, 3, 1).reshape(cout, 9 * cin))
+        if post is not None:
+            w2 = sd[post + ".conv.weight"]
+            n2 = w2.shape[0]
+            s2_, h2_ = self._bn(post + ".bn")
+            self._gemm(x, Wt, cout, 9 * cin, out, self.B * Hout * Wout, ksize=3, stride=s, geom=(self.B, Hin, Win, Hout, Wout, cin),
+                       scale=scale, shift=shift, act=act, post=(self._weight(w2.reshape(n2, cout)), s2_, h2_, n2, L.ACT_SILU))
+            fn, args = self._steps[-1]
+            rc = fn(*args, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            if rc == -38:                          # MOY_ENOSYS: no fused form for this shape / launch size
+                self._steps.pop()
+                self.meta.pop()
+                return False
+            L.check(rc, "moy_gemm (conv + folded 1x1 consumer)")
+            return (Hout, Wout)
         self._gemm(x, Wt, cout, 9 * cin, out, self.B * Hout * Wout, ksize=3, stride=s,
                    geom=(self.B, Hin, Win, Hout, Wout, cin), scale=scale, shift=shift, act=act, R=R)
         return (Hout, Wout)
@@ -297,6 +319,8 @@ class TrackEngine:
                 return (up.kind == "Upsample" and consumers.get(up.i, []) == [cat.i] and len(cons) == 1 and cons[0].kind == "C2f"
                         and os.environ.get("MOY_FUSE_UPSAMPLE", "1") != "0")
             self._layer_first_step: Dict[int, int] = {}
+            pending_post: Dict[int, tuple] = {}
+            self.post_fused_layers = set()
             for Ls in arch.layers:
                 p = f"model.{Ls.i}"
                 self._layer_first_step[Ls.i] = len(self._steps)
@@ -342,6 +366,10 @@ class TrackEngine:
                                             flops=2 * B * (H // 2) * (W // 2) * Ls.c2 * 27))
                     self._stem_step = len(self._steps) - 1       # its first argument is the input slot's pointer
                     outv[0] = o
+                elif Ls.kind == "Conv" and self._post_candidate(Ls, consumers, home):
+                    # its only consumer is the cv1 of the next C2f: planned there, as ONE launch when the library has the fused form
+                    pending_post[Ls.i] = (p, x, hin, Ls)
+                    outv[Ls.i] = None
                 elif Ls.kind == "Conv":
                     o = out_view(Ls.i, Ls.c2)
                     self._conv(p, x, hin, Ls.c1, Ls.c2, Ls.k, Ls.s, o)
@@ -375,7 +403,19 @@ class TrackEngine:
                     h_, w_ = hin
                     cat = View(self._buf(B * h_ * w_, (2 + Ls.n) * c))
                     tmp = View(self._buf(B * h_ * w_, c))
-                    if Ls.src[0] in virt_cat:
+                    fused_cv1 = False
+                    if Ls.src[0] in pending_post:
+                        pp, px, phin, PL = pending_post.pop(Ls.src[0])
+                        fused_cv1 = bool(self._conv(pp, px, phin, PL.c1, PL.c2, PL.k, PL.s, cat.slice(0, 2 * c), post=p + ".cv1"))
+                        if fused_cv1:
+                            self.post_fused_layers.add(PL.i)       # never materialised: its tiles only ever exist in LDS
+                        else:
+                            x = out_view(PL.i, PL.c2)
+                            self._conv(pp, px, phin, PL.c1, PL.c2, PL.k, PL.s, x)
+                            outv[PL.i] = x
+                    if fused_cv1:
+                        pass
+                    elif Ls.src[0] in virt_cat:
                         u, uhw, cu, xs, cx = virt_cat[Ls.src[0]]
                         self._conv(p + ".cv1", xs, hin, cx, 2 * c, 1, 1, cat.slice(0, 2 * c), up_src=(u, uhw, cu))
                     else:
@@ -417,7 +457,8 @@ class TrackEngine:
                 else:
                     raise ValueError(Ls.kind)
             self.layer_views, self.layer_hw = outv, hw
-            self.virtual_layers = set(virt_up) | set(virt_cat)     # never materialised (Upsample + Concat folded into the C2f)
+            assert not pending_post
+            self.virtual_layers = set(virt_up) | set(virt_cat) | self.post_fused_layers     # never materialised (Upsample + Concat folded into the C2f; a Conv folded with its 1x1 consumer)
 
             head_src = [(outv[j], hw[j]) for j in (15, 18, 21)]
         self._head_start = len(self._steps)
@@ -901,6 +942,20 @@ class TrackEngine:
         tid = a[lay["o_tid"]:lay["o_nr"]].view(np.int64).reshape(B, R)
         n_ids = a[lay["o_ni"]:lay["o_ni"] + 4 * B].view(np.int32)
         return rows, tid, n_rows, n_ids
+
+    def _post_candidate(self, Ls, consumers, home):
+        """Round 4: a down-sampling Conv (64 -> 128, 3x3, stride 2: yolo_track.yaml:19) whose ONLY consumer is the generic C2f that
+        follows (i.e. its cv1, block.py:225-235) and whose output lives in no concat buffer: planned as one launch with that cv1
+        (`moy_gemm_args.post_*`); MOY_POST_1X1=0 keeps the two launches."""
+        if self.dtype == torch.float32 or os.environ.get("MOY_POST_1X1", "1") == "0":
+            return False
+        if not (Ls.k == 3 and Ls.s == 2 and Ls.c1 == 64 and Ls.c2 == 128) or Ls.i in home:
+            return False
+        cons = consumers.get(Ls.i, [])
+        if len(cons) != 1 or cons[0] != Ls.i + 1:
+            return False
+        nxt = self.arch.layers[cons[0]]
+        return nxt.kind == "C2f" and nxt.c1 == 128 and nxt.c2 == 128 and list(nxt.src) in ([-1], [Ls.i])
 
     def _plan_fork(self):
         """Round 4, CU partition inside the plan -- MEASURED AND LEFT OFF (MOY_FORK_VALUE=<units> switches it on).

@@ -47,7 +47,7 @@ def pad_weight(w2d: torch.Tensor, dtype) -> torch.Tensor:
 
 def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shift=None, act=L.ACT_NONE, A2=None,
          a_rows=None, a_mask=None, mask_period=0, R=None, ln=None, out_f32=False, M=None, c_rpb=0, c_bstride=0,
-         dot=None, store=True, pre=None, a2_cols=0, planes=None, runs=None, dot_out=None):
+         dot=None, store=True, pre=None, a2_cols=0, planes=None, runs=None, dot_out=None, post=None):
     """See moy_gemm.  store=False (with dot): C = NULL, only the fused head's output is produced (returned as (None, dot_out)).
     A: 2-D row-major view [rows, >=Cin] (channels-last pixels or tokens)."""
     _need_gpu(A, Wp)
@@ -84,7 +84,7 @@ def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shi
     else:
         if out is None:
             rows = M if not c_rpb else (M // c_rpb) * c_bstride
-            out = torch.empty(rows, N, device=A.device, dtype=torch.float32 if out_f32 else A.dtype)
+            out = torch.empty(rows, N if post is None else post[0].shape[0], device=A.device, dtype=torch.float32 if out_f32 else A.dtype)
         a.C, a.ldc, a.out_f32, a.dtype = out.data_ptr(), _ld(out), int(out_f32), _code(A)
     a.c_rows_per_batch, a.c_batch_stride = c_rpb, c_bstride
     if pre is not None:     # (fp32 [B*(H/2)*(W/2), >=N], H, W): accumulator seed = nearest-2x upsampled half-resolution product
@@ -99,6 +99,11 @@ def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shi
         for i, (t0, pit, ln_, rw) in enumerate(runs["levels"]):
             a.run_tok0[i], a.run_pitch[i], a.run_len[i], a.run_rows[i] = t0, pit, ln_, rw
         a.run_a_period, a.run_a_off = runs.get("a_period", 0), runs.get("a_off", 0)
+    if post is not None:    # (W2 padded [n2, ceil64(N)], scale2, shift2, act2): a 1x1 conv on the finished tiles; `out` has n2 columns
+        pw_, ps_, ph_, pact = post
+        a.post_W, a.post_n, a.post_act = pw_.data_ptr(), pw_.shape[0], pact
+        a.post_scale = ps_.data_ptr() if ps_ is not None else None
+        a.post_shift = ph_.data_ptr() if ph_ is not None else None
     if dot is not None:     # (w fp32 [n, 256], b fp32 [n]) fused behind the LayerNorm
         dw, db = dot
         if dot_out is None:

@@ -384,6 +384,43 @@ def test_conv3x3_stride2_weight_stationary_kernel(dt, Cin, Cout, B, H, W):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,W", [(16, 60, 136), (3, 151, 271), (40, 152, 272)])
+def test_conv3x3_stride2_with_its_1x1_consumer_folded_in(dt, B, H, W):
+    """Round 4: Conv(64 -> 128, 3x3, stride 2) whose only consumer is the cv1 of the following C2f (yolo_track.yaml:19-20,
+    block.py:225-235): `moy_gemm_args.post_*` applies the 1x1 conv + BN + SiLU to every finished tile on chip, the conv's own
+    output never reaches HBM.  BIT-identical to the two launches (the intermediate is rounded where the first launch stored it; the
+    1x1 product sums k in the same 32-wide panels as the stand-alone kernels), odd sizes, output as a channel slice of a wider
+    buffer (the C2f's concat buffer); and against torch fp32.  A shape without the fused form answers MOY_ENOSYS, it is never
+    silently computed without the consumer."""
+    Cin, Cout = 64, 128
+    x = q(rnd(B, Cin, H, W, seed=1), dt)
+    w = q(rnd(Cout, Cin, 3, 3, seed=2, scale=1 / math.sqrt(9 * Cin)), dt)
+    w2 = q(rnd(Cout, Cout, seed=5, scale=1 / math.sqrt(Cout)), dt)
+    sc, sh = rnd(Cout, seed=3) * 0.2 + 1, rnd(Cout, seed=4, scale=0.1)
+    sc2, sh2 = rnd(Cout, seed=6) * 0.2 + 1, rnd(Cout, seed=7, scale=0.1)
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    xin = x.permute(0, 2, 3, 1).reshape(B * H * W, Cin).contiguous().to(DEV, dt)
+    wp = ops.pad_weight(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).to(DEV), dt)
+    w2p = ops.pad_weight(w2.to(DEV), dt)
+    kw = dict(ksize=3, stride=2, geom=(B, H, W, Ho, Wo, Cin), scale=sc.to(DEV), shift=sh.to(DEV), act=L.ACT_SILU)
+    mid = ops.gemm(xin, wp, Cout, 9 * Cin, **kw)
+    two = ops.gemm(mid, w2p, Cout, Cout, scale=sc2.to(DEV), shift=sh2.to(DEV), act=L.ACT_SILU)
+    cat = torch.full((B * Ho * Wo, 256), 3.0, device=DEV, dtype=dt)
+    ops.gemm(xin, wp, Cout, 9 * Cin, out=cat[:, :Cout], post=(w2p, sc2.to(DEV), sh2.to(DEV), L.ACT_SILU), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(cat[:, :Cout], two), f"{int((cat[:, :Cout] != two).sum())} of {two.numel()} values differ"
+    assert bool((cat[:, Cout:] == 3.0).all())
+    m = F.silu(F.conv2d(x, w, None, 2, 1) * sc[None, :, None, None] + sh[None, :, None, None])
+    ref = F.silu(F.conv2d(q(m, dt), w2[:, :, None, None]) * sc2[None, :, None, None] + sh2[None, :, None, None])
+    got = cat[:, :Cout].float().cpu().view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    assert torch.allclose(got, ref, atol=tol(dt, 2e-5, 4e-2), rtol=1e-2)
+    with pytest.raises(L.MoyoloError):        # a stride-1 conv has no fused consumer: refused, not ignored
+        ops.gemm(mid, ops.pad_weight(q(rnd(Cout, 9 * Cout, seed=8, scale=0.03), dt).to(DEV), dt), Cout, 9 * Cout, ksize=3, stride=1,
+                 geom=(B, Ho, Wo, Ho, Wo, Cout), scale=sc.to(DEV), shift=sh.to(DEV), act=L.ACT_SILU,
+                 post=(w2p, sc2.to(DEV), sh2.to(DEV), L.ACT_SILU))
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("Cin,Cout,s,B,H,W,res", [(128, 256, 2, 40, 76, 136, False), (256, 256, 2, 156, 38, 68, False),
                                                   (256, 256, 1, 156, 19, 34, True), (192, 256, 1, 10, 77, 135, True),
                                                   (512, 512, 1, 40, 38, 68, False)])
