@@ -998,20 +998,9 @@ class TrackEngine:
         if any((v.ld % 8) or (v.ptr % 16) for v, _ in head_src):
             return None
         d = f"model.{len(arch.layers)}.decoder"
-        v = valid_host.bool()
-        rect, off = [], 0
-        for (h_, w_) in self.shapes:
-            m = v[off:off + h_ * w_].view(h_, w_)
-            ys, xs = m.any(1).nonzero().flatten(), m.any(0).nonzero().flatten()
-            if len(ys) == 0:
-                return None
-            y0, y1, x0, x1 = int(ys[0]), int(ys[-1]), int(xs[0]), int(xs[-1])
-            full = torch.zeros_like(m)
-            full[y0:y1 + 1, x0:x1 + 1] = True
-            if not torch.equal(full, m):
-                return None
-            rect.append((y0, y1, x0, x1))
-            off += h_ * w_
+        rect = valid_rectangles(valid_host, self.shapes)
+        if rect is None or any(r_ is None for r_ in rect):
+            return None
         s_, t_, sWp = [], [], []
         for li in range(len(self.shapes)):
             p = f"{d}.input_proj.{li}.1"
@@ -1030,20 +1019,15 @@ class TrackEngine:
         if self.dtype == torch.float32 or os.environ.get("MOY_SCORE_RUNS", "1") == "0":
             return
         v = valid_host.bool()
+        rects = valid_rectangles(v, self.shapes)
+        if rects is None:
+            return                                       # not a rectangle per level: keep the masked pass
         tok0, pitch, rlen, rows = [], [], [], []
         off = 0
-        for (h_, w_) in self.shapes:
-            m = v[off:off + h_ * w_].view(h_, w_)
-            ys, xs = m.any(1).nonzero().flatten(), m.any(0).nonzero().flatten()
-            if len(ys) == 0:
-                off += h_ * w_
-                continue
-            y0, y1, x0, x1 = int(ys[0]), int(ys[-1]), int(xs[0]), int(xs[-1])
-            rect = torch.zeros_like(m)
-            rect[y0:y1 + 1, x0:x1 + 1] = True
-            if not torch.equal(rect, m):
-                return                                   # not a rectangle: keep the masked pass
-            tok0.append(off + y0 * w_ + x0); pitch.append(w_); rlen.append(x1 - x0 + 1); rows.append(y1 - y0 + 1)
+        for (h_, w_), rc_ in zip(self.shapes, rects):
+            if rc_ is not None:
+                y0, y1, x0, x1 = rc_
+                tok0.append(off + y0 * w_ + x0); pitch.append(w_); rlen.append(x1 - x0 + 1); rows.append(y1 - y0 + 1)
             off += h_ * w_
         if not tok0 or len(tok0) > 4 or sum(a * b for a, b in zip(rlen, rows)) != int(v.sum()):
             return
@@ -1296,6 +1280,28 @@ class StreamedEngines:
         """Per-frame outputs of the whole batch, concatenated over the sub-batches (after `synchronize()`)."""
         outs = [e.outputs() for e in self.engines]
         return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+
+
+def valid_rectangles(valid, shapes):
+    """The valid-token mask of `_generate_anchors` (head.py:1007), level by level, as rectangles (y0, y1, x0, x1) inclusive -- or None
+    for a level without valid tokens; the whole result is None when some level's mask is NOT one rectangle (the callers then keep
+    the masked pass over all tokens).  valid: bool / uint8 [S] in level-major order, shapes: [(h, w), ...]."""
+    v = torch.as_tensor(valid).bool().flatten()
+    out, off = [], 0
+    for (h_, w_) in shapes:
+        m = v[off:off + h_ * w_].view(h_, w_)
+        off += h_ * w_
+        ys, xs = m.any(1).nonzero().flatten(), m.any(0).nonzero().flatten()
+        if len(ys) == 0:
+            out.append(None)
+            continue
+        y0, y1, x0, x1 = int(ys[0]), int(ys[-1]), int(xs[0]), int(xs[-1])
+        rect = torch.zeros_like(m)
+        rect[y0:y1 + 1, x0:x1 + 1] = True
+        if not torch.equal(rect, m):
+            return None
+        out.append((y0, y1, x0, x1))
+    return out
 
 
 def _generate_anchors(shapes, grid_size=0.05, eps=1e-2):

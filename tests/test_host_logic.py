@@ -220,3 +220,39 @@ def test_product_hota_standard_definition_properties():
     assert np.allclose(comb["HOTA_TP"], 2 * T * n) and np.allclose(comb["AssA"], (1 + 2 / 3) / 2)
     empty = h.eval_sequence(build_hota_data(gt, [np.zeros(0, np.int64)] * T, [np.zeros((n, 0))] * T))
     assert np.allclose(empty["HOTA_FN"], T * n) and empty["HOTA(0)"] == 0
+
+
+def test_valid_token_rectangles_of_the_reference_anchor_mask():
+    """Round 3 / 4 host logic behind the score pass over the valid tokens and the folded head: the valid mask of
+    `_generate_anchors` (head.py:993-1010, axes swapped as shipped) is ONE rectangle per pyramid level at every resolution the
+    configs use -- checked against the oracle's restatement of the reference formula -- and anything else is refused."""
+    from mo_yolo_amd.engine import _generate_anchors, valid_rectangles
+    from oracle.track_oracle import generate_anchors
+    for H, W in ((608, 1088), (1088, 1920), (128, 192), (640, 640)):
+        shapes = [(H // s, W // s) for s in (8, 16, 32)]
+        _, v_ref = generate_anchors(shapes)
+        _, v = _generate_anchors(shapes)
+        assert torch.equal(v.bool(), v_ref.bool())
+        rects = valid_rectangles(v[0, :, 0], shapes)
+        assert rects is not None and len(rects) == 3
+        off, n = 0, 0
+        for (h, w), r in zip(shapes, rects):
+            m = v[0, off:off + h * w, 0].bool().view(h, w)
+            off += h * w
+            if r is None:
+                assert not bool(m.any())
+                continue
+            y0, y1, x0, x1 = r
+            assert bool(m[y0:y1 + 1, x0:x1 + 1].all())
+            n += (y1 - y0 + 1) * (x1 - x0 + 1)
+        assert n == int(v.sum())
+    # the swapped axes cut the 1088-wide levels at x / h < 0.99: 54 % of the tokens are valid at 608 x 1088 (SURVEY 0.6)
+    shapes = [(76, 136), (38, 68), (19, 34)]
+    _, v = _generate_anchors(shapes)
+    assert int(v.sum()) == 7317 and valid_rectangles(v[0, :, 0], shapes) == [(1, 75, 1, 74), (1, 37, 0, 37), (0, 18, 0, 18)]
+    holed = v[0, :, 0].clone().bool()
+    holed[5 * 136 + 7] = False                                   # (row 5, column 7 of the P3 level)
+    assert bool(v[0, 5 * 136 + 7, 0])                                   # a hole: not a rectangle any more
+    assert valid_rectangles(holed, shapes) is None
+    assert valid_rectangles(torch.zeros(13566, dtype=torch.bool), shapes) == [None, None, None]
+
