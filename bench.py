@@ -509,6 +509,20 @@ def main(argv=None):
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_ms": round(per[dom], 4), "share_of_step": round(per[dom] / sum(per), 4),
                     "alg_bytes_per_launch": m["bytes"], "tflops": round(m["flops"] / (per[dom] * 1e-3) / 1e12, 2)}
+            # Round 4: the value projection (1.6-1.9 ms, HBM-bound) and the fused stem (1.62-1.67 ms, bound by vector-instruction issue:
+            # SiLU + the uint8 fragment build, 15 % matrix-pipe busy -- profiles/r04_b_pmc_all_kernels_b288_1stream.txt) are within a few per
+            # cent of each other, so which one is "dominant" differs by device: the runner-up is always reported beside it
+            order = sorted(range(nL), key=lambda i: -per[i])
+            if len(order) > 1:
+                m2 = eng.meta[order[1]]
+                ach2 = m2["bytes"] / (per[order[1]] * 1e-3) / 1e9 if m2["bytes"] else 0.0
+                tr2 = prof.get("launches", prof).get(m2["name"], {}).get("hbm_bytes") if dtype_name == "bf16" else None
+                roof["runner_up"] = {"kernel": m2["name"], "launch_index": order[1], "avg_ms": round(per[order[1]], 4), "achieved": round(ach2, 1),
+                                     "frac": round(ach2 / HBM_PEAK_GBS, 4), "traffic": tr2, "alg_bytes_per_launch": m2["bytes"],
+                                     "tflops": round(m2["flops"] / (per[order[1]] * 1e-3) / 1e12, 2)}
+            if m["name"].startswith("stem"):
+                roof["note"] = ("fused preprocess + stem + conv1: bound by vector-instruction issue (SiLU at 28 cycles per value, uint8 fragment build), "
+                                "neither the HBM nor the matrix roof is near; the HBM-bound value projection is `runner_up`")
             if dtype_name == "f32":
                 # the exact-fp32 engine multiplies on v_mfma_f32_16x16x4_f32: 1/16 of the bf16 matrix rate, the same as the fp32
                 # vector rate (MI355X_MICROARCH.md: 157.3 TFLOP/s spec, 155 measured) -- its dominant launch is bound by THAT

@@ -43,6 +43,10 @@ if os.path.exists(f"{src}/traffic_step.json") and os.path.exists(f"{src}/traffic
             key = "gemm1x1 M2976768 N1536 K128"
         elif "gemm_wreg_kernel" in r["kernel"] and "32, 3, 1, false, 8, 64, 256" in r["kernel"] and r["grid"] == "122880" and r["dispatches"] == 5:
             key = "gemm1x1 M3907008 N1536 K256"
+        if "stem_l1_kernel" in r["kernel"] and r["dispatches"] == 5:      # within 3 % of the value launch in time: whichever is longer on a device is `roofline`
+            key = "stem+conv1 fused M11907072 N64"
+        elif "c2f_fused_kernel" in r["kernel"] and r["dispatches"] == 5:
+            key = "c2f fused M11907072 64->[32|32]->64"
         if key:
             doc["launches"][key] = dict(
                 hbm_bytes=r["hbm_bytes"], source=f"profiles/{tag}_b288_hbm_traffic_pmc.json ({r['kernel'][:70]}, grid {r['grid']}, "
