@@ -145,6 +145,9 @@ def lib():
     return _lib
 
 
+EINVAL, ENOSYS = -22, -38          # MOY_EINVAL / MOY_ENOSYS of include/moyolo.h
+
+
 def check(rc: int, what: str = ""):
     if rc != 0:
         msg = lib().moy_strerror(rc).decode()

@@ -224,7 +224,7 @@ class TrackEngine:
                        scale=scale, shift=shift, act=act, post=(self._weight(w2.reshape(n2, cout)), s2_, h2_, n2, L.ACT_SILU))
             fn, args = self._steps[-1]
             rc = fn(*args, C.c_void_p(torch.cuda.current_stream().cuda_stream))
-            if rc == -38:                          # MOY_ENOSYS: no fused form for this shape / launch size
+            if rc == L.ENOSYS:                     # no fused form for this shape / launch size
                 self._steps.pop()
                 self.meta.pop()
                 return False

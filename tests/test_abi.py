@@ -61,6 +61,20 @@ def test_version_and_errors_no_gpu_needed():
     assert lib.moy_sigmoid_f32(None, 0, None, None) == -22
 
 
+def test_host_side_contracts_of_the_round4_entries_no_gpu_needed():
+    """moy_set_cu_limit is host state (per thread, returns the previous budget); a folded 1x1 consumer (`post_*`) on a launch that
+    has no fused form is refused with MOY_ENOSYS on the host -- never computed without the consumer."""
+    import ctypes as C
+    lib = _lib.lib()
+    assert lib.moy_set_cu_limit(128) == 0 and lib.moy_set_cu_limit(0) == 128 and lib.moy_set_cu_limit(-5) == 0 and lib.moy_set_cu_limit(0) == 0
+    a = _lib.GemmArgs()
+    fake = 0x10000                       # aligned, never dereferenced: the refusal comes before any launch
+    a.A, a.lda, a.W, a.C, a.ldc = fake, 128, fake, fake, 128
+    a.M, a.N, a.K, a.ksize, a.stride, a.dtype = 1 << 17, 128, 128, 1, 1, _lib.BF16
+    a.post_W, a.post_n, a.post_act = fake, 128, 1
+    assert lib.moy_gemm(C.byref(a), None) == _lib.ENOSYS
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
