@@ -50,6 +50,13 @@ struct ConvWsParams {
   int per_xcd, bpx;                 // tiles per XCD chunk, blocks per XCD
   FastDiv fd_timg, fd_tx;
   int prio;                         // ping-pong form: raise the wave priority during its MFMA halves (MOY_CWS_PRIO, default 1)
+  // GRP forms (round 4): G images side by side on one VIRTUAL row, one zero column between neighbours (= each image's padding), so
+  // that 16-column tiles are cut from G * (Wd + 1) - 1 columns instead of from Wd: 68 columns are 5 tiles alone (85 % of a tile
+  // row used) and 13 tiles per three images (95 %).  A tile batch index is then a GROUP; virtual column xv -> image g = xv / (Wd + 1)
+  // of the group, column xv - g * (Wd + 1) (== Wd: the zero column); the descriptor of a group spans its images.
+  int Wv, G, nimg;
+  FastDiv fd_w1;
+  int delta_a, delta_r, delta_c;    // bytes from virtual column xv of image 0 to the same pixel of image g, per g: image bytes - (Wd + 1) pixels
 };
 
 template <int C>
@@ -97,7 +104,7 @@ struct CwsGeom {
   static constexpr int NPASS = TPX * NCP / 512;             // 16-byte stores per thread and tile
 };
 
-template <typename T, int C, int N, int TH, int WN, int NBUF, bool RES, int OCC, bool SPREAD, int ABL = 0>   // ABL: timing-only ablation builds (tools/bench_gemm.py)
+template <typename T, int C, int N, int TH, int WN, int NBUF, bool RES, int OCC, bool SPREAD, int ABL = 0, bool GRP = false>   // ABL: timing-only ablation builds (tools/bench_gemm.py)
 __global__ __launch_bounds__(512, 2 * OCC) void conv_ws_kernel(const ConvWsParams p) {
   using G = CwsGeom<C, N, TH, NBUF, RES>;
   constexpr int PW = G::PW, CPP = G::CPP, NCP = G::NCP, IPW = G::IPW, NPASS = G::NPASS;
@@ -165,6 +172,18 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_ws_kernel(const ConvWsParam
     x0 = (rem - ty * p.tiles_x) * 16;
   };
 
+  // virtual column -> (valid, byte correction) of a pixel of the group (GRP) or plain range test
+  auto col_ok = [&](int xx, int delta, int& corr) {
+    corr = 0;
+    if constexpr (GRP) {
+      if ((unsigned)xx >= (unsigned)p.Wv) return false;
+      const int g = (int)fdiv((uint32_t)xx, p.fd_w1);
+      corr = g * delta;
+      return xx - g * (p.Wd + 1) < p.Wd;
+    } else {
+      return (unsigned)xx < (unsigned)p.Wd;
+    }
+  };
   // DMA of one tile = scalar set-up (descriptors, tile origin) + IPW independent pieces, so the pieces can be issued all at
   // once (prologue) or one by one between the MFMA groups of the tile being computed (SPREAD).
   struct TileDma {
@@ -178,9 +197,11 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_ws_kernel(const ConvWsParam
     d.live = it < n_mine;                                       // tiles past the end: every lane out of range (uniform counts)
     int b;
     tile_coords(min(t_first + it * p.bpx, p.ntiles - 1), b, d.y0, d.x0);
-    d.rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Ag + (int64_t)b * img_a), 0, (uint32_t)(img_a * 2), 0x00020000);
-    d.rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>((RES ? Rg : Ag) + (int64_t)b * (RES ? img_r : img_a)), 0,
-                                              (uint32_t)((RES ? img_r : img_a) * 2), 0x00020000);
+    // (GRP: b is a group; its descriptor spans the group's images -- the last group may hold fewer, what lies past them reads as zero)
+    const int b0 = GRP ? b * p.G : b, nim = GRP ? min(p.G, p.nimg - b0) : 1;
+    d.rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Ag + (int64_t)b0 * img_a), 0, (uint32_t)(img_a * 2 * nim), 0x00020000);
+    d.rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>((RES ? Rg : Ag) + (int64_t)b0 * (RES ? img_r : img_a)), 0,
+                                              (uint32_t)((RES ? img_r : img_a) * 2 * nim), 0x00020000);
     const int org = d.y0 * p.Wd + d.x0;
     d.off_a = org * (int)p.lda * 2;
     d.off_r = org * (int)p.ldr * 2;
@@ -193,8 +214,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_ws_kernel(const ConvWsParam
     int dy, dx, rel;
     piece_geom(pc, dy, dx, rel);
     const int yy = d.y0 + dy, xx = d.x0 + dx;
-    const bool ok = d.live && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.Wd;
-    const uint32_t voff = ok ? (uint32_t)((is_res ? d.off_r : d.off_a) + rel) : OOB;
+    int corr;
+    const bool cok = col_ok(xx, is_res ? p.delta_r : p.delta_a, corr);
+    const bool ok = d.live && (unsigned)yy < (unsigned)p.H && cok;
+    const uint32_t voff = ok ? (uint32_t)((is_res ? d.off_r : d.off_a) + rel + corr) : OOB;
     const uint32_t dst = pc < G::PIECES ? d.dst + pc * 1024 : scratch;
     if (ABL == 2) return;
     if (is_res) cws_dma16(voff, d.rsR, dst);
@@ -218,8 +241,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_ws_kernel(const ConvWsParam
       int dy, dx, rel;
       piece_geom(pc, dy, dx, rel);
       const int yy = d.y0 + dy, xx = d.x0 + dx;
-      const bool ok = d.live && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.Wd;
-      vo[k] = ok ? (uint32_t)((is_res ? d.off_r : d.off_a) + rel) : OOB;
+      int corr;
+      const bool cok = col_ok(xx, is_res ? p.delta_r : p.delta_a, corr);
+      const bool ok = d.live && (unsigned)yy < (unsigned)p.H && cok;
+      vo[k] = ok ? (uint32_t)((is_res ? d.off_r : d.off_a) + rel + corr) : OOB;
       asm volatile("" : "+v"(vo[k]));      // materialised HERE (the scheduler would otherwise sink the arithmetic to its use at the loop top)
     }
   };
@@ -382,9 +407,11 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_ws_kernel(const ConvWsParam
     {
       int b, y0, x0;
       tile_coords(t_first + it * p.bpx, b, y0, x0);
-      const auto rsC = __builtin_amdgcn_make_buffer_rsrc(Cg + (int64_t)b * img_c, 0, (uint32_t)(img_c * 2), 0x00020000);
-      const int off_c = (y0 * p.Wd + x0) * (int)p.ldc * 2 + s_rel;
-      const bool xok = x0 + s_tx < p.Wd;
+      const int b0 = GRP ? b * p.G : b, nim = GRP ? min(p.G, p.nimg - b0) : 1;
+      const auto rsC = __builtin_amdgcn_make_buffer_rsrc(Cg + (int64_t)b0 * img_c, 0, (uint32_t)(img_c * 2 * nim), 0x00020000);
+      int corr_c;
+      const bool xok = col_ok(x0 + s_tx, p.delta_c, corr_c);
+      const int off_c = (y0 * p.Wd + x0) * (int)p.ldc * 2 + s_rel + corr_c;
       u32x4 vv[NPASS];
 #pragma unroll
       for (int k = 0; k < NPASS; ++k) vv[k] = *reinterpret_cast<const u32x4*>(stg + s_lds + k * PASS_LDS);
@@ -1314,11 +1341,39 @@ static int launch_conv_s2(ConvS2Params& p, int B, hipStream_t st) {
   return launch_status();
 }
 
-template <typename T, int C, int N, int TH, int WN, int NBUF, bool RES, int OCC = 1, bool SPREAD = false, int ABL = 0>
+// Images per virtual row (GRP forms): the smallest group that saves at least 4 % of the tile columns, 1 = plain tiling.  The group's
+// descriptors must stay inside 31 bits.
+static int cws_group(int W, int64_t img_bytes_max) {
+  static int on = -1;                      // MOY_CWS_GROUP=0: plain tiling (A/B runs, bit-identity test)
+  if (on < 0) { const char* e = getenv("MOY_CWS_GROUP"); on = e ? atoi(e) : 1; }
+  if (!on) return 1;
+  const double base = (double)((W + 15) / 16);
+  int best = 1;
+  double best_t = base;
+  for (int g = 2; g <= 8; ++g) {
+    if (img_bytes_max * g > 0x3fffffffLL) break;
+    const double t = (double)((g * (W + 1) - 1 + 15) / 16) / g;
+    if (t < best_t * 0.98 && t <= base * 0.96) { best = g; best_t = t; }
+  }
+  return best;
+}
+
+template <typename T, int C, int N, int TH, int WN, int NBUF, bool RES, int OCC = 1, bool SPREAD = false, int ABL = 0, bool GRP = false>
 static int launch_conv_ws(ConvWsParams& p, int B, hipStream_t st) {
   using G = CwsGeom<C, N, TH, NBUF, RES>;
   static_assert(G::LDS * OCC <= 160 * 1024, "LDS budget");
-  if constexpr (ABL == 0 && std::is_same<T, bf16_t>::value && !RES) {
+  if constexpr (ABL == 0 && !GRP && C == 128 && !SPREAD && OCC == 1) {
+    const int64_t ldmax = p.lda > p.ldc ? (p.lda > p.ldr ? p.lda : p.ldr) : (p.ldc > p.ldr ? p.ldc : p.ldr);
+    const int g = cws_group(p.Wd, (int64_t)p.H * p.Wd * ldmax * 2);
+    if (g > 1 && B >= g) {
+      p.G = g; p.nimg = B; p.Wv = g * (p.Wd + 1) - 1;
+      p.fd_w1 = make_fastdiv((uint32_t)(p.Wd + 1));
+      const int px = p.H * p.Wd - (p.Wd + 1);
+      p.delta_a = px * (int)p.lda * 2; p.delta_r = px * (int)p.ldr * 2; p.delta_c = px * (int)p.ldc * 2;
+      return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 0, true>(p, B, st);
+    }
+  }
+  if constexpr (ABL == 0 && !GRP && std::is_same<T, bf16_t>::value && !RES) {
     static int abl = -1;                   // MOY_CWS_ABL=1..4: timing-only builds (no SiLU / no DMA / one MFMA group / no stores)
     if (abl < 0) abl = garbage_mode_env("MOY_CWS_ABL");
     if (abl == 1) return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 1>(p, B, st);
@@ -1327,7 +1382,7 @@ static int launch_conv_ws(ConvWsParams& p, int B, hipStream_t st) {
     if (abl == 4) return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 4>(p, B, st);
     if (abl == 5) return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 5>(p, B, st);
   }
-  auto kern = conv_ws_kernel<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, ABL>;
+  auto kern = conv_ws_kernel<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, ABL, GRP>;
   {
     static int prio = -1;
     if (prio < 0) { const char* e = getenv("MOY_CWS_PRIO"); prio = e ? atoi(e) : 1; }
@@ -1339,10 +1394,10 @@ static int launch_conv_ws(ConvWsParams& p, int B, hipStream_t st) {
       return MOY_ELAUNCH;
     attr_set = true;
   }
-  p.tiles_x = (p.Wd + 15) / 16;
+  p.tiles_x = ((GRP ? p.Wv : p.Wd) + 15) / 16;
   const int tiles_y = (p.H + TH - 1) / TH;
   p.tiles_img = p.tiles_x * tiles_y;
-  p.ntiles = B * p.tiles_img;
+  p.ntiles = (GRP ? (B + p.G - 1) / p.G : B) * p.tiles_img;
   p.fd_timg = make_fastdiv((uint32_t)p.tiles_img);
   p.fd_tx = make_fastdiv((uint32_t)p.tiles_x);
   p.per_xcd = (p.ntiles + 7) / 8;

@@ -523,6 +523,40 @@ def test_gemm_dma_other_forms_in_a_child_process(form):
     assert len(lines) >= 3 and all(" mismatches 0 of" in ln for ln in lines), r.stdout[-2000:]
 
 
+@pytest.mark.parametrize("dtn", ["bf16", "f16"])
+def test_conv3x3_grouped_virtual_row_tiling_bit_identical_to_plain_tiling(dtn, tmp_path):
+    """Round 4: at C = 128 the weight-stationary 3x3 kernel cuts its 16-column tiles from a VIRTUAL row of G images with one zero
+    column between neighbours (68 columns: 5 tiles alone, 13 per three images).  Same arithmetic per pixel, so the outputs must
+    equal the plain tiling's (a child process with MOY_CWS_GROUP=0: the switch is read once per process) bit for bit -- batch sizes
+    that are not a multiple of the group, odd sizes, the shortcut form, channel-slice operands (the probe checks that nothing
+    outside the output slice is written) -- and agree with torch fp32."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools", "probes"))
+    import conv_group_check as P
+    dt = torch.bfloat16 if dtn == "bf16" else torch.float16
+    grouped = P.run(dt)
+    out = str(tmp_path / "plain.pt")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "conv_group_check.py"), out, dtn],
+                       env=dict(os.environ, MOY_CWS_GROUP="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    plain = torch.load(out)
+    assert len(plain) == len(grouped) == len(P.SHAPES)
+    for a, b in zip(grouped, plain):
+        assert a["shape"] == b["shape"] and torch.equal(a["x"], b["x"])
+        assert torch.equal(a["y"], b["y"]), (a["shape"], int((a["y"] != b["y"]).sum()))
+        B, H, W, res = a["shape"]
+        x = a["x"].float().view(B, H, W, 128).permute(0, 3, 1, 2)
+        w = a["w"].float().view(128, 3, 3, 128).permute(0, 3, 1, 2)
+        ref = F.silu(F.conv2d(x, w, None, 1, 1) * a["sc"][None, :, None, None] + a["sh"][None, :, None, None])
+        if res:
+            ref = ref + a["r"].float().view(B, H, W, 128).permute(0, 3, 1, 2)
+        got = a["y"].float().view(B, H, W, 128).permute(0, 3, 1, 2)
+        assert torch.allclose(got, ref, atol=tol(dt, 2e-5, 4e-2), rtol=1e-5), float((got - ref).abs().max())
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,H,W", [(2, 64, 96), (3, 100, 132), (1, 608, 1088)])
 def test_stem_and_first_downsample_fused(dt, B, H, W):
