@@ -234,7 +234,15 @@ def test_engine_folded_input_proj_plan_vs_classic_plan(dt, monkeypatch):
     vc, vf = classic.value_planes.float(), folded.value_planes.float()
     sc, sf_ = classic.scores_all, folded.scores_all
     eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
-    assert float((vc - vf).abs().max()) <= 16 * eps * float(vc.abs().max()), (float((vc - vf).abs().max()), float(vc.abs().max()))
+    dv = (vc - vf).abs()
+    if float(dv.max()) > 16 * eps * float(vc.abs().max()):
+        # (seen ONCE in ~15 executions on one device of the pool, never reproduced: say WHERE, so that a recurrence names its kernel)
+        bad = (dv.view(-1, B, S, 32) > 16 * eps * float(vc.abs().max())).nonzero()
+        where = dict(outliers=len(bad), planes=sorted(set(bad[:, 0].tolist()))[:16], frames=sorted(set(bad[:, 1].tolist()))[:16],
+                     tokens=(int(bad[:, 2].min()), int(bad[:, 2].max())), level_starts=(0, 76 * 136, 76 * 136 + 38 * 68),
+                     backbone_layers_that_differ=[i for i, v in classic.layer_views.items() if v is not None and i not in classic.virtual_layers
+                                                  and not torch.equal(v.tensor(), folded.layer_views[i].tensor())])
+        raise AssertionError(f"value planes of the two plans differ by {float(dv.max()):.4f} (max |v| {float(vc.abs().max()):.3f}): {where}")
     assert float((sc - sf_).abs().max()) <= 16 * eps * max(1.0, float(sc.abs().max())), float((sc - sf_).abs().max())
     # the selected tokens' projected features: fp32 product rounded once, against the classic plan's feature map rows
     tk = of["topk_ind"].long()
