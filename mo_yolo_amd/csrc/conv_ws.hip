@@ -78,6 +78,21 @@ __device__ __forceinline__ void cws_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// End-of-tile wait of the patch ring (see wait_ring_tile in gemm_wreg.hip): behind the pieces of tile it+1 lie DIST-1 younger piece
+// groups and one group of NPASS stores per tile ALREADY COMPUTED -- min(DIST, it+1) of them.  Round 5: the steady-state count used
+// from the first tile on left the NPASS youngest pieces of tile 1 unwaited.
+template <int DIST, int IPW, int NPASS>
+__device__ __forceinline__ void cws_wait_ring_tile(int it) {   // `it` wave-uniform
+  if constexpr (DIST >= 2) {
+    if (it == 0) { cws_wait_vmcnt<(DIST - 1) * IPW + NPASS>(); return; }
+  }
+  if constexpr (DIST >= 3) {
+    if (it == 1) { cws_wait_vmcnt<(DIST - 1) * IPW + 2 * NPASS>(); return; }
+  }
+  static_assert(DIST <= 3, "ring depth");
+  cws_wait_vmcnt<(DIST - 1) * IPW + DIST * NPASS>();
+}
+
 template <typename T>
 __device__ __forceinline__ f32x4 cws_mfma(f32x4 acc, u32x4 w, u32x4 a);
 template <>
@@ -423,7 +438,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_ws_kernel(const ConvWsParam
     }
     // tile it+1 must have landed; the younger DMA pieces and the stores issued since stay in flight
     stamp(4);                              // store pass
-    cws_wait_vmcnt<(DIST - 1) * (IPW + NPASS) + NPASS>();
+    cws_wait_ring_tile<DIST, IPW, NPASS>(it);
     stamp(5);                              // wait for the next tile's pieces
     __syncthreads();
     stamp(6);                              // barrier
@@ -1309,7 +1324,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvS2Params p) {
         __builtin_amdgcn_raw_buffer_store_b128(vv[k], rsC, ok ? (uint32_t)(off_c + k * s_pass_rel) : OOB, 0, 0);
       }
     }
-    cws_wait_vmcnt<(DIST - 1) * (IPW + NPASS) + NPASS>();
+    cws_wait_ring_tile<DIST, IPW, NPASS>(it);
     __syncthreads();
     if (++set == NBUF) set = 0;
   }
@@ -1437,9 +1452,8 @@ static int conv_ws_dispatch(ConvWsParams& p, int B, int C, bool res, hipStream_t
     return res ? launch_conv_ws<T, 32, 32, 16, 2, 3, true>(p, B, st) : launch_conv_ws<T, 32, 32, 16, 2, 3, false>(p, B, st);
   }
   if (C == 64) {
-    static int wn64 = -1;                  // MOY_CWS_WN64=2: two column groups of 32 channels (NT = 2, 4 rows per wave) instead of four of 16
-    if (wn64 < 0) { const char* e = getenv("MOY_CWS_WN64"); wn64 = e ? atoi(e) : 4; }
-    if (wn64 == 2) return res ? launch_conv_ws<T, 64, 64, 16, 2, 2, true>(p, B, st) : launch_conv_ws<T, 64, 64, 16, 2, 3, false>(p, B, st);
+    // (round 5: the two-column-group form MOY_CWS_WN64=2 -- measured slower, DESIGN.md round 4 item 4 -- spilled 15-90 registers: scratch
+    //  traffic is vector-memory traffic the counted waits of the patch ring do not know about; it left the tree)
     if (sp) return res ? launch_conv_ws<T, 64, 64, 16, 4, 2, true, 1, true>(p, B, st) : launch_conv_ws<T, 64, 64, 16, 4, 3, false, 1, true>(p, B, st);
     return res ? launch_conv_ws<T, 64, 64, 16, 4, 2, true>(p, B, st) : launch_conv_ws<T, 64, 64, 16, 4, 3, false>(p, B, st);
   }

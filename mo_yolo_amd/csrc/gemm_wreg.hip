@@ -102,6 +102,27 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// End-of-tile wait of a DMA ring whose tiles also issue NST stores each: tile it+1 must have landed.  The wave's queue, oldest
+// first, is DMA(it+1), stores(it-DIST+1), DMA(it+2), ..., DMA(it+DIST), stores(it): behind the piece that is needed lie DIST-1
+// younger DMA groups and one store group per tile ALREADY COMPUTED, i.e. min(DIST, it+1) of them -- not DIST.  Round 5: until
+// then the steady-state count (DIST-1)*(IPW+NST)+NST was used from the first tile on; with NST >= IPW it exceeds what is
+// outstanding at the end of tile 0 (2 IPW + NST at DIST = 2), so the wait was empty and tile 1 was read on the strength of
+// having been requested one tile earlier (the one-off wrong value planes of round 4: DESIGN.md section 4, round 5 item 1).
+template <int DIST, int IPW, int NST>
+__device__ __forceinline__ void wait_ring_tile(int it) {   // `it` wave-uniform
+  if constexpr (DIST >= 2 && NST > 0) {
+    if (it == 0) { wait_vmcnt<(DIST - 1) * IPW + NST>(); return; }
+  }
+  if constexpr (DIST >= 3 && NST > 0) {
+    if (it == 1) { wait_vmcnt<(DIST - 1) * IPW + 2 * NST>(); return; }
+  }
+  if constexpr (DIST >= 4 && NST > 0) {
+    if (it == 2) { wait_vmcnt<(DIST - 1) * IPW + 3 * NST>(); return; }
+  }
+  static_assert(DIST <= 4, "ring depth");
+  wait_vmcnt<(DIST - 1) * IPW + DIST * NST>();
+}
+
 template <typename T>
 __device__ __forceinline__ f32x4 mfma16(f32x4 acc, u32x4 w, u32x4 a);
 template <>
@@ -559,7 +580,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && OCC == 2) ? 4 : OCC) void gemm
 #pragma unroll
       for (int k = 0; k < 4; ++k) seed[k] = seed_next[k];
     } else if constexpr (ABL & 4) wait_vmcnt<NST>();
-    else wait_vmcnt<(DIST - 1) * (IPW + NST) + NST>();
+    else wait_ring_tile<DIST, IPW, NST>(it);
     stamp(3);
     __syncthreads();
     stamp(4);
@@ -751,11 +772,8 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
     static int v128 = -1;
     if (v128 < 0) { const char* e = getenv("MOY_WREG_V128"); v128 = e ? atoi(e) : 0; }
     switch (v128) {
-      case 1: return launch_wreg<bf16_t, 32, 3, 2, false, 8, 64, 128>(p, st);     // two blocks per CU
-      case 2: return launch_wreg<bf16_t, 32, 4, 2, false, 8, 64, 128>(p, st);     // ... and a deeper ring
       case 3: return launch_wreg<bf16_t, 32, 5, 1, false, 8, 64, 128>(p, st);     // one block, ring of 5
       case 4: return launch_wreg<bf16_t, 64, 3, 1, false, 8, 64, 128>(p, st);     // 64-row tiles
-      case 5: return launch_wreg<bf16_t, 64, 3, 2, false, 8, 64, 128>(p, st);     // 64-row tiles, two blocks per CU
       case 6: return launch_wreg<bf16_t, 64, 2, 1, false, 8, 64, 128>(p, st);     // 64-row tiles, ring of 2
       case 7: return launch_wreg<bf16_t, 64, 4, 1, false, 8, 64, 128>(p, st);     // 64-row tiles, ring of 4
       case 9: return launch_wreg<bf16_t, 32, 3, 1, false, 8, 64, 128>(p, st);     // 32-row tiles (the form before the measurement)
@@ -770,9 +788,8 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
     switch (v256) {
       case 1: return launch_wreg<bf16_t, 64, 3, 1, false, 8, 32, 256>(p, st);     // 32 columns per wave (one plane), 64-row tiles
       case 2: return launch_wreg<bf16_t, 32, 3, 1, false, 8, 32, 256>(p, st);     // 32 columns per wave, 32-row tiles
-      // measured (P4 level, 288 frames): 0.86-0.89 ms against 0.62 -- 256 VGPRs with 14-15 spilled: the 64-row tile that pays at K = 128 does not fit here
-      case 3: if (!a->scale) return launch_wreg<bf16_t, 64, 3, 1, false, 8, 64, 256>(p, st); break;   // 64-row tiles, lean epilogue registers
-      case 4: if (!a->scale) return launch_wreg<bf16_t, 64, 2, 1, false, 8, 64, 256>(p, st); break;   // ... ring of 2
+      // (round 5: the forms that spilled -- two blocks per CU at K = 128 [1, 2, 5], 64-row tiles at K = 256 [3, 4: 0.86-0.89 ms against 0.62] -- left
+      //  the tree: scratch loads and stores are vector-memory operations the counted waits of the ring do not know about)
       default: break;
     }
   }

@@ -86,6 +86,8 @@ class TrackEngine:
         self.shapes = [tuple(s) for s in level_shapes_override] if level_shapes_override else level_shapes(H, W)
         self.S = sum(h * w for h, w in self.shapes)
         self._keep: List[torch.Tensor] = []          # device tensors referenced by raw pointers
+        self._act_bufs: List[torch.Tensor] = []      # the subset of _keep that `_buf` handed out as per-step activations
+        self._value_launches: List = []              # (GemmArgs, rows per frame) of the value-projection launches (stress.value_planes_vs_tiled)
         self._steps: List = []                       # (fn, args tuple) launches
         self.meta: List[dict] = []                   # per launch: name, algorithmic bytes, flops
         self.sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
@@ -105,10 +107,24 @@ class TrackEngine:
         self._keep.append(t)
         return t
 
-    def _buf(self, rows, cols, dtype=None):
+    def _buf(self, rows, cols, dtype=None, static=False):
+        """An activation buffer of the plan.  static=True: the buffer carries state the step does not rewrite (constants left at plan
+        build, the temporal query memory) -- `poison_activations` leaves those alone."""
         t = torch.zeros(rows, cols, device=self.dev, dtype=dtype or self.dtype)
         self._keep.append(t)
+        if not static:
+            self._act_bufs.append(t)
         return t
+
+    def poison_activations(self):
+        """Self-check hook (mo_yolo_amd/stress.py): fill every floating-point activation buffer the step is supposed to (re)write with
+        NaN, so that a pass that reads something it never wrote shows it in its outputs.  Returns the number of buffers filled."""
+        n = 0
+        for t in self._act_bufs:
+            if t.is_floating_point():
+                t.fill_(float("nan"))
+                n += 1
+        return n
 
     def _kpad(self, K):
         bk = 32 if self.dtype == torch.float32 else 64
@@ -508,6 +524,7 @@ class TrackEngine:
             value = [(View(self.value_planes[i * arch.nh * B * S:(i * arch.nh + 1) * B * S]), B * S * dh) for i in range(ndl)]
             if fold is None:
                 self._gemm(feats, self._weight(Wv), ndl * hd, hd, value[0][0], B * S, shift=self._dev(bv), planes=(dh, B * S * dh))
+                self._value_launches.append((self._steps[-1][1][0]._obj, S))
             else:
                 # value = (P . Wp^T * s + t) . Wv^T + bv = P . (Wv diag(s) Wp)^T + (Wv t + bv): one launch per level, rows (b, i) of the
                 # level -> token b*S + off + i of every head plane (output row remap)
@@ -517,6 +534,7 @@ class TrackEngine:
                     bc = (Wv.double() @ fold["t"][li] + bv.double()).float()
                     self._gemm(src_view, self._weight(Wc), ndl * hd, arch.head_ch[li], View(self.value_planes[off:]), B * h_ * w_,
                                shift=self._dev(bc), planes=(dh, B * S * dh), c_rpb=h_ * w_, c_bstride=S)
+                    self._value_launches.append((self._steps[-1][1][0]._obj, h_ * w_))
                     if li == 0:
                         self._value_p3_step = len(self._steps) - 1
                     off += h_ * w_
@@ -535,7 +553,7 @@ class TrackEngine:
         # write.  The selected rows are recomputed below by the same GEMM on gathered rows.
         Wt_enc, bias_enc = self._linear_w(d + ".enc_output.0")
         ln_enc = (self._dev(sd[d + ".enc_output.1.weight"]), self._dev(sd[d + ".enc_output.1.bias"]))
-        self.scores_all = self._buf(B * S, nc, torch.float32)
+        self.scores_all = self._buf(B * S, nc, torch.float32, static=True)     # (masked tokens keep the constant written at plan build)
         wsc, bsc = self._dev(sd[d + ".enc_score_head.weight"]), self._dev(sd[d + ".enc_score_head.bias"])
         fuse_score = nc <= 8     # enc_score_head rides on the LayerNorm epilogue
         if fold is not None:
@@ -646,8 +664,8 @@ class TrackEngine:
         else:
             # per-sequence query memory (static shapes: the whole temporal step stays graph-capturable)
             i32, i64 = torch.int32, torch.int64
-            self.trk = dict(embed=self._buf(B * n_max, hd), qpos=self._buf(B * n_max, hd),
-                            ref=self._buf(B * n_max, 4, torch.float32),
+            self.trk = dict(embed=self._buf(B * n_max, hd, static=True), qpos=self._buf(B * n_max, hd, static=True),
+                            ref=self._buf(B * n_max, 4, torch.float32, static=True),
                             id=torch.full((B, n_max), -1, device=self.dev, dtype=i64),
                             dis=torch.zeros(B, n_max, device=self.dev, dtype=i32),
                             n=torch.zeros(B, device=self.dev, dtype=i32),
