@@ -72,9 +72,14 @@ const char* moy_strerror(int code);
  *   S tokens without materialising enc_output for them, head.py:1036-1042; the selected rows are recomputed afterwards).
  * 16-bit launches with N % 256 == 0, K >= 512, K % 64 == 0 (3x3: Cin % 64 == 0) and >= 384 tiles of 256 x 256 run the large-tile
  * LDS-DMA kernel (csrc/gemm_dma.hip): results bit-identical to the tiled kernel.
- * 16-bit launches with K == 256, N % 256 == 0 and M >= 65536 run a weight-stationary kernel (csrc/gemm_wreg.hip), with
- * results bit-identical to the tiled kernel in store mode; its score mode evaluates the LayerNorm statistics in one pass
- * (E[v^2] - mean^2), i.e. equal up to fp32 rounding.
+ * 16-bit 1x1 launches with M >= 65536 run a weight-stationary kernel (csrc/gemm_wreg.hip), results bit-identical to the tiled
+ * kernel in store mode: N % 256 == 0 with K in {128, 256, 384, 512} (incl. c_rows_per_batch, and `pre` at K == 256), N == 128 with
+ * K in {128, 192, 256} (`pre` at K == 128), the value form N % 512 == 0, plane_cols == 32, K in {128, 256} (incl. plane_cols
+ * together with c_rows_per_batch: one pyramid level per launch), and the score mode (C == NULL, ln_* + dot_*, N == 256, K in
+ * {128, 256}, optionally over row runs run_* with a second A numbering run_a_*), which evaluates the LayerNorm statistics in one
+ * pass (E[v^2] - mean^2), i.e. equal up to fp32 rounding.  Refusals the host checks before any launch (MOY_ENOSYS; moy_gemm_query
+ * answers the same without launching): M * lda * 2 > 4 GiB with row runs, a remapped C of more than 2 GiB, a head plane of more
+ * than 1 GiB, a seed of more than 2 GiB, lda / ldc not a multiple of 8 elements or a base that is not 16-byte aligned.
  * -------------------------------------------------------------------------------------------- */
 typedef struct moy_gemm_args {
   const void* A;
@@ -480,6 +485,20 @@ int moy_level_rows(const int32_t* tok_local, int B, int nq, int n_levels, const 
                    void* stream);
 int moy_level_select(const float* G, int64_t level_stride, int64_t ldg, const int32_t* level, const float* shift,
                      const int32_t* tok_local, const uint8_t* valid, int M, int N, void* dst, int64_t ldd, int dtype, void* stream);
+
+/* Round 5: the dispatch of moy_gemm WITHOUT the launch (host only: no stream, nothing is enqueued, no device memory is touched).
+ * Runs the argument validation and the kernel eligibility rules of a real call and returns what that call would return before it
+ * launches -- MOY_OK, MOY_EINVAL, or MOY_ENOSYS where a form the arguments REQUIRE (row runs, a folded 1x1 consumer) has no kernel for
+ * the shape / launch size; *kernel (may be NULL) receives the kernel family that would run (MOY_KERNEL_*), 0 on error.  A planner
+ * (mo_yolo_amd/engine.py: the folded head, the conv + 1x1 consumer pair, the score runs) asks here instead of trial-launching
+ * on uninitialised buffers.  The reference has no counterpart: cuDNN / cuBLAS pick their kernels behind torch. */
+#define MOY_KERNEL_TILED 1        /* gemm_kernel: tiled implicit GEMM (every shape) */
+#define MOY_KERNEL_WREG 2         /* gemm_wreg_kernel: weight-stationary 1x1 / value / score forms */
+#define MOY_KERNEL_DMA 3          /* gemm_dma_kernel: 256 x 256 tiles, both operands by LDS-DMA */
+#define MOY_KERNEL_CONV_WS 4      /* conv_ws_kernel: persistent weight-stationary 3x3, stride 1 */
+#define MOY_KERNEL_CONV_S2 5      /* conv_s2_kernel: persistent weight-stationary 3x3, stride 2 (+ folded 1x1 consumer) */
+#define MOY_KERNEL_CONV_DIRECT 6  /* conv_direct_kernel: tiled direct 3x3 */
+int moy_gemm_query(const moy_gemm_args* a, int* kernel);
 
 /* Round 4: compute-unit budget of the calling host THREAD's following launches.  The persistent kernels behind moy_gemm (the
  * weight-stationary 1x1 / value / score kernel, the weight-stationary 3x3 convolution) size their grids for `n_cus` compute units

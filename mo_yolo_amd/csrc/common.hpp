@@ -184,6 +184,17 @@ inline int launch_status() {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// moy_gemm_query (round 5): the dispatch of moy_gemm WITHOUT the launch.  While the calling thread's slot is non-zero every launch
+// site of moy_gemm's kernels records its kernel family there and returns MOY_OK instead of launching -- the validation and the
+// eligibility rules are the ones a real call runs, so a planner can ask "which kernel, if any" on the host.
+int& plan_only_slot();
+inline bool plan_only(int kernel) {
+  int& s = plan_only_slot();
+  if (!s) return false;
+  s = kernel;
+  return true;
+}
+
 // gemm_wreg.hip: weight-stationary kernel for K == 256 (MOY_ENOSYS when the shape is not its own)
 int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st);
 // gemm_dma.hip: 256-row tiles, both operands by LDS-DMA, for the matrix-rate-bound products (MOY_ENOSYS when the shape is not its own)

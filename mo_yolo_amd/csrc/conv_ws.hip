@@ -698,6 +698,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_ws_pipe_kernel(const ConvWs
 
 template <typename T, int C, int N, int TH, int WN, bool RES, int OCC = 1, int STAG = 0>
 static int launch_conv_ws_pipe(ConvWsParams& p, int B, hipStream_t st) {
+  if (plan_only(MOY_KERNEL_CONV_WS)) return MOY_OK;          // moy_gemm_query: the dispatch without the launch (and without touching the attribute statics)
   constexpr int PATCH_PIECES = ((TH + 2) * 18 * (C / 8) + 63) / 64;
   constexpr int LDS = 2 * (PATCH_PIECES * 1024 + TH * 16 * N * 2) + 1024;
   if constexpr (STAG == 0 && OCC == 1) {
@@ -1053,6 +1054,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_pp_kernel(const ConvWsParams p
 
 template <typename T, int C, int N, int TH, int WN, bool RES, int ABL = 0>
 static int launch_conv_ws_pp(ConvWsParams& p, int B, hipStream_t st) {
+  if (plan_only(MOY_KERNEL_CONV_WS)) return MOY_OK;          // moy_gemm_query: the dispatch without the launch (and without touching the attribute statics)
   constexpr int PATCH_PIECES = ((TH + 2) * 18 * (C / 8) + 63) / 64;
   constexpr int LDS = 2 * (PATCH_PIECES * 1024 + TH * 16 * N * 2) + 1024;
   if constexpr (ABL == 0 && std::is_same<T, bf16_t>::value && !RES) {
@@ -1333,6 +1335,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvS2Params p) {
 
 template <typename T, int C, int N, int TH, int WN, int NBUF, bool POST = false>
 static int launch_conv_s2(ConvS2Params& p, int B, hipStream_t st) {
+  if (plan_only(MOY_KERNEL_CONV_S2)) return MOY_OK;          // moy_gemm_query: the dispatch without the launch (and without touching the attribute statics)
   constexpr int PIECES = ((2 * TH + 1) * 33 * (C / 8) + 63) / 64;
   constexpr int LDS = NBUF * PIECES * 1024 + (POST ? 2 : 1) * TH * 16 * N * 2 + 1024;
   auto kern = conv_s2_kernel<T, C, N, TH, WN, NBUF, POST>;
@@ -1375,6 +1378,7 @@ static int cws_group(int W, int64_t img_bytes_max) {
 
 template <typename T, int C, int N, int TH, int WN, int NBUF, bool RES, int OCC = 1, bool SPREAD = false, int ABL = 0, bool GRP = false>
 static int launch_conv_ws(ConvWsParams& p, int B, hipStream_t st) {
+  if (plan_only(MOY_KERNEL_CONV_WS)) return MOY_OK;          // moy_gemm_query: the dispatch without the launch (and without touching the attribute statics)
   using G = CwsGeom<C, N, TH, NBUF, RES>;
   static_assert(G::LDS * OCC <= 160 * 1024, "LDS budget");
   if constexpr (ABL == 0 && !GRP && C == 128 && !SPREAD && OCC == 1) {

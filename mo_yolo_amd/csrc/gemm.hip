@@ -597,6 +597,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
 
 template <typename T, int BM, int BN, int WGM, int WGN, bool LN, int KS, int NSET>
 static int launch_inst(GemmParams& p, hipStream_t st) {
+  if (plan_only(MOY_KERNEL_TILED)) return MOY_OK;          // moy_gemm_query: the dispatch without the launch (and without touching the attribute statics)
   constexpr int lds = gemm_lds_bytes<BM, BN>();
   auto kern = gemm_kernel<T, BM, BN, WGM, WGN, LN, KS, NSET>;
   static bool attr_set = false;   // > 64 KiB dynamic LDS needs the opt-in once per kernel symbol
@@ -841,6 +842,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_direct_kernel(const Ge
 
 template <typename T, int C, int BN, int TH, int WGM, int WGN>
 static int launch_conv_direct(GemmParams& p, int B, hipStream_t st) {
+  if (plan_only(MOY_KERNEL_CONV_DIRECT)) return MOY_OK;          // moy_gemm_query: the dispatch without the launch (and without touching the attribute statics)
   constexpr int BM = TH * 16;
   constexpr int stage = conv_stage_bytes<C, BN, TH>();
   constexpr int epi_h = BM * (BN + 4) * 2, epi_f = BM * (BN + 4) * 4;
@@ -929,6 +931,22 @@ int& cu_limit_slot() {
   return v;
 }
 }  // namespace moy
+
+namespace moy {
+int& plan_only_slot() {
+  static thread_local int v = 0;
+  return v;
+}
+}  // namespace moy
+
+extern "C" int moy_gemm_query(const moy_gemm_args* a, int* kernel) {
+  int& slot = moy::plan_only_slot();
+  slot = -1;
+  const int rc = moy_gemm(a, nullptr);
+  if (kernel) *kernel = (rc == MOY_OK && slot > 0) ? slot : 0;
+  slot = 0;
+  return rc;
+}
 
 extern "C" int moy_set_cu_limit(int n_cus) {
   int& v = moy::cu_limit_slot();

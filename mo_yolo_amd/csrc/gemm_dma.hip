@@ -488,6 +488,7 @@ __device__ __forceinline__ void gd_epilogue(const GdParams& p, f32x4 (&acc)[2][4
 template <typename T, int WR, int NJ, int KS, int DIAG = 0, int MF = 16>
 static int gd_launch(GdParams& p, hipStream_t st) {
   using G = GdGeom<WR, NJ>;
+  if (plan_only(MOY_KERNEL_DMA)) return MOY_OK;          // moy_gemm_query: the dispatch without the launch (and without touching the attribute statics)
   if constexpr (DIAG == 0 && MF == 16 && WR == 2 && NJ == 2) {
     static int mf32 = -1;                  // MOY_GD_MFMA32=1: v_mfma_f32_32x32x16 (A/B knob; results equal up to fp32 rounding, not bit for bit)
     if (mf32 < 0) { const char* e = getenv("MOY_GD_MFMA32"); mf32 = e ? atoi(e) : 0; }

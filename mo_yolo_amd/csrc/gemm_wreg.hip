@@ -611,17 +611,18 @@ template <typename T, int BM, int NBUF, int OCC, bool LN = false, int NW = 4, in
 static int launch_wreg(WregParams& p, hipStream_t st) {
   const int lds = wreg_lds_bytes<BM, NBUF, LN, NW, WC, K>() + (LN && p.a_mask ? ((p.mask_period + 31) / 32) * 4 : 0);
   auto kern = gemm_wreg_kernel<T, BM, NBUF, OCC, LN, NW, WC, K, ABL, PRE>;
+  const int slots = cu_limit(wreg_num_cus()) / 8 * OCC;          // resident blocks per XCD
+  p.ntiles = ((p.run_levels ? p.run_mv : p.M) + BM - 1) / BM;
+  p.ngroups = p.N / (NW * WC);
+  p.lanes = slots / p.ngroups;
+  if (p.lanes < 1) return MOY_ENOSYS;
+  if (plan_only(MOY_KERNEL_WREG)) return MOY_OK;          // moy_gemm_query: the dispatch without the launch (and without touching the attribute statics)
   static int attr_lds = 0;
   if (lds > 65536 && lds > attr_lds) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return MOY_ELAUNCH;
     attr_lds = lds;
   }
-  const int slots = cu_limit(wreg_num_cus()) / 8 * OCC;          // resident blocks per XCD
-  p.ntiles = ((p.run_levels ? p.run_mv : p.M) + BM - 1) / BM;
-  p.ngroups = p.N / (NW * WC);
-  p.lanes = slots / p.ngroups;
-  if (p.lanes < 1) return MOY_ENOSYS;
   hipLaunchKernelGGL(kern, dim3(8 * p.lanes * p.ngroups), dim3(64 * NW), lds, st, p);
   return launch_status();
 }

@@ -209,8 +209,9 @@ class TrackEngine:
     # conv + BN + SiLU on channels-last views
     def _conv(self, p, x: View, hw_in, cin, cout, k, s, out: View, R: View | None = None, act=L.ACT_SILU, up_src=None, post=None):
         """post = prefix of a 1x1 Conv that is this 3x3 conv's only consumer: folded into the launch (`out` then takes ITS output);
-        returns False -- nothing planned -- when the library has no fused form for the shape (the launch is tried once, now)."""
-        """up_src = (u view, (h, w), cu): the conv's input is Concat[Upsample2x(u), x] (u at half resolution, cu channels first)."""
+        returns False -- nothing planned -- when the library has no fused form for the shape / launch size (asked on the host:
+        `moy_gemm_query`, nothing is launched at plan build).
+        up_src = (u view, (h, w), cu): the conv's input is Concat[Upsample2x(u), x] (u at half resolution, cu channels first)."""
         sd = self.sd
         w = sd[p + ".conv.weight"]
         scale, shift = self._bn(p + ".bn")
@@ -238,17 +239,25 @@ class TrackEngine:
             s2_, h2_ = self._bn(post + ".bn")
             self._gemm(x, Wt, cout, 9 * cin, out, self.B * Hout * Wout, ksize=3, stride=s, geom=(self.B, Hin, Win, Hout, Wout, cin),
                        scale=scale, shift=shift, act=act, post=(self._weight(w2.reshape(n2, cout)), s2_, h2_, n2, L.ACT_SILU))
-            fn, args = self._steps[-1]
-            rc = fn(*args, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            rc, _ = self._query_last()
             if rc == L.ENOSYS:                     # no fused form for this shape / launch size
                 self._steps.pop()
                 self.meta.pop()
                 return False
-            L.check(rc, "moy_gemm (conv + folded 1x1 consumer)")
+            L.check(rc, "moy_gemm_query (conv + folded 1x1 consumer)")
             return (Hout, Wout)
         self._gemm(x, Wt, cout, 9 * cin, out, self.B * Hout * Wout, ksize=3, stride=s,
                    geom=(self.B, Hin, Win, Hout, Wout, cin), scale=scale, shift=shift, act=act, R=R)
         return (Hout, Wout)
+
+    def _query_last(self):
+        """(rc, kernel family) the library answers for the `moy_gemm` launch planned last -- validation and kernel eligibility of a
+        real call, on the host, without launching (include/moyolo.h: moy_gemm_query)."""
+        fn, args = self._steps[-1]
+        assert fn is self.lib.moy_gemm or fn.__name__ == "moy_gemm"
+        k = C.c_int(0)
+        rc = self.lib.moy_gemm_query(args[0], C.byref(k))
+        return rc, k.value
 
     def _linear_w(self, p, rows=None):
         w, b = self.sd[p + ".weight"], self.sd[p + ".bias"]
@@ -1026,6 +1035,28 @@ class TrackEngine:
             shift = sd[p + ".bias"].double() - sd[p + ".running_mean"].double() * scale
             Wp = sd[f"{d}.input_proj.{li}.0.weight"].reshape(arch.hd, arch.head_ch[li]).double()
             s_.append(scale); t_.append(shift); sWp.append(scale[:, None] * Wp)
+        # the folded launches exist in the weight-stationary kernel only (head planes + output row remap; row runs with a
+        # second A numbering) -- ask the library, on the host, whether it takes every one of them at this batch (byte-range limits of
+        # its 32-bit lane offsets: a plane <= 1 GiB, M * lda * 2 <= 4 GiB, ...); anything else keeps the classic plan
+        S, hd, dh = self.S, arch.hd, arch.hd // arch.nh
+        al = self._dev(torch.zeros(64, dtype=torch.float32)).data_ptr()       # any 16-byte aligned device address: the query dereferences nothing
+        off = 0
+        for li, ((v, _), (h_, w_)) in enumerate(zip(head_src, self.shapes)):
+            y0, y1, x0, x1 = rect[li]
+            a = L.GemmArgs()
+            a.A, a.lda, a.W, a.M, a.N, a.K, a.ksize, a.stride = v.ptr, v.ld, al, B * h_ * w_, arch.ndl * hd, arch.head_ch[li], 1, 1
+            a.shift, a.C, a.ldc, a.dtype = al, al, dh, self.code
+            a.plane_cols, a.plane_stride, a.c_rows_per_batch, a.c_batch_stride = dh, B * S * dh, h_ * w_, S
+            b = L.GemmArgs()
+            b.A, b.lda, b.W, b.M, b.N, b.K, b.ksize, b.stride = v.ptr, v.ld, al, B * S, hd, arch.head_ch[li], 1, 1
+            b.shift, b.ln_g, b.ln_b, b.dot_w, b.dot_b, b.dot_out, b.dot_n, b.dtype = al, al, al, al, al, al, arch.nc, self.code
+            b.run_levels, b.run_period, b.run_a_period, b.run_a_off = 1, S, h_ * w_, off
+            b.run_tok0[0], b.run_pitch[0], b.run_len[0], b.run_rows[0] = off + y0 * w_ + x0, w_, x1 - x0 + 1, y1 - y0 + 1
+            for q_ in (a, b):
+                k = C.c_int(0)
+                if self.lib.moy_gemm_query(C.byref(q_), C.byref(k)) != 0 or k.value != L.KERNEL_WREG:
+                    return None
+            off += h_ * w_
         return dict(rect=rect, s=s_, t=t_, sWp=sWp)
 
     def _score_runs(self, valid_host):

@@ -89,3 +89,41 @@ def test_cpu_tensors_are_rejected_like_the_reference_op():
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
         ops.ms_deform_attn_forward(v, torch.tensor([[2, 2]]), torch.tensor([0]), torch.zeros(1, 1, 1, 1, 1, 2),
                                    torch.zeros(1, 1, 1, 1, 1))
+
+
+def test_gemm_query_answers_the_dispatch_on_the_host():
+    """moy_gemm_query (round 5): validation + kernel eligibility of a real moy_gemm call, no launch, no device access -- so it runs
+    here without a GPU.  The engine's planner asks it instead of trial-launching on uninitialised buffers."""
+    lib = _lib.lib()
+    buf = (ctypes.c_char * 4096)()
+    al = (ctypes.addressof(buf) + 63) // 64 * 64                    # a 64-byte aligned address: the query dereferences nothing
+
+    def q(**kw):
+        a = _lib.GemmArgs()
+        a.A, a.W, a.C, a.lda, a.ldc, a.ksize, a.stride, a.dtype = al, al, al, kw.get("K", 256), kw.get("N", 256), 1, 1, _lib.BF16
+        for k, v in kw.items():
+            setattr(a, k, v)
+        k = ctypes.c_int(-7)
+        rc = lib.moy_gemm_query(ctypes.byref(a), ctypes.byref(k))
+        return rc, k.value
+
+    assert q(M=300, N=256, K=256) == (0, _lib.KERNEL_TILED)                        # the decoder's query-sized linears
+    assert q(M=70000, N=256, K=256, c_rows_per_batch=1000, c_batch_stride=1300) == (0, _lib.KERNEL_WREG)   # input_proj with its token scatter
+    assert q(M=70000, N=1536, K=128, ldc=32, plane_cols=32, plane_stride=70000 * 32) == (0, _lib.KERNEL_WREG)   # the P3 value form
+    assert q(M=70000, N=256, K=256, dtype=_lib.F32) == (0, _lib.KERNEL_TILED)        # fp32: always the exact tiled kernel
+    assert q(M=100000, N=512, K=1024) == (0, _lib.KERNEL_DMA)                       # deep K: the 256 x 256 LDS-DMA tiles
+    # a plane of more than 1 GiB is outside the 32-bit lane offsets of the value form: the tiled kernel takes the launch instead
+    assert q(M=70000, N=1536, K=128, ldc=32, plane_cols=32, plane_stride=1 << 30) == (0, _lib.KERNEL_TILED)
+    # a form the arguments REQUIRE (row runs: score pass over the valid rectangle) below the persistent kernel's launch size: refused
+    runs = dict(run_levels=1, run_period=1000, run_tok0=(ctypes.c_int32 * 4)(0), run_pitch=(ctypes.c_int32 * 4)(10), run_len=(ctypes.c_int32 * 4)(10),
+                run_rows=(ctypes.c_int32 * 4)(10))
+    rc, k = q(M=5000, N=256, K=256, C=None, ln_g=al, ln_b=al, dot_w=al, dot_b=al, dot_out=al, dot_n=1, **runs)
+    assert (rc, k) == (_lib.ENOSYS, 0)
+    assert q(M=300, N=250, K=256)[0] == _lib.EINVAL                                  # N % 4
+    geom = dict(ksize=3, stride=2, B=64, Hin=152, Win=272, Hout=76, Wout=136, Cin=64, M=64 * 76 * 136, N=128, K=576, lda=64, ldc=128, act=_lib.ACT_SILU,
+                scale=al, shift=al)
+    assert q(**geom) == (0, _lib.KERNEL_CONV_S2)
+    assert q(**dict(geom, post_W=al, post_scale=al, post_shift=al, post_n=128, post_act=_lib.ACT_SILU)) == (0, _lib.KERNEL_CONV_S2)
+    small = dict(geom, B=1, M=76 * 136)
+    assert q(**small)[0] == 0 and q(**small)[1] != _lib.KERNEL_CONV_S2
+    assert q(**dict(small, post_W=al, post_scale=al, post_shift=al, post_n=128, post_act=_lib.ACT_SILU))[0] == _lib.ENOSYS   # never computed without its consumer

@@ -140,7 +140,9 @@ def test_bench_control_flow_c3_eight_ranks_gloo_dry_run():
     assert [e["sequences"] for e in rm] == [[i] for i in range(8)]                   # sequence i -> rank i, nothing shared
     assert abs(d["value"] - 576 * 4 * 8 / (d["ms_per_step"] * 4 * 1e-3)) < 1e-4 * d["value"]
     # the per-rank table that makes the first hardware run diagnosable -- 8 distinct devices, 8 sequences, 8 timings
-    rk = d["config"]["ranks"]
+    assert len(lines[0]) < 4096
+    assert [e["rank"] for e in d["config"]["ranks"]] == list(range(8))          # the line carries the short per-rank records ...
+    rk = json.load(open(d["full"]))["config"]["ranks"]                           # ... the side file it names the full ones
     assert [e["rank"] for e in rk] == list(range(8)) and [e["local_rank"] for e in rk] == list(range(8))
     assert len({e["hip_visible_devices"] for e in rk}) == 8
     assert sorted(sq for e in rk for sq in e["sequences"]) == list(range(8))
@@ -150,6 +152,87 @@ def test_bench_control_flow_c3_eight_ranks_gloo_dry_run():
     assert all(c for c in cpus)
     if len(os.sched_getaffinity(0)) >= 16:
         assert len(set(cpus)) == 8                                # every rank pinned its own slice of the host cores
+
+
+def _bench(*flags, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HIP_VISIBLE_DEVICES", "LOCAL_WORLD_SIZE",
+                                                            "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=timeout)
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_gpus_n_self_launches_n_ranks_without_torchrun(n, tmp_path):
+    """`python bench.py --gpus N` launched plainly means N GPUs -- the parent (which never touches HIP) starts N ranks of
+    itself with the environment torch.distributed.run would give them and forwards rank 0's line (ultralytics/utils/dist.py:49-60 is
+    the reference's own self-launch)."""
+    import json
+    p = _bench("--gpus", str(n), "--steps", "3", "--warmup", "1", "--dry-run", "--backend", "gloo", "--full-out", str(tmp_path / "full.json"))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096, (len(lines), [len(l) for l in lines])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["config"]["dry_run"] is True
+    rk = d["config"]["ranks"]
+    assert [e["rank"] for e in rk] == list(range(n)) and [e["hip_visible_devices"] for e in rk] == [str(i) for i in range(n)]
+    assert sorted(sq for e in rk for sq in e["sequences"]) == list(range(n))
+    assert abs(d["value"] - 576 * 3 * n / (d["ms_per_step"] * 3 * 1e-3)) < 1e-4 * d["value"]
+    full = json.load(open(tmp_path / "full.json"))                 # the side file the line names holds the same headline
+    assert d["full"] == str(tmp_path / "full.json") and full["value"] == d["value"] and full["n_gpus"] == n
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """Under a launcher, `--gpus` must equal WORLD_SIZE: one rank reported as eight (or eight as one) is refused with exit code 2."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 2 and b"--gpus 2" in p.stderr and not p.stdout.strip()
+    p = _bench("--temporal", "100", "--from-host", "--dry-run", timeout=120)     # ADVICE r4: per-frame-mode legs are rejected with --temporal
+    assert p.returncode == 2 and b"not with --temporal" in p.stderr
+
+
+def test_bench_final_line_is_compact_whatever_the_run_measured():
+    """round 4's default line was 23 KB (ten nested legs with full parity blocks) and the driver could not parse it.  The
+    final line is built by `compact_line` from the full record: under 4 KB with every block at its largest, json round trip, the
+    contract's keys + roofline / cpu_baseline / parity / selfcheck scalars; the rest lives in the side file it names."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    big = "x" * 3000
+    stats = {"frames": 32, "topk_overlap": 0.97531, "topk_order_equal_frames": 0, "rows_matched": 9363, "box_max_err_matched": 0.00407823920249939,
+             "score_max_err_matched": 0.14741730690002441, "hs_max_err_matched": 0.673367440700531, "births_flipped": 78, "active_rows_reference": 1048,
+             "active_rows": 1066, "birth_flip_frac_of_active": 0.07443, "ids_equal": False}
+    full = {"metric": "frames/sec (whole node) on 1088x608 MOT17 streams", "value": 15846.81, "unit": "frames/s", "n_gpus": 8, "steps": 20, "warmup": 5,
+            "ms_per_step": 36.3480, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": big, "frames_per_step_per_gpu": 576, "streams": 2, "graph": True, "launches_per_step": 83, "weights": big,
+                       "sequences_of_rank0": [0], "control_backend": "gloo", "hip_visible_devices_rank0": "0", "dry_run": False, "hbm_allocated_gb": 67.1,
+                       "ranks": [{"rank": r, "local_rank": r, "dt_local_s": 0.727123, "fps_local": 15846.81, "hip_visible_devices": str(r), "cpus": "0-31 (32)",
+                                  "sequences": [r], "host": big, "device": big, "uuid": big, "pci_bus_id": "0000:05:00.0"} for r in range(8)],
+                       "host_link": {"spec": big}, "predictor": big},
+            "roofline": {"bound": "hbm", "kernel": "gemm1x1 M2976768 N1536 K128" + big, "launch_index": 40, "achieved": 5417.3, "peak": 8000.0, "unit": "GB/s",
+                         "frac": 0.6772, "traffic": 9910000000.0, "traffic_source": big[:200], "avg_ms": 1.8287, "share_of_step": 0.09, "alg_bytes_per_launch": 9907000000,
+                         "tflops": 640.0, "runner_up": {"kernel": "stem+conv1 fused" + big, "avg_ms": 1.55, "frac": 0.17, "traffic": 1.0}, "note": big},
+            "roofline_step": {"frac": 0.75, "traffic_frac": 0.45, "sum_of_floors_frac": 0.43, "sum_kernel_ms_eager": 19.5, "top_kernels": [{"name": big, "ms": 1.0}] * 8},
+            "parity": {"bench_engine_vs_fp32_engine": stats, "token_id_agreement": {"tokens_id_equal_frac": 0.91253, "junk": big},
+                       "agreement_hota": {"published": {"HOTA": 37.8, "DetA": 85.0, "AssA": 17.2}, "compat": {"HOTA": 1.0}}, "frames": 32, "first_frame": 8,
+                       "bench_engine": "bf16 B=288", "reference_engine": "f32 B=4", "absolute": {"ok": True, "yardstick": {"engine": {"births_flipped": 18, "x": big},
+                       "eager_torch_same_dtype": {"births_flipped": 44}}}, "regression": {"ok": True, "bars": {"a": big}}, "ok": True,
+                       "fp32_engine_vs_cpu_oracle": {"frames": 2, "logits_max_err": 2.8e-05, "topk_equal": True, "ids_exact": True, "ok": True}},
+            "selfcheck": {"ok": True, "replays_bit_identical": True, "value_planes_equal_tiled": True, "detail": {"junk": big}},
+            "cpu_baseline": {"value": 10.4, "unit": "frames/s", "cores": 16, "kind": "port", "numeric_only_fps": 10.5, "cores_available": 256, "sample": big},
+            "legs": {f"leg{i}": {"value": 1000.0 + i, "parity": big} for i in range(10)}}
+    line = json.dumps(bench.compact_line(full, "gpurun_out/bench_full.json"))
+    assert len(line) < 4096, len(line)
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d
+    assert d["value"] == 15846.81 and d["n_gpus"] == 8 and d["config"]["frames_per_step_per_gpu"] == 576 and len(d["config"]["ranks"]) == 8
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "avg_ms", "alg_bytes_per_launch")) <= set(d["roofline"])
+    assert d["cpu_baseline"]["value"] == 10.4 and d["cpu_baseline"]["cores"] == 16 and d["cpu_baseline"]["kind"] == "port"
+    assert d["parity"]["ok"] is True and d["parity"]["ids_equal"] is False and d["parity"]["birth_flip_frac"] == 0.07443
+    assert d["parity"]["births_flipped_engine_vs_eager_same_dtype"] == [18, 44] and d["parity"]["fp32_engine_vs_cpu_oracle"]["ids_exact"] is True
+    assert d["selfcheck"] == {"ok": True, "replays_bit_identical": True, "value_planes_equal_tiled": True} and d["full"] == "gpurun_out/bench_full.json"
 
 
 def test_bench_pins_one_device_per_local_rank(monkeypatch):

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--config", default="c2")
     ap.add_argument("--no-hog", action="store_true")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--time", type=int, default=0, help="also time every form: mean of this many back-to-back launches on a quiet device (HIP events)")
     a = ap.parse_args()
     import torch
     from mo_yolo_amd import _lib as L
@@ -55,6 +56,19 @@ def main():
                     torch.cuda.synchronize()
                     if not torch.equal(got, ref):
                         fails.append(dict(run=i, where=case.where(got, ref)))
+                if a.time:
+                    hog.stream.synchronize()
+                    torch.cuda.synchronize()
+                    out_t = case.run()                  # (allocation of the output outside the timed launches)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize()
+                    e0.record()
+                    for _ in range(a.time):
+                        case._launch(out_t, 0, case.B if hasattr(case, "B") else case.f["B"])
+                    e1.record()
+                    torch.cuda.synchronize()
+                    extra["us_per_launch"] = round(e0.elapsed_time(e1) / a.time * 1e3, 2)
+                    del out_t
                 key = f"{form}/{str(dt).replace('torch.', '')}"
                 res["forms"][key] = dict(runs=a.reps, failures=len(fails), first=fails[:3], **extra)
                 print(f"[stress {time.time() - t_start:6.0f}s] {key}: {len(fails)} of {a.reps} runs differ", file=sys.stderr, flush=True)
