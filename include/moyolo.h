@@ -329,6 +329,36 @@ int moy_mha_core_masked(const void* qkv, int64_t ld_qkv, int B, int L, int nh, i
 int moy_msda_fused(const void* value, int64_t ldv, int64_t head_stride, int B, int S, const int32_t* shapes_hw, int L,
                    const float* offaw, int64_t ld_oa, const float* ref, int Lq, void* out, int64_t ldo, int dtype, void* stream);
 
+/* Round 5: the same sampling with the FIRST pyramid level gathered RAW and projected afterwards (csrc/msda_raw.hip).  value_proj
+ * (transformer.py:255-257), input_proj + BN (head.py:838-839) and the bilinear sum (nn/modules/utils.py:41-78) are all linear, so for
+ * level 0:  sum_p a_p . bilinear(W x + c)(loc_p) = W_h . (sum_p a_p . bilinear(x)(loc_p)) + c_h . sum_p a_p . (in-range corner weights)
+ * -- the level's projected value planes (54 % of which no sample of a layer touches at 1088x608) are never formed.
+ *   x0 T: level 0 as the backbone left it, [B, H0, W0, 128] channels-last with pixel pitch ld0 (>= 128) elements;
+ *   wc T [256][128] / bc fp32 [256]: value_proj o BN o input_proj of THIS layer composed by the caller (W = Wv diag(s) Wp, c = Wv t + bv);
+ *   planes T: head planes of levels 1 .. L-1, [8][B * S1][32] with head_stride elements between heads, S1 = tokens per frame of
+ *   those levels (level-major); offaw / ref / out / shapes_hw as moy_msda_fused (shapes_hw[0] = (H0, W0)).  16-bit types only
+ *   (MOY_ENOSYS otherwise: the fp32 engine keeps the projected planes); H0, W0 >= 2; a frame of level 0 below 2 GiB.
+ *   Numerics vs moy_msda_fused over projected planes: the level-0 contribution is rounded to T once (the gathered vector, before
+ *   its product) instead of once per projected value; sums in fp32. */
+typedef struct moy_msda_raw_args {
+  const void* x0;
+  int64_t ld0;
+  const void* wc;
+  const float* bc;
+  const void* planes;
+  int64_t head_stride;
+  int32_t S1;
+  int32_t B, Lq, L;
+  const int32_t* shapes_hw;   /* HOST int32 [L][2] = (H, W) per level */
+  const float* offaw;
+  int64_t ld_oa;
+  const float* ref;
+  void* out;
+  int64_t ldo;
+  int32_t dtype;
+} moy_msda_raw_args;
+int moy_msda_raw0(const moy_msda_raw_args* a, void* stream);
+
 /* ---- Temporal mode: carried track queries in a fixed-size query memory per sequence.
  * The shipped snapshot resets its state every frame and its carried branch crashes, so these entry points
  * follow the branch's visible intent (nn/modules/head.py:206-221, 1055-1064: decoder rows = [track queries | top-k detect

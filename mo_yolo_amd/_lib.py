@@ -57,6 +57,15 @@ class DecoderMidArgs(C.Structure):
     ]
 
 
+class MsdaRawArgs(C.Structure):
+    """Mirror of `moy_msda_raw_args` (include/moyolo.h)."""
+    _fields_ = [
+        ("x0", vp), ("ld0", i64), ("wc", vp), ("bc", vp), ("planes", vp), ("head_stride", i64), ("S1", i32),
+        ("B", i32), ("Lq", i32), ("L", i32), ("shapes_hw", vp), ("offaw", vp), ("ld_oa", i64), ("ref", vp),
+        ("out", vp), ("ldo", i64), ("dtype", i32),
+    ]
+
+
 class C2fArgs(C.Structure):
     """Mirror of `moy_c2f_args` (include/moyolo.h)."""
     _fields_ = [
@@ -95,6 +104,7 @@ SIGNATURES = {
                                       vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "moy_temporal_commit": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "moy_msda_fused": (C.c_int, [vp, i64, i64, C.c_int, C.c_int, vp, C.c_int, vp, i64, vp, C.c_int, vp, i64, C.c_int, vp]),
+    "moy_msda_raw0": (C.c_int, [C.POINTER(MsdaRawArgs), vp]),
     "moy_msda_fwd_f32": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp, vp]),
     "moy_msda_fwd_bf16": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp, vp]),
     "moy_msda_fwd_f16": (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp, vp]),

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmoyolo.so")
-SOURCES = ["gemm.hip", "gemm_wreg.hip", "gemm_dma.hip", "conv_ws.hip", "stem_l1.hip", "c2f_fused.hip", "mlp_head.hip", "dec_tail.hip", "dec_mid.hip", "ops.hip"]
+SOURCES = ["gemm.hip", "gemm_wreg.hip", "gemm_dma.hip", "conv_ws.hip", "stem_l1.hip", "c2f_fused.hip", "mlp_head.hip", "dec_tail.hip", "dec_mid.hip", "msda_raw.hip", "ops.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

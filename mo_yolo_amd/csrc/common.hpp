@@ -83,6 +83,17 @@ struct DT<f16_t> {
     asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(w), "v"(g), "v"(acc));
     return d;
   }
+  // the same with a wave-uniform weight in an SGPR (msda_raw.hip: weights come from v_readlane)
+  static __device__ __forceinline__ float fma_lo_s(uint32_t w, float g, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(w), "s"(g), "v"(acc));
+    return d;
+  }
+  static __device__ __forceinline__ float fma_hi_s(uint32_t w, float g, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(w), "s"(g), "v"(acc));
+    return d;
+  }
   static __device__ __forceinline__ f32x4 load4(const f16_t* p) {
     u32x2 w = *reinterpret_cast<const u32x2*>(p);
     return f32x4{lo(w.x), hi(w.x), lo(w.y), hi(w.y)};
@@ -101,6 +112,8 @@ struct DT<bf16_t> {
   static __device__ __forceinline__ float lo(uint32_t w) { return bflo(w); }
   static __device__ __forceinline__ float fma_lo(uint32_t w, float g, float acc) { return __builtin_fmaf(bflo(w), g, acc); }
   static __device__ __forceinline__ float fma_hi(uint32_t w, float g, float acc) { return __builtin_fmaf(bfhi(w), g, acc); }
+  static __device__ __forceinline__ float fma_lo_s(uint32_t w, float g, float acc) { return __builtin_fmaf(bflo(w), g, acc); }
+  static __device__ __forceinline__ float fma_hi_s(uint32_t w, float g, float acc) { return __builtin_fmaf(bfhi(w), g, acc); }
   static __device__ __forceinline__ float hi(uint32_t w) { return bfhi(w); }
   static __device__ __forceinline__ f32x4 load4(const bf16_t* p) {
     u32x2 w = *reinterpret_cast<const u32x2*>(p);

@@ -1,0 +1,314 @@
+// Deformable-attention sampling with the FIRST pyramid level gathered RAW and projected afterwards (round 5).
+//
+// MSDeformAttn.forward (nn/modules/transformer.py:246-287) projects all S tokens with `value_proj` (:255-257) and then samples
+// 300 x 8 x 12 points of the projected maps (nn/modules/utils.py:41-78).  On the P3 level (76 x 136 tokens at 1088x608) a layer's
+// 38.4 k taps touch at most 46 % of the 82.7 k head-cells it projected, and that launch was the longest of the plan (9.9 GB per 288
+// frames, 9.1 GB of them writes).  Both maps are linear and the bilinear sum is linear, so for level 0
+//
+//     sum_p a_p . bilinear(W x + c)(loc_p)  =  W_h . ( sum_p a_p . bilinear(x)(loc_p) )  +  c_h . sum_p a_p . (in-range corner weights)
+//
+// with x the level's own 128-channel tensor, W = value_proj o BN o input_proj composed on the host (the fold of round 4) and c its
+// bias (zero padding applies to the PROJECTED map, bias included: a corner outside the level contributes nothing, hence the weight
+// sum beside c).  The value planes of level 0 are never formed.
+//
+// One block = 16 queries (4 waves x 4).  Per query a wave
+//   * computes softmax / sampling locations with lane = head*8 + sub as `msda_planes_kernel` does and gathers levels 1.. from the
+//     head planes exactly as that kernel (two x-corners per 16-byte lane load) -> fp32 partial row in LDS;
+//   * gathers level 0 raw: for every (head, point) FOUR dword loads, one per corner -- 64 lanes x 4 bytes = the corner's 128 channels,
+//     the address a wave-uniform SCALAR offset (v_readlane of the head's lane) + lane*4, no vector address arithmetic; a lane owns two
+//     channels and sums its 16 taps per head in fp32 with scalar weights (no cross-lane reduction); corners outside the level are
+//     handled by clamping the 2x2 window into the level and re-dealing the weights to the slots that survive;
+//   * leaves g[head][128] (rounded to T: the MFMA operand) and the in-range weight sums in LDS.
+// Then wave w multiplies heads 2w, 2w+1: W_h[32 x 128] (A operand, from L2) x g[16 queries] (B operand) on v_mfma_f32_16x16x32, adds
+// c_h . s and the partial of the other levels, and stores the 16 x 64 output values it owns.
+#include "common.hpp"
+
+#include <type_traits>
+#include <utility>
+
+namespace moy {
+
+struct LevelInfoR {
+  int H[4], W[4], start[4];      // start[l] (l >= 1): first token of level l in the planes' own numbering (level 0 is not in them)
+};
+
+struct MsdaRawParams {
+  const void* x0;        // level 0, raw: [B, H0, W0, >= 128] channels-last, pixel pitch ld0 elements
+  int64_t ld0;
+  const void* wc;        // composed weights of this layer: T [256][128]
+  const float* bc;       // composed bias fp32 [256]
+  const void* planes;    // head planes of levels 1..: T [8][B * S1][32] (head_stride elements between heads)
+  int64_t head_stride;
+  int S1;                // tokens per frame in the planes
+  LevelInfoR lv;
+  int L;
+  const float* offaw;
+  int64_t ld_oa;
+  const float* ref;
+  int Lq, nrows;
+  int ngroups;           // ceil(nrows / 16)
+  void* out;
+  int64_t ldo;
+};
+
+template <typename T>
+__device__ __forceinline__ f32x4 mr_mfma(f32x4 acc, u32x4 w, u32x4 a);
+template <>
+__device__ __forceinline__ f32x4 mr_mfma<bf16_t>(f32x4 acc, u32x4 w, u32x4 a) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4 mr_mfma<f16_t>(f32x4 acc, u32x4 w, u32x4 a) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
+}
+
+#ifndef MOY_MR_DEPTH
+#define MOY_MR_DEPTH 1
+#endif
+constexpr int MR_QB = 16;                    // queries per block
+constexpr int MR_GP = 8 * 128 * 2 + 16;      // bytes per query row of g (+16: the 16 rows of a fragment read start 4 banks apart)
+constexpr int MR_PP = 256 * 4 + 16;          // bytes per query row of the other levels' partial (fp32)
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void msda_raw_kernel(const MsdaRawParams p) {
+  static_assert(sizeof(T) == 2, "16-bit values");
+  __shared__ __attribute__((aligned(16))) unsigned char sG[MR_QB * MR_GP];
+  __shared__ __attribute__((aligned(16))) unsigned char sP[MR_QB * MR_PP];
+  __shared__ float sS[MR_QB * 8];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // XCD-aware walk: workgroup i runs on XCD i % 8, and every XCD has its own L2 -- XCD x takes the x-th eighth of the query groups,
+  // in order, so that the few frames its resident blocks work on (a level-0 map is 2.6 MB at 1088x608) are re-read from ITS L2
+  const int nblk = (int)gridDim.x, chunk = (nblk + 7) >> 3;
+  const int lblk = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if (lblk >= p.ngroups) return;
+  const int row0 = lblk * MR_QB;
+  const int m = lane >> 3, sub = lane & 7, cx = sub >> 2, oct = sub & 3;
+  const int L = p.L, LP = L * 4;
+  const T* planes = static_cast<const T*>(p.planes);
+  const T* x0 = static_cast<const T*>(p.x0);
+  constexpr uint32_t OOB = 0x80000000u;
+  const int H0 = p.lv.H[0], W0 = p.lv.W[0];
+  const uint32_t pix_pitch = (uint32_t)(p.ld0 * 2), row_pitch = (uint32_t)(W0 * p.ld0 * 2);
+
+  for (int j = 0; j < 4; ++j) {
+    const int ql = wave * 4 + j;                                   // query of the block
+    const int row = min(row0 + ql, p.nrows - 1);                   // rows past the end recompute the last one (never stored)
+    const int b = __builtin_amdgcn_readfirstlane(row / p.Lq);
+    const float* oa = p.offaw + (long)row * p.ld_oa;
+    const float* offp = oa + m * LP * 2;
+    const float* awp = oa + 8 * LP * 2 + m * LP;
+    float logit[16], offx[16], offy[16];
+#pragma unroll
+    for (int i = 0; i < 16; i += 4)
+      if (i < LP) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(awp + i);
+        logit[i] = a.x; logit[i + 1] = a.y; logit[i + 2] = a.z; logit[i + 3] = a.w;
+        const f32x4 o0 = *reinterpret_cast<const f32x4*>(offp + 2 * i), o1 = *reinterpret_cast<const f32x4*>(offp + 2 * i + 4);
+        offx[i] = o0.x; offy[i] = o0.y; offx[i + 1] = o0.z; offy[i + 1] = o0.w;
+        offx[i + 2] = o1.x; offy[i + 2] = o1.y; offx[i + 3] = o1.z; offy[i + 3] = o1.w;
+      }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < LP) mx = fmaxf(mx, logit[i]);
+    float den = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < LP) { logit[i] = __builtin_amdgcn_exp2f((logit[i] - mx) * 1.4426950408889634f); den += logit[i]; }
+    const float inv_den = __builtin_amdgcn_rcpf(den);
+    const f32x4 rb = *reinterpret_cast<const f32x4*>(p.ref + (long)row * 4);
+
+    // ---- level 0, raw: per point the clamped 2x2 window (byte offset of its first pixel inside the frame) and the four slot weights
+    uint32_t base0[4];
+    float w00[4], w01[4], w10[4], w11[4];
+    float sw = 0.f;
+#pragma unroll
+    for (int pnt = 0; pnt < 4; ++pnt) {
+      // loc = ref_xy + off / n_points * ref_wh * 0.5   (transformer.py:280-282)
+      const float lx = rb.x + offx[pnt] / 4.0f * rb.z * 0.5f;
+      const float ly = rb.y + offy[pnt] / 4.0f * rb.w * 0.5f;
+      const float x = lx * W0 - 0.5f, y = ly * H0 - 0.5f;
+      const float aw = logit[pnt] * inv_den;
+      const float xf = floorf(x), yf = floorf(y);
+      const float fx = x - xf, fy = y - yf;
+      // (a sample far outside the level: clamp before the int conversion)
+      const int xi = (int)fminf(fmaxf(xf, -2.0f), (float)W0 + 1.0f), yi = (int)fminf(fmaxf(yf, -2.0f), (float)H0 + 1.0f);
+      const float ax0 = (unsigned)xi < (unsigned)W0 ? 1.f - fx : 0.f, ax1 = (unsigned)(xi + 1) < (unsigned)W0 ? fx : 0.f;
+      const float ay0 = (unsigned)yi < (unsigned)H0 ? 1.f - fy : 0.f, ay1 = (unsigned)(yi + 1) < (unsigned)H0 ? fy : 0.f;
+      const int xb = min(max(xi, 0), W0 - 2), yb = min(max(yi, 0), H0 - 2);
+      // slot s of the clamped window holds pixel xb + s: which real corner (if any) is that
+      const float sx0 = xi == xb ? ax0 : (xi + 1 == xb ? ax1 : 0.f), sx1 = xi == xb ? ax1 : (xi == xb + 1 ? ax0 : 0.f);
+      const float sy0 = yi == yb ? ay0 : (yi + 1 == yb ? ay1 : 0.f), sy1 = yi == yb ? ay1 : (yi == yb + 1 ? ay0 : 0.f);
+      base0[pnt] = (uint32_t)(yb * W0 + xb) * pix_pitch;
+      w00[pnt] = aw * sx0 * sy0; w01[pnt] = aw * sx1 * sy0; w10[pnt] = aw * sx0 * sy1; w11[pnt] = aw * sx1 * sy1;
+      sw += aw * (ax0 + ax1) * (ay0 + ay1);
+    }
+    if (sub == 0) sS[ql * 8 + m] = sw;
+
+    // ---- levels 1..: head planes, as msda_planes_kernel (one level's taps in flight)
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    {
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(planes + (int64_t)b * p.S1 * 32), 0, 0x80000000u, 0x00020000);
+      const uint32_t lane_off = (uint32_t)((m * p.head_stride + oct * 8) * 2);
+#pragma unroll
+      for (int l = 1; l < 4; ++l)
+        if (l < L) {
+          const int H = p.lv.H[l], W = p.lv.W[l];
+          u32x4 tap[4][2];
+          float wgt[4][2];
+#pragma unroll
+          for (int pnt = 0; pnt < 4; ++pnt) {
+            const int i = l * 4 + pnt;
+            const float lx = rb.x + offx[i] / 4.0f * rb.z * 0.5f;
+            const float ly = rb.y + offy[i] / 4.0f * rb.w * 0.5f;
+            const float x = lx * W - 0.5f, y = ly * H - 0.5f;
+            const float aw = logit[i] * inv_den;
+            const float xf = floorf(x), yf = floorf(y);
+            const float fx = x - xf, fy = y - yf;
+            const int xi = (int)xf + cx, y0 = (int)yf;
+            const float wx = (cx ? fx : 1.f - fx) * aw;
+            const bool xin = (unsigned)xi < (unsigned)W;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const int yi = y0 + t;
+              const bool ok = xin && (unsigned)yi < (unsigned)H;
+              const uint32_t off = lane_off + (uint32_t)((p.lv.start[l] + yi * W + xi) * 64);
+              tap[pnt][t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0));
+              wgt[pnt][t] = wx * (t ? fy : 1.f - fy);
+            }
+          }
+#pragma unroll
+          for (int pnt = 0; pnt < 4; ++pnt)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const u32x4 w = tap[pnt][t];
+              const float g = wgt[pnt][t];
+              acc[0] = DT<T>::fma_lo(w.x, g, acc[0]); acc[1] = DT<T>::fma_hi(w.x, g, acc[1]); acc[2] = DT<T>::fma_lo(w.y, g, acc[2]); acc[3] = DT<T>::fma_hi(w.y, g, acc[3]);
+              acc[4] = DT<T>::fma_lo(w.z, g, acc[4]); acc[5] = DT<T>::fma_hi(w.z, g, acc[5]); acc[6] = DT<T>::fma_lo(w.w, g, acc[6]); acc[7] = DT<T>::fma_hi(w.w, g, acc[7]);
+            }
+        }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], 4);
+      if (cx == 0) {
+        float* dst = reinterpret_cast<float*>(sP + ql * MR_PP) + m * 32 + oct * 8;
+        *reinterpret_cast<f32x4*>(dst) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+      }
+    }
+
+    // ---- level 0 gather: head by head, four corners x four points = 16 dword loads per head, scalar offsets and weights
+    {
+      const int64_t frame = (int64_t)H0 * W0 * p.ld0;
+      const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x0 + (int64_t)b * frame), 0, (uint32_t)(frame * 2), 0x00020000);
+      const uint32_t voff = (uint32_t)lane * 4u;
+      uint32_t* gdst = reinterpret_cast<uint32_t*>(sG + ql * MR_GP) + lane;
+      // two heads' taps in flight: head h+1 is requested before head h is summed (32 dword loads outstanding per wave)
+      constexpr int DEPTH = MOY_MR_DEPTH;                           // heads whose taps are in flight beside the one being summed
+      uint32_t tp[DEPTH + 1][4][4];
+      auto issue = [&](auto hc, uint32_t (&t)[4][4]) {
+        constexpr int h = decltype(hc)::value;
+#pragma unroll
+        for (int pnt = 0; pnt < 4; ++pnt) {
+          const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)base0[pnt], h * 8);
+          t[pnt][0] = __builtin_amdgcn_raw_buffer_load_b32(rs0, voff, sb, 0);
+          t[pnt][1] = __builtin_amdgcn_raw_buffer_load_b32(rs0, voff, sb + pix_pitch, 0);
+          t[pnt][2] = __builtin_amdgcn_raw_buffer_load_b32(rs0, voff, sb + row_pitch, 0);
+          t[pnt][3] = __builtin_amdgcn_raw_buffer_load_b32(rs0, voff, sb + row_pitch + pix_pitch, 0);
+        }
+      };
+      auto consume = [&](auto hc, const uint32_t (&t)[4][4]) {
+        constexpr int h = decltype(hc)::value;
+        float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+        for (int pnt = 0; pnt < 4; ++pnt) {
+          const float ws[4] = {__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w00[pnt]), h * 8)),
+                               __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w01[pnt]), h * 8)),
+                               __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w10[pnt]), h * 8)),
+                               __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w11[pnt]), h * 8))};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            g0 = DT<T>::fma_lo_s(t[pnt][c], ws[c], g0);
+            g1 = DT<T>::fma_hi_s(t[pnt][c], ws[c], g1);
+          }
+        }
+        gdst[h * 64] = DT<T>::pack2(g0, g1);                        // channels 2*lane, 2*lane + 1 of head h's gathered vector
+      };
+      [&]<int... Hs>(std::integer_sequence<int, Hs...>) { (issue(std::integral_constant<int, Hs>{}, tp[Hs]), ...); }
+      (std::make_integer_sequence<int, DEPTH>{});
+      [&]<int... Hs>(std::integer_sequence<int, Hs...>) {
+        (([&] {
+           if constexpr (Hs + DEPTH < 8) issue(std::integral_constant<int, Hs + DEPTH>{}, tp[(Hs + DEPTH) % (DEPTH + 1)]);
+           __builtin_amdgcn_sched_barrier(0);                       // keep the later heads' requests ahead of this head's sums
+           consume(std::integral_constant<int, Hs>{}, tp[Hs % (DEPTH + 1)]);
+         }()), ...);
+      }(std::make_integer_sequence<int, 8>{});
+    }
+  }
+  __syncthreads();
+
+  // ---- projection: wave w owns heads 2w, 2w+1.  A = W_h rows (out channel t*16 + r), B = g of the 16 queries (column r = query r)
+  const int r = lane & 15, q4 = lane >> 4;
+  const T* wc = static_cast<const T*>(p.wc);
+  T* out = static_cast<T*>(p.out);
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int h = wave * 2 + hh;
+    u32x4 wa[2][4], gb[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int pn = 0; pn < 4; ++pn)
+        wa[t][pn] = *reinterpret_cast<const u32x4*>(wc + (h * 32 + t * 16 + r) * 128 + pn * 32 + q4 * 8);
+#pragma unroll
+    for (int pn = 0; pn < 4; ++pn) gb[pn] = *reinterpret_cast<const u32x4*>(sG + r * MR_GP + h * 256 + pn * 64 + q4 * 16);
+    f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int pn = 0; pn < 4; ++pn)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc2[t] = mr_mfma<T>(acc2[t], wa[t][pn], gb[pn]);
+    const float s = sS[r * 8 + h];
+    const int row = row0 + r;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ch = h * 32 + t * 16 + q4 * 4;
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bc + ch);
+      const f32x4 part = *reinterpret_cast<const f32x4*>(sP + r * MR_PP + ch * 4);
+      const f32x4 v = acc2[t] + bias * s + part;
+      if (row < p.nrows) *reinterpret_cast<u32x2*>(out + (int64_t)row * p.ldo + ch) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+    }
+  }
+}
+
+}  // namespace moy
+
+using namespace moy;
+
+extern "C" int moy_msda_raw0(const moy_msda_raw_args* a, void* stream) {
+  if (!a || !a->x0 || !a->wc || !a->bc || !a->offaw || !a->ref || !a->out || !a->shapes_hw) return MOY_EINVAL;
+  if (a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_ENOSYS;          // 16-bit engines only (the fp32 engine keeps the classic plan)
+  if (a->B <= 0 || a->Lq <= 0 || a->L < 1 || a->L > 4) return MOY_EINVAL;
+  if (a->L > 1 && (!a->planes || a->S1 <= 0)) return MOY_EINVAL;
+  MsdaRawParams p{};
+  int s = 0;
+  for (int l = 0; l < a->L; ++l) {
+    p.lv.H[l] = a->shapes_hw[2 * l]; p.lv.W[l] = a->shapes_hw[2 * l + 1];
+    if (p.lv.H[l] <= 0 || p.lv.W[l] <= 0) return MOY_EINVAL;
+    if (l >= 1) { p.lv.start[l] = s; s += p.lv.H[l] * p.lv.W[l]; }
+  }
+  if (a->L > 1 && s != a->S1) return MOY_EINVAL;
+  if (p.lv.H[0] < 2 || p.lv.W[0] < 2) return MOY_ENOSYS;                        // the clamped 2x2 window needs two rows and two columns
+  if (a->ld0 < 128 || (a->ld0 % 2) || (reinterpret_cast<uintptr_t>(a->x0) % 4)) return MOY_EINVAL;
+  if ((int64_t)p.lv.H[0] * p.lv.W[0] * a->ld0 * 2 > 0x7fffffffLL) return MOY_ENOSYS;      // one frame of level 0 per buffer descriptor
+  if (a->L > 1 && (a->head_stride < 32 || (a->head_stride % 8) || a->head_stride * 8 * 2 > 0x7fffffffLL || !aligned16(a->planes))) return MOY_EINVAL;
+  if (a->ld_oa < 8 * a->L * 4 * 3 || (a->ld_oa % 4) || a->ldo < 256 || (a->ldo % 4) || !aligned16(a->ref) || !aligned16(a->offaw)) return MOY_EINVAL;
+  if (!aligned16(a->wc) || !aligned16(a->bc) || (reinterpret_cast<uintptr_t>(a->out) % 8)) return MOY_EINVAL;
+  p.x0 = a->x0; p.ld0 = a->ld0; p.wc = a->wc; p.bc = a->bc; p.planes = a->planes; p.head_stride = a->head_stride; p.S1 = a->S1;
+  p.L = a->L; p.offaw = a->offaw; p.ld_oa = a->ld_oa; p.ref = a->ref; p.Lq = a->Lq; p.nrows = a->B * a->Lq; p.out = a->out; p.ldo = a->ldo;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  p.ngroups = (p.nrows + MR_QB - 1) / MR_QB;
+  const int nblk = (p.ngroups + 7) / 8 * 8;          // a multiple of the 8 XCDs: XCD x walks the x-th eighth of the groups
+  if (a->dtype == MOY_BF16) hipLaunchKernelGGL((msda_raw_kernel<bf16_t>), dim3(nblk), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((msda_raw_kernel<f16_t>), dim3(nblk), dim3(256), 0, st, p);
+  return launch_status();
+}

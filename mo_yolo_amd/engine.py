@@ -526,11 +526,20 @@ class TrackEngine:
         # ... written as ndl contiguous [B*S, hd] planes: a layer's slice is dense in HBM for its deformable gather
         vmode = os.environ.get("MOY_VALUE_PLANES", "2")
         dh = hd // arch.nh
+        # Round 5: level 0 (P3) of the deformable attention gathered RAW and projected after the bilinear sum (csrc/msda_raw.hip): its
+        # value planes -- the longest launch of the plan, 54 % of whose output no sample touches -- are never formed.  Folded head only
+        # (the composed weights are the fold's); MOY_P3_RAW=0 keeps the planes of all levels.
+        self.p3raw = None
+        self.value_tokens = S                  # tokens per frame in the value planes
+        if (fold is not None and vmode == "2" and os.environ.get("MOY_P3_RAW", "1") != "0" and nl >= 2 and arch.head_ch[0] == 128
+                and min(self.shapes[0]) >= 2 and self.shapes[0][0] * self.shapes[0][1] * head_src[0][0].ld * 2 <= 0x7fffffff):
+            self.value_tokens = S - self.shapes[0][0] * self.shapes[0][1]
         if vmode == "2":
             # [layer][head][token][32]: a head's map is a dense [B*S, 32] matrix, so the two x-taps of a bilinear sample are
             # 128 contiguous bytes and the GEMM's stores are contiguous runs
-            self.value_planes = self._buf(ndl * arch.nh * B * S, dh)
-            value = [(View(self.value_planes[i * arch.nh * B * S:(i * arch.nh + 1) * B * S]), B * S * dh) for i in range(ndl)]
+            Sv = self.value_tokens
+            self.value_planes = self._buf(ndl * arch.nh * B * Sv, dh)
+            value = [(View(self.value_planes[i * arch.nh * B * Sv:(i * arch.nh + 1) * B * Sv]), B * Sv * dh) for i in range(ndl)]
             if fold is None:
                 self._gemm(feats, self._weight(Wv), ndl * hd, hd, value[0][0], B * S, shift=self._dev(bv), planes=(dh, B * S * dh))
                 self._value_launches.append((self._steps[-1][1][0]._obj, S))
@@ -541,8 +550,13 @@ class TrackEngine:
                 for li, ((src_view, _), (h_, w_)) in enumerate(zip(head_src, self.shapes)):
                     Wc = (Wv.double() @ fold["sWp"][li]).float()
                     bc = (Wv.double() @ fold["t"][li] + bv.double()).float()
+                    if li == 0 and Sv != S:
+                        # level 0 is sampled raw: its composed weights [ndl * 256, 128] / biases go to the gather, layer by layer
+                        self.p3raw = dict(view=src_view, wc=self._weight(Wc), bc=self._dev(bc))
+                        assert self.p3raw["wc"].shape == (ndl * hd, 128)
+                        continue
                     self._gemm(src_view, self._weight(Wc), ndl * hd, arch.head_ch[li], View(self.value_planes[off:]), B * h_ * w_,
-                               shift=self._dev(bc), planes=(dh, B * S * dh), c_rpb=h_ * w_, c_bstride=S)
+                               shift=self._dev(bc), planes=(dh, B * Sv * dh), c_rpb=h_ * w_, c_bstride=Sv)
                     self._value_launches.append((self._steps[-1][1][0]._obj, h_ * w_))
                     if li == 0:
                         self._value_p3_step = len(self._steps) - 1
@@ -759,13 +773,33 @@ class TrackEngine:
             # DISTINCT cells under uniform sampling, cells x (1 - exp(-taps / cells)) -- 1.31 GB per launch at 288 frames against
             # 1.20 GB measured by PMC (round 2 charged 2.15 GB and the launch table showed a fraction > 1)
             import math
-            cells = B * S * arch.nh
-            ntaps = M * arch.nh * nl * arch.ndp * 4
-            touched = int(cells * (1.0 - math.exp(-ntaps / cells))) * (hd // arch.nh) * self._esz
-            self._add(lib.moy_msda_fused, vslice.ptr, vslice.ld, vhs, B, S, shapes_c, nl, offaw.data_ptr(), offaw.shape[1],
-                      refs[cur].data_ptr(), Lq, samp.ptr, samp.ld, code,
-                      meta=dict(name=f"msda_fused M{M}", bytes=touched + M * (offaw.shape[1] * 4 + 16 + hd * self._esz),
-                                flops=2 * M * arch.nh * nl * arch.ndp * 4 * (hd // arch.nh)))
+            if self.p3raw is not None:
+                # levels 1..: distinct 64-byte head cells as before; level 0: distinct 256-byte PIXELS of the raw map (every head's taps
+                # read whole pixels) + the layer's composed weights once
+                hw0 = self.shapes[0][0] * self.shapes[0][1]
+                cells1, taps1 = B * self.value_tokens * arch.nh, M * arch.nh * (nl - 1) * arch.ndp * 4
+                cells0, taps0 = B * hw0, M * arch.nh * arch.ndp * 4
+                touched = (int(cells1 * (1.0 - math.exp(-taps1 / cells1))) * dh + int(cells0 * (1.0 - math.exp(-taps0 / cells0))) * 128) * self._esz
+                t = L.MsdaRawArgs()
+                pv = self.p3raw["view"]
+                t.x0, t.ld0 = pv.ptr, pv.ld
+                t.wc = self.p3raw["wc"].data_ptr() + i * hd * 128 * self._esz
+                t.bc = self.p3raw["bc"].data_ptr() + i * hd * 4
+                t.planes, t.head_stride, t.S1 = vslice.ptr, vhs, self.value_tokens
+                t.B, t.Lq, t.L, t.shapes_hw = B, Lq, nl, C.cast(shapes_c, C.c_void_p)
+                t.offaw, t.ld_oa, t.ref, t.out, t.ldo, t.dtype = offaw.data_ptr(), offaw.shape[1], refs[cur].data_ptr(), samp.ptr, samp.ld, code
+                self._keep.append(t)
+                self._add(lib.moy_msda_raw0, C.byref(t),
+                          meta=dict(name=f"msda_raw0 M{M}", bytes=touched + hd * 128 * self._esz + M * (offaw.shape[1] * 4 + 16 + hd * self._esz),
+                                    flops=2 * M * arch.nh * nl * arch.ndp * 4 * dh + 2 * M * hd * 128 + 2 * M * arch.nh * arch.ndp * 4 * (128 - dh)))
+            else:
+                cells = B * S * arch.nh
+                ntaps = M * arch.nh * nl * arch.ndp * 4
+                touched = int(cells * (1.0 - math.exp(-ntaps / cells))) * (hd // arch.nh) * self._esz
+                self._add(lib.moy_msda_fused, vslice.ptr, vslice.ld, vhs, B, S, shapes_c, nl, offaw.data_ptr(), offaw.shape[1],
+                          refs[cur].data_ptr(), Lq, samp.ptr, samp.ld, code,
+                          meta=dict(name=f"msda_fused M{M}", bytes=touched + M * (offaw.shape[1] * 4 + 16 + hd * self._esz),
+                                    flops=2 * M * arch.nh * nl * arch.ndp * 4 * (hd // arch.nh)))
             Wp, bp = self._linear_w(q + ".cross_attn.output_proj")
             W1, b1 = self._linear_w(q + ".linear1")
             W2, b2 = self._linear_w(q + ".linear2")

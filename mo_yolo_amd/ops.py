@@ -310,6 +310,26 @@ def msda_fused(value, B, S, shapes, offaw, ref, Lq, head_planes=False):
     return out
 
 
+def msda_raw0(x0, wc, bc, planes, B, shapes, offaw, ref, Lq):
+    """moy_msda_raw0: level 0 gathered raw from x0 [B*H0*W0, >= 128] (channel-slice view) and projected with wc [256, 128] / bc [256]
+    after the bilinear sum; levels 1.. from head planes [8, B*S1, 32] (None when there is one level)."""
+    _need_gpu(x0, wc, bc, offaw, ref)
+    nl = len(shapes)
+    a = L.MsdaRawArgs()
+    sh = (C.c_int32 * (2 * nl))(*[int(v) for hw in shapes for v in hw])
+    S1 = sum(h * w for h, w in shapes[1:])
+    out = torch.empty(B * Lq, 256, device=x0.device, dtype=x0.dtype)
+    a.x0, a.ld0, a.wc, a.bc = x0.data_ptr(), _ld(x0), wc.data_ptr(), bc.data_ptr()
+    if planes is not None:
+        assert planes.is_contiguous() and tuple(planes.shape) == (8, B * S1, 32) and planes.dtype == x0.dtype
+        a.planes, a.head_stride = planes.data_ptr(), B * S1 * 32
+    a.S1, a.B, a.Lq, a.L, a.shapes_hw = S1, B, Lq, nl, C.cast(sh, C.c_void_p)
+    a.offaw, a.ld_oa, a.ref, a.out, a.ldo, a.dtype = offaw.data_ptr(), _ld(offaw), ref.data_ptr(), out.data_ptr(), 256, _code(x0)
+    assert wc.is_contiguous() and tuple(wc.shape) == (256, 128) and wc.dtype == x0.dtype and bc.dtype == torch.float32
+    L.check(L.lib().moy_msda_raw0(C.byref(a), _st()), "moy_msda_raw0")
+    return out
+
+
 def _msda_check(tensors, value, im2col_step):
     for t in tensors:
         if not t.is_cuda:

@@ -240,7 +240,7 @@ def value_planes_vs_tiled(eng, n_frames: int | None = None):
     launches = getattr(eng, "_value_launches", None)
     if not launches or getattr(eng, "value_planes", None) is None or os.environ.get("MOY_VALUE_PLANES", "2") != "2":
         return dict(equal=True, skipped="no head-plane value launches in this plan")
-    arch, B, S = eng.arch, eng.B, eng.S
+    arch, B, S = eng.arch, eng.B, getattr(eng, "value_tokens", eng.S)      # (tokens per frame IN THE PLANES: without level 0 when it is sampled raw)
     P, dh = arch.ndl * arch.nh, arch.hd // arch.nh
     rows_max = max(r for _, r in launches)
     n = n_frames or max(1, min(4, B, 60000 // rows_max))

@@ -890,6 +890,45 @@ def test_msda_fused_vs_oracle(dt):
         assert float(((y2.float() - y.float()).abs() / y.float().abs().clamp_min(0.05)).max()) <= 2 * ulp
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Lq,shapes,ld0", [(2, 37, [(12, 20), (6, 10), (3, 5)], 128), (3, 300, [(76, 136), (38, 68), (19, 34)], 128),
+                                            (1, 21, [(9, 7)], 192), (2, 50, [(2, 2), (4, 4)], 136)])
+def test_msda_raw_level0_gather_then_project_vs_oracle(dt, B, Lq, shapes, ld0):
+    """Round 5: level 0 of the deformable attention gathered RAW and projected after the bilinear sum (csrc/msda_raw.hip):
+    W_h . (sum_p a_p bilinear(x)(loc_p)) + c_h . sum_p a_p (in-range corner weights) == sum_p a_p bilinear(W x + c)(loc_p)
+    (transformer.py:255-287 over nn/modules/utils.py:41-78, zero padding of the PROJECTED map).  Against the oracle's sampling core on
+    the explicitly projected level-0 map (fp32 product of the same 16-bit operands) + the given planes of the other levels; offsets large
+    enough that samples leave the level on every side, a box in a corner, one level only, a level of 2 x 2, level 0 as a channel slice."""
+    H0, W0 = shapes[0]
+    S1 = sum(h * w for h, w in shapes[1:])
+    nl = len(shapes)
+    x = q(rnd(B * H0 * W0, 128, seed=1), dt)
+    wc, bc = q(rnd(256, 128, seed=2, scale=1 / math.sqrt(128)), dt), rnd(256, seed=3, scale=0.5)
+    v1 = q(rnd(B, max(S1, 1), 256, seed=4), dt)
+    offaw = torch.cat([rnd(B * Lq, 8 * nl * 8, seed=5, scale=6.0), rnd(B * Lq, 8 * nl * 4, seed=6, scale=2.0)], 1)
+    ref_box = torch.rand(B * Lq, 4, generator=torch.Generator().manual_seed(7))
+    ref_box[:, 2:] = ref_box[:, 2:] * 0.5 + 0.05
+    ref_box[0, :2] = torch.tensor([0.01, 0.99])               # taps fall outside: zero padding (bias included)
+    ref_box[1, :2] = torch.tensor([0.995, 0.002])
+    xbuf = torch.zeros(B * H0 * W0, ld0, device=DEV, dtype=dt)
+    xbuf[:, :128] = x.to(DEV, dt)
+    planes = v1.view(B * S1, 8, 32).permute(1, 0, 2).contiguous().to(DEV, dt) if S1 else None
+    y = ops.msda_raw0(xbuf[:, :128], wc.to(DEV, dt).contiguous(), bc.to(DEV), planes, B, shapes, offaw.to(DEV), ref_box.to(DEV), Lq)
+    torch.cuda.synchronize()
+    v0 = (x @ wc.T + bc).view(B, H0 * W0, 256)
+    value = torch.cat([v0, v1[:, :S1]], 1) if S1 else v0
+    off = offaw[:, :8 * nl * 8].view(B, Lq, 8, nl, 4, 2)
+    aw = torch.softmax(offaw[:, 8 * nl * 8:].view(B, Lq, 8, nl * 4), -1).view(B, Lq, 8, nl, 4)
+    rb = ref_box.view(B, Lq, 1, 1, 1, 4)
+    loc = rb[..., :2] + off / 4 * rb[..., 2:] * 0.5
+    want = O.msda_core(value.view(B, -1, 8, 32), shapes, loc, aw).view(B * Lq, 256)
+    # one rounding of the gathered vector to T before its product (|g| <= 1, 128 terms of |w| ~ 0.09) + the output rounding
+    assert torch.allclose(y.float().cpu(), want, atol=tol(dt, 2e-5, 1.5e-2), rtol=tol(dt, 1e-5, 1e-2)), float((y.float().cpu() - want).abs().max())
+    with pytest.raises(L.MoyoloError):          # fp32: refused (the exact engine keeps the projected planes)
+        ops.msda_raw0(xbuf[:, :128].float().contiguous(), wc.to(DEV).contiguous(), bc.to(DEV), planes.float() if planes is not None else None,
+                      B, shapes, offaw.to(DEV), ref_box.to(DEV), Lq)
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_ms_deform_attn_forward_kats(dt):
     """The reference operator API on its own KAT construction (MOTR/models/ops/test.py:21-30),
