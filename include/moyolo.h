@@ -27,6 +27,11 @@ extern "C" {
 #define MOY_F32 0
 #define MOY_BF16 1
 #define MOY_F16 2
+/* moy_gemm only (round 5): fp32 tensors exactly as MOY_F32 (A, W, R, C are float), but the products run on the 16-bit matrix
+ * cores in SPLIT precision -- every operand x = hi + lo * 2^-11 with hi = fp16(x), lo = fp16((x - hi) * 2^11), three products
+ * hi.hi, hi.lo, lo.hi (v_mfma_f32_16x16x32_f16, fp32 accumulation in two accumulator sets combined at the end); lo.lo is dropped:
+ * about 22 mantissa bits per product at 16/3 of the fp32 matrix rate.  Operands must be finite and below 65504 in magnitude. */
+#define MOY_F32X3 3
 
 #define MOY_OK 0
 #define MOY_EINVAL (-22)   /* bad shape / argument */

@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOYOLO_LIB") or os.path.join(HERE, "libmoyolo.so")   # override: A/B runs of two builds on one device
 
 F32, BF16, F16 = 0, 1, 2
+F32X3 = 3        # moy_gemm only: fp32 tensors, split-fp16 matrix arithmetic (include/moyolo.h: MOY_F32X3)
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float

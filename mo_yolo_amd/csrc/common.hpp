@@ -53,6 +53,25 @@ struct DT<double> {   // operator-API entries only (the reference's native op di
   static __device__ __forceinline__ double load1(const double* p) { return *p; }
   static __device__ __forceinline__ void store1(double* p, double v) { *p = v; }
 };
+// MOY_F32X3 (moy_gemm): fp32 in memory, split-fp16 matrix arithmetic -- a tag type, laid out and loaded like float
+struct f32x3_t {
+  float v;
+};
+template <>
+struct DT<f32x3_t> {
+  static constexpr int KPB = 4;
+  static constexpr int code = MOY_F32X3;
+  static __device__ __forceinline__ f32x4 load4(const f32x3_t* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void store4(f32x3_t* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+  static __device__ __forceinline__ float load1(const f32x3_t* p) { return p->v; }
+  static __device__ __forceinline__ void store1(f32x3_t* p, float v) { p->v = v; }
+};
+template <typename T>
+struct is_f32 { static constexpr bool value = false; };
+template <>
+struct is_f32<float> { static constexpr bool value = true; };
+template <>
+struct is_f32<f32x3_t> { static constexpr bool value = true; };
 template <typename T>
 struct AccOf { typedef float type; };
 template <>

@@ -83,6 +83,8 @@ __device__ __forceinline__ u32x4 add_chunks16(u32x4 a, u32x4 b) {
   return r;
 }
 template <>
+__device__ __forceinline__ u32x4 add_chunks<f32x3_t>(u32x4 a, u32x4 b) { return add_chunks<float>(a, b); }
+template <>
 __device__ __forceinline__ u32x4 add_chunks<bf16_t>(u32x4 a, u32x4 b) { return add_chunks16<bf16_t>(a, b); }
 template <>
 __device__ __forceinline__ u32x4 add_chunks<f16_t>(u32x4 a, u32x4 b) { return add_chunks16<f16_t>(a, b); }
@@ -107,6 +109,22 @@ __device__ __forceinline__ void mma_panel<float>(f32x4& acc, u32x4 wfrag, u32x4 
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, a.y, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, a.z, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, a.w, acc, 0, 0, 0);
+}
+
+template <>
+__device__ __forceinline__ void mma_panel<f32x3_t>(f32x4& acc, u32x4 wfrag, u32x4 afrag) {}   // (the split form multiplies in compute_stage)
+
+// MOY_F32X3: a 16-byte chunk of four fp32 values -> their fp16 heads and the fp16 of the scaled remainders (x = hi + lo * 2^-11).
+// x - float(hi) is exact in fp32 (hi is within half an fp16 ulp of x), so nothing is lost before the second conversion.
+__device__ __forceinline__ void split_f16x3(u32x4 c, u32x2& hi, u32x2& lo) {
+  typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+  const f32x4 x = __builtin_bit_cast(f32x4, c);
+  const h2_ h01 = __builtin_convertvector(f32x2_{x.x, x.y}, h2_), h23 = __builtin_convertvector(f32x2_{x.z, x.w}, h2_);
+  const f32x2_ b01 = __builtin_convertvector(h01, f32x2_), b23 = __builtin_convertvector(h23, f32x2_);
+  const h2_ l01 = __builtin_convertvector(f32x2_{(x.x - b01.x) * 2048.0f, (x.y - b01.y) * 2048.0f}, h2_);
+  const h2_ l23 = __builtin_convertvector(f32x2_{(x.z - b23.x) * 2048.0f, (x.w - b23.y) * 2048.0f}, h2_);
+  hi = u32x2{__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23)};
+  lo = u32x2{__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23)};
 }
 
 template <int BM, int BN>
@@ -159,7 +177,7 @@ __device__ __forceinline__ void stage_acc_act(const GemmParams& p, f32x4 (&acc)[
         // the tile goes to LDS already rounded to the output type: half the ds_write traffic (the VGPR->LDS path, ~80 B/clk
         // per CU, is the scarcest resource of the kernel) and no conversion in the output pass.  Row stride BN + 4 halves:
         // the 16 rows of a ds_write_b64 lane group fall on 16 distinct bank pairs.
-        if constexpr (!std::is_same<T, float>::value) {
+        if constexpr (!is_f32<T>::value) {
           unsigned char* ch = reinterpret_cast<unsigned char*>(Cs) + ((size_t)ml * (BN + 4) + nl) * 2;
           *reinterpret_cast<u32x2*>(ch) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
         }
@@ -324,6 +342,10 @@ __device__ __forceinline__ void gemm_epilogue_half(const GemmParams& p, const fl
 // wait placement degrade for both (measured).
 template <typename T, int BM, int BN, int WGM, int WGN, bool LN, int KS, int NSET>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p) {
+  // X3 (MOY_F32X3): the tensors are fp32 and staged exactly as in the fp32 kernel (32 k per stage: 128 bytes of a row), but a stage's
+  // LDS image is TWO fp16 panels of 64 bytes per row -- panel 0 the heads, panel 1 the scaled remainders of the same 32 k -- and a stage
+  // is ONE k step of v_mfma_f32_16x16x32_f16, three products per output sub-tile (hi.hi into acc; hi.lo, lo.hi into accx)
+  constexpr bool X3 = std::is_same<T, f32x3_t>::value;
   constexpr int KPB = DT<T>::KPB;      // elements per 16-B chunk
   constexpr int BKP = 4 * KPB;         // elements per 64-B panel
   constexpr int BK = BKP * PANELS;     // elements per stage
@@ -468,6 +490,28 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
     constexpr int SET = decltype(set_c)::value;
     unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
     unsigned char* Bs = As + A_BYTES;
+    if constexpr (X3) {
+      // this thread's chunk = k (spn*16 + sq*4 .. +3) of its row: 8 bytes of fp16 heads at k*2 inside the row's 64-byte head panel
+      // (16-byte column k/8 = spn*2 + (sq >> 1), swizzled as the 16-bit kernels swizzle it; half (sq & 1)), same place in the lo panel
+      const int c16 = spn * 2 + (sq >> 1), hb = (sq & 1) * 8;
+#pragma unroll
+      for (int j = 0; j < RA2; ++j) {
+        const int row = srow + j * RPP;
+        u32x2 hi, lo;
+        split_f16x3(areg[SET][j], hi, lo);
+        *reinterpret_cast<u32x2*>(As + row * 64 + swz(row, c16) * 16 + hb) = hi;
+        *reinterpret_cast<u32x2*>(As + (BM + (row ^ SKEW)) * 64 + swz(row, c16) * 16 + hb) = lo;
+      }
+#pragma unroll
+      for (int j = 0; j < RB2; ++j) {
+        const int row = srow + j * RPP;
+        u32x2 hi, lo;
+        split_f16x3(breg[SET][j], hi, lo);
+        *reinterpret_cast<u32x2*>(Bs + row * 64 + swz(row, c16) * 16 + hb) = hi;
+        *reinterpret_cast<u32x2*>(Bs + (BN + (row ^ SKEW)) * 64 + swz(row, c16) * 16 + hb) = lo;
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < RA2; ++j) {
       const int row = srow + j * RPP;
@@ -481,10 +525,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
   };
 
   f32x4 acc[MT][NT];
+  f32x4 accx[X3 ? MT : 1][X3 ? NT : 1];        // X3: the cross products hi.lo + lo.hi, in units of 2^-11
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (X3) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) accx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   if (p.pre) {   // wave-uniform; the loads are in flight under the first staging loads
 #pragma unroll
@@ -506,6 +557,30 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
   auto compute_stage = [&](int buf) {
     const unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
     const unsigned char* Bs = As + A_BYTES;
+    if constexpr (X3) {
+      u32x4 ah[MT], al[MT], wh[NT], wl[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = wm * TM + i * 16 + r;
+        ah[i] = *reinterpret_cast<const u32x4*>(As + row * 64 + swz(row, q) * 16);
+        al[i] = *reinterpret_cast<const u32x4*>(As + (BM + (row ^ SKEW)) * 64 + swz(row, q) * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int row = wn * TN + j * 16 + r;
+        wh[j] = *reinterpret_cast<const u32x4*>(Bs + row * 64 + swz(row, q) * 16);
+        wl[j] = *reinterpret_cast<const u32x4*>(Bs + (BN + (row ^ SKEW)) * 64 + swz(row, q) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          mma_panel<f16_t>(acc[i][j], wh[j], ah[i]);
+          mma_panel<f16_t>(accx[i][j], wh[j], al[i]);
+          mma_panel<f16_t>(accx[i][j], wl[j], ah[i]);
+        }
+      return;
+    }
 #pragma unroll
     for (int pn = 0; pn < PANELS; ++pn) {
       u32x4 af[MT], wf[NT];
@@ -574,9 +649,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
     __syncthreads();
   }
 
+  if constexpr (X3) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] += accx[i][j] * (1.0f / 2048.0f);
+  }
   // ---- epilogue: accumulators -> LDS tile [BM][BN+4] (fp32, or the output type when nothing else is added)
   float* Cs = reinterpret_cast<float*>(smem);
-  if constexpr (!LN && !std::is_same<T, float>::value) {
+  if constexpr (!LN && !is_f32<T>::value) {
     if (p.wide_store) {
       if (!p.R) {
         stage_acc<T, true, BN, TM, TN, MT, NT>(p, acc, Cs, n0, wm, wn, r, q);
@@ -958,9 +1039,10 @@ extern "C" int moy_set_cu_limit(int n_cus) {
 extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->W) return MOY_EINVAL;
   if (!a->C && !(a->ln_g && a->dot_n > 0 && a->dot_out)) return MOY_EINVAL;   // rows may be dropped only when the fused head is the output
-  if (a->dtype != MOY_F32 && a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_EINVAL;
-  const int kpb = a->dtype == MOY_F32 ? 4 : 8;
-  const int esz = a->dtype == MOY_F32 ? 4 : 2;
+  if (a->dtype != MOY_F32 && a->dtype != MOY_BF16 && a->dtype != MOY_F16 && a->dtype != MOY_F32X3) return MOY_EINVAL;
+  const bool is32 = a->dtype == MOY_F32 || a->dtype == MOY_F32X3;      // fp32 tensors (MOY_F32X3: split-fp16 matrix arithmetic)
+  const int kpb = is32 ? 4 : 8;
+  const int esz = is32 ? 4 : 2;
   const int bk = 4 * kpb * PANELS;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return MOY_EINVAL;
   if (a->N % 4) return MOY_EINVAL;
@@ -1015,7 +1097,7 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
   p.a2_cols = a->a2_cols ? a->a2_cols : 0x7fffffff;
   if (a->plane_cols < 0 || (a->plane_cols % 32) || (a->plane_cols && (a->ksize != 1 || a->plane_stride <= 0))) return MOY_EINVAL;
   p.plane_cols = a->plane_cols; p.plane_stride = a->plane_stride;
-  p.wide_store = a->dtype != MOY_F32 && !a->out_f32 && !ln && a->N % 8 == 0 && (a->ldc % 8) == 0 && aligned16(a->C) &&
+  p.wide_store = !is32 && !a->out_f32 && !ln && a->N % 8 == 0 && (a->ldc % 8) == 0 && aligned16(a->C) &&
                  (!a->R || ((a->ldr % 8) == 0 && aligned16(a->R)));
   if (a->ksize == 1) {
     if (a->K % kpb) return MOY_EINVAL;
@@ -1036,22 +1118,22 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
   // section 4): an LDS-DMA ring (global_load_lds, 1-2 blocks/CU), weights-resident-in-LDS with
   // activations straight to registers (16 rows x 64 B request shape), prefetch distance 2, a persistent
   // tile loop, a direct-from-register epilogue.  They are not kept in the tree.
-  if (a->post_W && (a->ksize != 3 || a->dtype == MOY_F32 || ln || a->post_n <= 0)) return MOY_ENOSYS;   // (never ignored)
-  if (a->ksize == 1 && a->dtype != MOY_F32) {
+  if (a->post_W && (a->ksize != 3 || is32 || ln || a->post_n <= 0)) return MOY_ENOSYS;   // (never ignored)
+  if (a->ksize == 1 && !is32) {
     const int rc = gemm_wreg_try(a, st);
     if (rc != MOY_ENOSYS) return rc;
   }
   if (a->run_levels) return MOY_ENOSYS;      // row runs exist in the weight-stationary score kernel only: the caller falls back to a_mask
-  if (a->ksize == 3 && a->dtype != MOY_F32 && !ln) {
+  if (a->ksize == 3 && !is32 && !ln) {
     const int rc = conv_ws_try(a, st);
     if (rc != MOY_ENOSYS) return rc;
   }
   if (a->post_W) return MOY_ENOSYS;          // the folded 1x1 consumer exists in the stride-2 weight-stationary kernel only: the caller launches it separately
-  if (a->dtype != MOY_F32 && !ln) {          // deep K, N % 128 == 0, enough tiles: 256-row tiles through an LDS-DMA pipeline (gemm_dma.hip)
+  if (!is32 && !ln) {          // deep K, N % 128 == 0, enough tiles: 256-row tiles through an LDS-DMA pipeline (gemm_dma.hip)
     const int rc = gemm_dma_try(a, st);
     if (rc != MOY_ENOSYS) return rc;
   }
-  if (a->ksize == 3 && a->dtype != MOY_F32) {
+  if (a->ksize == 3 && !is32) {
     const int rc = a->dtype == MOY_BF16 ? try_conv_direct<bf16_t>(p, a->B, ln, st) : try_conv_direct<f16_t>(p, a->B, ln, st);
     if (rc != MOY_ENOSYS) return rc;
   }
@@ -1059,5 +1141,7 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
     return a->ksize == 1 ? dispatch_tile<bf16_t, 1>(p, ln, st) : dispatch_tile<bf16_t, 3>(p, ln, st);
   if (a->dtype == MOY_F16)
     return a->ksize == 1 ? dispatch_tile<f16_t, 1>(p, ln, st) : dispatch_tile<f16_t, 3>(p, ln, st);
+  if (a->dtype == MOY_F32X3)
+    return a->ksize == 1 ? dispatch_tile<f32x3_t, 1>(p, ln, st) : dispatch_tile<f32x3_t, 3>(p, ln, st);
   return a->ksize == 1 ? dispatch_tile<float, 1>(p, ln, st) : dispatch_tile<float, 3>(p, ln, st);
 }

@@ -62,12 +62,20 @@ class TrackEngine:
                  dtype: torch.dtype = torch.float32, device="cuda", input_format: str = "u8", conf: float = 0.25,
                  score_thresh: float = 0.4, scale_boxes: bool = True, head_only: bool = False,
                  level_shapes_override=None, side_state: bool = False, iou: float = 0.7, max_det: int = 300, orig_hw=None,
-                 temporal: int = 0, filter_score_thresh: float = 0.5, miss_tolerance: int = 5, n_inputs: int = 1):
+                 temporal: int = 0, filter_score_thresh: float = 0.5, miss_tolerance: int = 5, n_inputs: int = 1,
+                 split_f16: bool = False):
         if not torch.cuda.is_available():
             raise L.MoyoloError("TrackEngine needs a HIP device (no CPU path)")
         self.lib = L.lib()
         self.arch, self.H, self.W, self.B = arch, H, W, batch
         self.dtype, self.code, self.dev = dtype, _code(dtype), torch.device(device)
+        # split_f16 (fp32 engines, round 5): every product of `moy_gemm` on the 16-bit matrix cores in split precision (MOY_F32X3:
+        # x = hi + lo * 2^-11, three fp16 products, fp32 accumulation -- about 22 mantissa bits at 16/3 of the fp32 matrix rate);
+        # tensors, the other kernels and the plan stay those of the fp32 engine
+        if split_f16 and dtype != torch.float32:
+            raise ValueError("split_f16 is a mode of the fp32 engine")
+        self.split_f16 = bool(split_f16)
+        self.code_gemm = L.F32X3 if split_f16 else self.code
         self._esz = 4 if dtype == torch.float32 else 2
         self.input_format = input_format
         self.conf, self.score_thresh = conf, score_thresh
@@ -175,7 +183,7 @@ class TrackEngine:
             a.ln_g, a.ln_b = ln[0].data_ptr(), ln[1].data_ptr()
         if C_ is not None:
             a.C, a.ldc = C_.ptr, C_.ld
-        a.out_f32, a.dtype = int(out_f32), self.code
+        a.out_f32, a.dtype = int(out_f32), self.code_gemm
         a.c_rows_per_batch, a.c_batch_stride = c_rpb, c_bstride
         if dot is not None:
             a.dot_w, a.dot_b, a.dot_out, a.dot_n = dot[0].data_ptr(), dot[1].data_ptr(), dot[2].data_ptr(), dot[0].shape[0]

@@ -47,7 +47,7 @@ def pad_weight(w2d: torch.Tensor, dtype) -> torch.Tensor:
 
 def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shift=None, act=L.ACT_NONE, A2=None,
          a_rows=None, a_mask=None, mask_period=0, R=None, ln=None, out_f32=False, M=None, c_rpb=0, c_bstride=0,
-         dot=None, store=True, pre=None, a2_cols=0, planes=None, runs=None, dot_out=None, post=None):
+         dot=None, store=True, pre=None, a2_cols=0, planes=None, runs=None, dot_out=None, post=None, split_f16=False):
     """See moy_gemm.  store=False (with dot): C = NULL, only the fused head's output is produced (returned as (None, dot_out)).
     A: 2-D row-major view [rows, >=Cin] (channels-last pixels or tokens)."""
     _need_gpu(A, Wp)
@@ -109,6 +109,9 @@ def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shi
         if dot_out is None:
             dot_out = torch.empty(M, dw.shape[0], device=A.device, dtype=torch.float32)
         a.dot_w, a.dot_b, a.dot_out, a.dot_n = dw.data_ptr(), db.data_ptr(), dot_out.data_ptr(), dw.shape[0]
+    if split_f16:           # MOY_F32X3: fp32 tensors, split-fp16 matrix arithmetic
+        assert A.dtype == torch.float32
+        a.dtype = L.F32X3
     L.check(L.lib().moy_gemm(C.byref(a), _st()), "moy_gemm")
     return out if dot is None else (out, dot_out)
 

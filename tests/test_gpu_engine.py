@@ -118,7 +118,7 @@ def test_engine_fp32_vs_reference_goldens_stream(name):
             assert np.array_equal(out["track_id"][t, :k].cpu().numpy(), g[f"post.{t}.track_id"].reshape(-1))
 
 
-def _direct_vs_golden(name, B):
+def _direct_vs_golden(name, B, **ekw):
     """Free-running fp32 engine (its own top-k) against the reference's outputs on EVERY fixture frame, directly: same query
     selection in the same order, y within 1e-3 (logit scale too), obj_idxes == the reference's obj_idxes.  The fixtures carry
     the margins of SURVEY App. G (adjacent top-k scores > 1e-3 apart, boundary > 5e-3, no score within 1e-2 of 0.4 / 0.5)."""
@@ -127,7 +127,7 @@ def _direct_vs_golden(name, B):
     T = cfg["frames"]
     assert float(g["topk_min_gap_all"]) > 1e-3 and float(g["topk_boundary_gap_all"]) > 5e-3 and float(g["score_margin"]) > 1e-2
     assert int(g["n_masked_in_topk"]) == 0
-    eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=torch.float32)
+    eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=torch.float32, **ekw)
     logit = lambda p: np.log(np.clip(p, 1e-7, 1 - 1e-7) / (1 - np.clip(p, 1e-7, 1 - 1e-7)))
     worst = 0.0
     for t0 in range(0, T, B):
@@ -147,7 +147,7 @@ def _direct_vs_golden(name, B):
             if bool(g[f"post.{t}.is_track"]):
                 k = int(out["n_ids"][b])
                 assert np.array_equal(out["track_id"][b, :k].cpu().numpy(), g[f"post.{t}.track_id"].reshape(-1))
-    print(f"[{name}] {T} frames direct vs reference: max |y diff| {worst:.2e}")
+    print(f"[{name}{' split_f16' if ekw else ''}] {T} frames direct vs reference: max |y diff| {worst:.2e}")
 
 
 def test_engine_fp32_full_scale_yaml_vs_reference_golden():
@@ -165,6 +165,15 @@ def test_engine_fp32_full_scale_yaml_vs_reference_golden():
 def test_engine_fp32_c2_vs_reference_golden():
     """Config C2 (s-scale, 1088x608, nq 300): all 8 golden frames, direct comparison."""
     _direct_vs_golden("c2", 4)
+
+
+@pytest.mark.parametrize("name,B", [("tiny", 3), ("c2", 4), ("c4", 2), ("full", 2)])
+def test_engine_split_f16_products_vs_reference_goldens(name, B):
+    """Round 5: the fp32 engine with every `moy_gemm` product in split fp16 precision (`split_f16=True`, MOY_F32X3) held
+    to the SAME bar as the exact-fp32 engine, directly against the reference's outputs on every fixture frame: same query selection in
+    the same order, y and decoder logits within 1e-3, obj_idxes and track ids bit-exact, predictor rows -- north_star's parity sentence,
+    at several times the exact engine's matrix rate."""
+    _direct_vs_golden(name, B, split_f16=True)
 
 
 @pytest.mark.slow

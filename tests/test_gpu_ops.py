@@ -55,6 +55,51 @@ def test_gemm_linear_variants(dt, M, N, K):
     assert torch.allclose(y.cpu(), ref, atol=tol(dt, 2e-5, 2e-2), rtol=1e-5)
 
 
+@pytest.mark.parametrize("M,N,K,scale", [(300, 256, 256, 1.0), (1000, 64, 96, 30.0), (129, 1024, 256, 1e-3), (4097, 32, 384, 1.0), (70000, 256, 128, 1.0)])
+def test_gemm_split_f16_products_carry_fp32_accuracy(M, N, K, scale):
+    """MOY_F32X3 (round 5): fp32 tensors, every product on the 16-bit matrix cores as hi.hi + (hi.lo + lo.hi) * 2^-11 with
+    hi = fp16(x), lo = fp16((x - hi) * 2^11).  Against a float64 product of the same fp32 operands: the error must be of the order of
+    the exact-fp32 kernel's own (v_mfma_f32_16x16x4_f32, the parity path) -- a few 2^-22 of the row's magnitude, nowhere near fp16's
+    2^-11 --, for operands of very different magnitudes, with bias / SiLU / residual, and through the LayerNorm epilogue."""
+    x, w = rnd(M, K, seed=1, scale=scale), rnd(N, K, seed=2, scale=1 / math.sqrt(K))
+    b, r = rnd(N, seed=3, scale=0.1 * scale), rnd(M, N, seed=4, scale=scale)
+    xd, wd = x.to(DEV), ops.pad_weight(w.to(DEV), torch.float32)
+    ref = (x.double() @ w.double().T + b.double())
+    mag = float((x.abs().double() @ w.abs().double().T).max())            # sum |x||w|: the scale rounding errors are relative to
+    y3 = ops.gemm(xd, wd, N, K, shift=b.to(DEV), split_f16=True).double().cpu()
+    y1 = ops.gemm(xd, wd, N, K, shift=b.to(DEV)).double().cpu()
+    e3, e1 = float((y3 - ref).abs().max()) / mag, float((y1 - ref).abs().max()) / mag
+    assert e3 <= 8 * 2.0 ** -22 and e3 <= max(16 * e1, 2.0 ** -21), (e3, e1)
+    assert e3 < 2.0 ** -14 / 8                                              # (fp16 products alone would sit at ~2^-11)
+    # epilogue forms on top of the split product: scale + shift + SiLU + residual, fp32 in and out
+    sc = rnd(N, seed=5) * 0.2 + 1.0
+    y = ops.gemm(xd, wd, N, K, scale=sc.to(DEV), shift=b.to(DEV), act=L.ACT_SILU, R=r.to(DEV), split_f16=True)
+    want = F.silu((x.double() @ w.double().T) * sc.double() + b.double()) + r.double()
+    assert float((y.double().cpu() - want).abs().max()) <= 16 * 2.0 ** -22 * max(mag, scale)
+    if N == 256:
+        g, be = rnd(N, seed=6) * 0.2 + 1.0, rnd(N, seed=7, scale=0.1)
+        y = ops.gemm(xd, wd, N, K, shift=b.to(DEV), R=r.to(DEV), ln=(g.to(DEV), be.to(DEV)), split_f16=True)
+        want = F.layer_norm(ref + r.double(), (N,), g.double(), be.double(), 1e-5)
+        assert float((y.double().cpu() - want).abs().max()) <= 2e-5
+    with pytest.raises(AssertionError):
+        ops.gemm(xd.to(torch.bfloat16), ops.pad_weight(w.to(DEV), torch.bfloat16), N, K, split_f16=True)      # a mode of fp32 tensors only
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,s", [(2, 13, 21, 16, 32, 1), (1, 38, 68, 64, 64, 2), (3, 8, 12, 32, 24, 1)])
+def test_gemm_split_f16_conv3x3(B, H, W, Cin, Cout, s):
+    """The implicit-GEMM 3x3 convolution in split precision against float64 (conv.py:36-38: conv + BN + SiLU)."""
+    x, w = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=1 / math.sqrt(9 * Cin))
+    sc, sh = rnd(Cout, seed=3) * 0.2 + 1, rnd(Cout, seed=4, scale=0.1)
+    ref = F.silu(F.conv2d(x.double(), w.double(), None, s, 1) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    Ho, Wo = ref.shape[2:]
+    xin = x.permute(0, 2, 3, 1).reshape(B * H * W, Cin).contiguous().to(DEV)
+    wp = ops.pad_weight(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).to(DEV), torch.float32)
+    y = ops.gemm(xin, wp, Cout, 9 * Cin, ksize=3, stride=s, geom=(B, H, W, Ho, Wo, Cin), scale=sc.to(DEV), shift=sh.to(DEV), act=L.ACT_SILU,
+                 split_f16=True)
+    got = y.double().cpu().view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    assert float((got - ref).abs().max()) <= 2e-6, float((got - ref).abs().max())
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,act", [(70000, 256, "none"), (65537, 512, "silu"), (66000 + 63, 1536, "none")])
 def test_gemm_weight_stationary_kernel_bit_identical_to_tiled(dt, M, N, act):
