@@ -47,6 +47,8 @@ if os.path.exists(f"{src}/traffic_step.json") and os.path.exists(f"{src}/traffic
             key = "stem+conv1 fused M11907072 N64"
         elif "c2f_fused_kernel" in r["kernel"] and r["dispatches"] == 5:
             key = "c2f fused M11907072 64->[32|32]->64"
+        elif "msda_raw_kernel" in r["kernel"] and r["dispatches"] == 30:      # round 5: six calls per pass (the dominant kernel by total time)
+            key = "msda_raw0 M86400"
         if key:
             doc["launches"][key] = dict(
                 hbm_bytes=r["hbm_bytes"], source=f"profiles/{tag}_b288_hbm_traffic_pmc.json ({r['kernel'][:70]}, grid {r['grid']}, "

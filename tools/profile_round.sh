@@ -28,13 +28,13 @@ run_line full_bf16 --config full --no-cpu-baseline --no-extra-legs --dump-launch
 fi
 [ "$stage" = "lines" ] && exit 0
 echo "[profile_round] rocprofv3 kernel stats (default run, 2 streams)" &&
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_default -- python3 bench.py --no-cpu-baseline --no-parity --no-launch-table --no-extra-legs --steps 10 --warmup 2 > $out/trace_default.log 2>&1 &&
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_default -- python3 bench.py --no-cpu-baseline --no-parity --no-launch-table --no-selfcheck --steps 10 --warmup 2 > $out/trace_default.log 2>&1 &&
 echo "[profile_round] rocprofv3 kernel stats (288 frames, 1 stream)" &&
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_1stream -- python3 bench.py --batch 288 --streams 1 --no-cpu-baseline --no-parity --steps 10 --warmup 2 > $out/trace_1stream.log 2>&1 &&
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_1stream -- python3 bench.py --batch 288 --streams 1 --no-cpu-baseline --no-parity --no-selfcheck --steps 10 --warmup 2 > $out/trace_1stream.log 2>&1 &&
 echo "[profile_round] PMC FETCH_SIZE" &&
-timeout -k 10 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --batch 288 --streams 1 --no-graph --no-cpu-baseline --no-parity --no-launch-table --steps 2 --warmup 1 > $out/fetch.log 2>&1 &&
+timeout -k 10 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --batch 288 --streams 1 --no-graph --no-cpu-baseline --no-parity --no-launch-table --no-selfcheck --steps 2 --warmup 1 > $out/fetch.log 2>&1 &&
 echo "[profile_round] PMC WRITE_SIZE" &&
-timeout -k 10 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --batch 288 --streams 1 --no-graph --no-cpu-baseline --no-parity --no-launch-table --steps 2 --warmup 1 > $out/write.log 2>&1 &&
+timeout -k 10 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --batch 288 --streams 1 --no-graph --no-cpu-baseline --no-parity --no-launch-table --no-selfcheck --steps 2 --warmup 1 > $out/write.log 2>&1 &&
 python3 tools/traffic_summary.py $out --steps 5 --frames 288 | tail -20 &&
 python3 tools/trace_by_grid.py $out/trace_1stream > $out/trace_1stream_by_launch_shape.csv &&
 find $out -name "*.db" -delete; find $out -name "*kernel_trace.csv" -size +8M -delete; find $out -name "*counter_collection.csv" -size +8M -delete; du -sh $out
