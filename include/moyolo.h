@@ -30,7 +30,10 @@ extern "C" {
 /* moy_gemm only (round 5): fp32 tensors exactly as MOY_F32 (A, W, R, C are float), but the products run on the 16-bit matrix
  * cores in SPLIT precision -- every operand x = hi + lo * 2^-11 with hi = fp16(x), lo = fp16((x - hi) * 2^11), three products
  * hi.hi, hi.lo, lo.hi (v_mfma_f32_16x16x32_f16, fp32 accumulation in two accumulator sets combined at the end); lo.lo is dropped:
- * about 22 mantissa bits per product at 16/3 of the fp32 matrix rate.  Operands must be finite and below 65504 in magnitude. */
+ * about 22 mantissa bits per product at 16/3 of the fp32 matrix rate.  Operands must be finite and below 65504 in magnitude.
+ * A (and A2, R, C, pre) are float; W is handed over PRE-SPLIT by the caller: fp16 [2][N][Kpad32] (Kpad32 = K rounded up to 32, zero
+ * padded), plane 0 = fp16(w), plane 1 = fp16((w - plane 0) * 2^11) -- the same bytes as the fp32 matrix, split once instead of in
+ * every tile that reads it. */
 #define MOY_F32X3 3
 
 #define MOY_OK 0

@@ -119,12 +119,20 @@ __device__ __forceinline__ void mma_panel<f32x3_t>(f32x4& acc, u32x4 wfrag, u32x
 __device__ __forceinline__ void split_f16x3(u32x4 c, u32x2& hi, u32x2& lo) {
   typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
   const f32x4 x = __builtin_bit_cast(f32x4, c);
-  const h2_ h01 = __builtin_convertvector(f32x2_{x.x, x.y}, h2_), h23 = __builtin_convertvector(f32x2_{x.z, x.w}, h2_);
-  const f32x2_ b01 = __builtin_convertvector(h01, f32x2_), b23 = __builtin_convertvector(h23, f32x2_);
-  const h2_ l01 = __builtin_convertvector(f32x2_{(x.x - b01.x) * 2048.0f, (x.y - b01.y) * 2048.0f}, h2_);
-  const h2_ l23 = __builtin_convertvector(f32x2_{(x.z - b23.x) * 2048.0f, (x.w - b23.y) * 2048.0f}, h2_);
-  hi = u32x2{__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23)};
-  lo = u32x2{__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23)};
+  const uint32_t h01 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_{x.x, x.y}, h2_));
+  const uint32_t h23 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_{x.z, x.w}, h2_));
+  // lo = fp16(x * 2^11 - hi * 2^11): v_fma_mixlo / mixhi_f16 read the fp16 head in place and round the fp32 fma straight into the low /
+  // high half of the result (x * 2^11 - hi * 2^11 is exact in fp32, so this is the ONE rounding of the remainder); 8 vector operations
+  // per four values instead of 16 (convert back, subtract, scale, convert)
+  const f32x4 xs = x * 2048.0f;
+  const float m2048 = -2048.0f;
+  uint32_t l01, l23;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(h01), "v"(m2048), "v"(xs.x));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h01), "v"(m2048), "v"(xs.y));
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(h23), "v"(m2048), "v"(xs.z));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "v"(m2048), "v"(xs.w));
+  hi = u32x2{h01, h23};
+  lo = u32x2{l01, l23};
 }
 
 template <int BM, int BN>
@@ -414,9 +422,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
   const uint32_t a_rec = (uint32_t)(a_left < 0x7fffffffLL ? a_left : 0x7fffffffLL);
   const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Ag + a_base), 0, a_rec, 0x00020000);
   const auto rsA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>((A2g ? A2g : Ag) + a_base), 0, a_rec, 0x00020000);
+  // X3: W arrives PRE-SPLIT -- fp16 [2][N][Kpad], plane 0 the heads, plane 1 the scaled remainders (moyolo.h, MOY_F32X3) -- and is
+  // staged like a 16-bit operand: panel = plane, 8 k per 16-byte chunk, no vector arithmetic on the way
+  constexpr int WESZ = X3 ? 2 : ESZ;
   const int64_t w_base = (int64_t)n0 * p.Kpad;
-  const int64_t w_left = ((int64_t)p.N * p.Kpad - w_base) * ESZ;
-  const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Wg + w_base), 0,
+  const int64_t w_plane = (int64_t)p.N * p.Kpad * WESZ;                         // bytes of one plane (X3) / of the matrix
+  const int64_t w_left = (X3 ? 2 : 1) * w_plane - w_base * WESZ;
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(Wg) + w_base * WESZ), 0,
                                                      (uint32_t)(w_left < 0x7fffffffLL ? w_left : 0x7fffffffLL), 0x00020000);
 
   uint32_t a_voff[RA2];    // byte offset of (row, kc0) for ksize 1; of pixel (iy0, ix0) channel 0 for ksize 3
@@ -452,7 +464,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
 #pragma unroll
   for (int j = 0; j < RB2; ++j) {
     const int n = n0 + srow + j * RPP;
-    b_voff[j] = n < p.N ? (uint32_t)(((int64_t)(srow + j * RPP) * p.Kpad + kc0) * ESZ) : OOB;
+    if constexpr (X3) b_voff[j] = n < p.N ? (uint32_t)(((int64_t)(srow + j * RPP) * p.Kpad + sq * 8) * 2 + spn * w_plane) : OOB;
+    else b_voff[j] = n < p.N ? (uint32_t)(((int64_t)(srow + j * RPP) * p.Kpad + kc0) * ESZ) : OOB;
   }
 
   u32x4 areg[NSET][RA2], breg[NSET][RB2];
@@ -482,8 +495,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
         areg[SET][j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0);
       }
     }
+    const int soff_w = X3 ? kt * BK * 2 : soff;            // (X3: 32 fp16 per plane row and stage)
 #pragma unroll
-    for (int j = 0; j < RB2; ++j) breg[SET][j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, b_voff[j], soff, 0);
+    for (int j = 0; j < RB2; ++j) breg[SET][j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, b_voff[j], soff_w, 0);
   };
 
   auto store_stage = [&](int buf, auto set_c) {
@@ -503,12 +517,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
         *reinterpret_cast<u32x2*>(As + (BM + (row ^ SKEW)) * 64 + swz(row, c16) * 16 + hb) = lo;
       }
 #pragma unroll
-      for (int j = 0; j < RB2; ++j) {
+      for (int j = 0; j < RB2; ++j) {          // (already split: the 16-bit kernels' store, panel = plane)
         const int row = srow + j * RPP;
-        u32x2 hi, lo;
-        split_f16x3(breg[SET][j], hi, lo);
-        *reinterpret_cast<u32x2*>(Bs + row * 64 + swz(row, c16) * 16 + hb) = hi;
-        *reinterpret_cast<u32x2*>(Bs + (BN + (row ^ SKEW)) * 64 + swz(row, c16) * 16 + hb) = lo;
+        *reinterpret_cast<u32x4*>(Bs + (spn * BN + (row ^ (spn * SKEW))) * 64 + swz(row, sq) * 16) = breg[SET][j];
       }
       return;
     }
@@ -571,14 +582,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
         wh[j] = *reinterpret_cast<const u32x4*>(Bs + row * 64 + swz(row, q) * 16);
         wl[j] = *reinterpret_cast<const u32x4*>(Bs + (BN + (row ^ SKEW)) * 64 + swz(row, q) * 16);
       }
+      // three sweeps over the sub-tiles, not three products per sub-tile: two MFMAs in a row into ONE accumulator wait for each other
+      // (a dependent v_mfma_f32_16x16x32 chain issues every ~53 cycles instead of 16: DESIGN.md round 3, item 11)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          mma_panel<f16_t>(acc[i][j], wh[j], ah[i]);
-          mma_panel<f16_t>(accx[i][j], wh[j], al[i]);
-          mma_panel<f16_t>(accx[i][j], wl[j], ah[i]);
-        }
+        for (int j = 0; j < NT; ++j) mma_panel<f16_t>(acc[i][j], wh[j], ah[i]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) mma_panel<f16_t>(accx[i][j], wh[j], al[i]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) mma_panel<f16_t>(accx[i][j], wl[j], ah[i]);
       return;
     }
 #pragma unroll

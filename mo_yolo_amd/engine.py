@@ -143,6 +143,9 @@ class TrackEngine:
         N, K = w2d.shape
         out = torch.zeros(N, self._kpad(K), dtype=torch.float32)
         out[:, :K] = w2d
+        if self.split_f16:      # MOY_F32X3 takes its weights pre-split: fp16 [2][N][Kpad], heads and scaled remainders
+            hi = out.to(torch.float16)
+            return self._dev(torch.stack([hi, ((out - hi.float()) * 2048.0).to(torch.float16)]))
         return self._dev(out, self.dtype)
 
     def _bn(self, p):

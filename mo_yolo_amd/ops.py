@@ -45,6 +45,14 @@ def pad_weight(w2d: torch.Tensor, dtype) -> torch.Tensor:
     return out.to(dtype).contiguous()
 
 
+def split_weight(w2d: torch.Tensor) -> torch.Tensor:
+    """[N, K] fp32 -> fp16 [2, N, Kpad32]: the operand form of MOY_F32X3 (moyolo.h): plane 0 = fp16(w), plane 1 = fp16((w - plane 0) * 2^11)."""
+    w = pad_weight(w2d, torch.float32)
+    hi = w.to(torch.float16)
+    lo = ((w - hi.float()) * 2048.0).to(torch.float16)
+    return torch.stack([hi, lo]).contiguous()
+
+
 def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shift=None, act=L.ACT_NONE, A2=None,
          a_rows=None, a_mask=None, mask_period=0, R=None, ln=None, out_f32=False, M=None, c_rpb=0, c_bstride=0,
          dot=None, store=True, pre=None, a2_cols=0, planes=None, runs=None, dot_out=None, post=None, split_f16=False):
@@ -109,8 +117,8 @@ def gemm(A, Wp, N, K, *, out=None, ksize=1, stride=1, geom=None, scale=None, shi
         if dot_out is None:
             dot_out = torch.empty(M, dw.shape[0], device=A.device, dtype=torch.float32)
         a.dot_w, a.dot_b, a.dot_out, a.dot_n = dw.data_ptr(), db.data_ptr(), dot_out.data_ptr(), dw.shape[0]
-    if split_f16:           # MOY_F32X3: fp32 tensors, split-fp16 matrix arithmetic
-        assert A.dtype == torch.float32
+    if split_f16:           # MOY_F32X3: fp32 tensors, split-fp16 matrix arithmetic; W pre-split (split_weight)
+        assert A.dtype == torch.float32 and Wp.dtype == torch.float16 and Wp.dim() == 3 and Wp.shape[0] == 2 and Wp.shape[1] == N
         a.dtype = L.F32X3
     L.check(L.lib().moy_gemm(C.byref(a), _st()), "moy_gemm")
     return out if dot is None else (out, dot_out)

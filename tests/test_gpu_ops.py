@@ -63,22 +63,22 @@ def test_gemm_split_f16_products_carry_fp32_accuracy(M, N, K, scale):
     2^-11 --, for operands of very different magnitudes, with bias / SiLU / residual, and through the LayerNorm epilogue."""
     x, w = rnd(M, K, seed=1, scale=scale), rnd(N, K, seed=2, scale=1 / math.sqrt(K))
     b, r = rnd(N, seed=3, scale=0.1 * scale), rnd(M, N, seed=4, scale=scale)
-    xd, wd = x.to(DEV), ops.pad_weight(w.to(DEV), torch.float32)
+    xd, wd, w3 = x.to(DEV), ops.pad_weight(w.to(DEV), torch.float32), ops.split_weight(w.to(DEV))
     ref = (x.double() @ w.double().T + b.double())
     mag = float((x.abs().double() @ w.abs().double().T).max())            # sum |x||w|: the scale rounding errors are relative to
-    y3 = ops.gemm(xd, wd, N, K, shift=b.to(DEV), split_f16=True).double().cpu()
+    y3 = ops.gemm(xd, w3, N, K, shift=b.to(DEV), split_f16=True).double().cpu()
     y1 = ops.gemm(xd, wd, N, K, shift=b.to(DEV)).double().cpu()
     e3, e1 = float((y3 - ref).abs().max()) / mag, float((y1 - ref).abs().max()) / mag
     assert e3 <= 8 * 2.0 ** -22 and e3 <= max(16 * e1, 2.0 ** -21), (e3, e1)
     assert e3 < 2.0 ** -14 / 8                                              # (fp16 products alone would sit at ~2^-11)
     # epilogue forms on top of the split product: scale + shift + SiLU + residual, fp32 in and out
     sc = rnd(N, seed=5) * 0.2 + 1.0
-    y = ops.gemm(xd, wd, N, K, scale=sc.to(DEV), shift=b.to(DEV), act=L.ACT_SILU, R=r.to(DEV), split_f16=True)
+    y = ops.gemm(xd, w3, N, K, scale=sc.to(DEV), shift=b.to(DEV), act=L.ACT_SILU, R=r.to(DEV), split_f16=True)
     want = F.silu((x.double() @ w.double().T) * sc.double() + b.double()) + r.double()
     assert float((y.double().cpu() - want).abs().max()) <= 16 * 2.0 ** -22 * max(mag, scale)
     if N == 256:
         g, be = rnd(N, seed=6) * 0.2 + 1.0, rnd(N, seed=7, scale=0.1)
-        y = ops.gemm(xd, wd, N, K, shift=b.to(DEV), R=r.to(DEV), ln=(g.to(DEV), be.to(DEV)), split_f16=True)
+        y = ops.gemm(xd, w3, N, K, shift=b.to(DEV), R=r.to(DEV), ln=(g.to(DEV), be.to(DEV)), split_f16=True)
         want = F.layer_norm(ref + r.double(), (N,), g.double(), be.double(), 1e-5)
         assert float((y.double().cpu() - want).abs().max()) <= 2e-5
     with pytest.raises(AssertionError):
@@ -93,7 +93,7 @@ def test_gemm_split_f16_conv3x3(B, H, W, Cin, Cout, s):
     ref = F.silu(F.conv2d(x.double(), w.double(), None, s, 1) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
     Ho, Wo = ref.shape[2:]
     xin = x.permute(0, 2, 3, 1).reshape(B * H * W, Cin).contiguous().to(DEV)
-    wp = ops.pad_weight(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).to(DEV), torch.float32)
+    wp = ops.split_weight(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).to(DEV))
     y = ops.gemm(xin, wp, Cout, 9 * Cin, ksize=3, stride=s, geom=(B, H, W, Ho, Wo, Cin), scale=sc.to(DEV), shift=sh.to(DEV), act=L.ACT_SILU,
                  split_f16=True)
     got = y.double().cpu().view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
