@@ -88,30 +88,33 @@ __global__ __launch_bounds__(512, 4) void stem_l1_kernel(const StemL1Params p) {
     t.x0 = (rem - ty * p.tiles_x) * 16;
     return t;
   };
-  // window of tile t -> registers: dword i = tid + k*512 of the [WR][ROW_DW] image; bytes outside the image row read as zero
+  // window of tile t -> registers: dword i = tid + k*512 of the [WR][ROW_DW] image.  Round 5: one buffer load per dword, the offset a
+  // per-thread constant (window row, dword) + three tile terms -- the first version did this in 64-bit arithmetic with a byte-wise
+  // branch per dword, 231 vector instructions per tile and thread: 22 % of the kernel's vector work for 7 KB of input.
+  //   byte (4 x0 - 3) * 3 = 12 x0 - 9 of an image row is where the window row starts; its aligned dword is 12 x0 - 12 (PHASE = 3;
+  //   image rows are dword aligned: W % 4 == 0).  Rows above / below the image: out-of-range offset (zeros = the stem's padding).
+  //   Left of the image (x0 == 0, dwords 0-2): the bytes in front of the row belong to the previous row, never to the padding: zeroed.
+  //   Right of the image: only stem pixels outside the stem image read them, and those are zeroed when the patch is written.
   uint32_t wreg[NLD];
+  int w_rr[NLD], w_off[NLD];
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int i = tid + k * 512;
+    w_rr[k] = i / ROW_DW;
+    const int dw = i - w_rr[k] * ROW_DW;
+    w_off[k] = w_rr[k] < WR ? w_rr[k] * p.W * 3 + dw * 4 - 12 : -1;     // -1: past the window
+    if (dw < 3) w_rr[k] |= 0x10000;                                      // bit 16: in front of the row when x0 == 0
+  }
+  const uint32_t img_bytes = (uint32_t)p.H * p.W * 3;
   auto load_window = [&](const Tile& t) {
-    const long img = (long)t.b * p.H * p.W * 3;
+    const auto rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.in + (int64_t)t.b * img_bytes), 0, img_bytes, 0x00020000);
+    const int tile_off = ((4 * t.y0 - 3) * p.W + 4 * t.x0) * 3;          // byte offset of window row 0, image column 4 x0
+    const int iy0 = 4 * t.y0 - 3;
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-      const int i = tid + k * 512;
-      const int rr = i / ROW_DW, dw = i - rr * ROW_DW;
-      const int iy = 4 * t.y0 - 3 + rr;
-      uint32_t v = 0;
-      if (rr < WR && (unsigned)iy < (unsigned)p.H) {
-        const long row0 = img + (long)iy * p.W * 3;
-        const long start = row0 + (long)(4 * t.x0 - 3) * 3;           // first byte of the window row (may precede the image row)
-        const long addr = (start & ~3L) + dw * 4;
-        const long hi = row0 + (long)p.W * 3;
-        if (addr >= row0 && addr + 4 <= hi) {
-          v = *reinterpret_cast<const uint32_t*>(p.in + addr);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (addr + e >= row0 && addr + e < hi) v |= (uint32_t)p.in[addr + e] << (8 * e);
-        }
-      }
-      wreg[k] = v;
+      const int iy = iy0 + (w_rr[k] & 0xffff);
+      const bool ok = w_off[k] != -1 && (unsigned)iy < (unsigned)p.H && !(t.x0 == 0 && (w_rr[k] & 0x10000));
+      wreg[k] = __builtin_amdgcn_raw_buffer_load_b32(rsI, ok ? (uint32_t)(tile_off + w_off[k]) : 0x80000000u, 0, 0);
     }
   };
   auto store_window = [&]() {

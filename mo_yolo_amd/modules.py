@@ -328,12 +328,18 @@ class MSDeformAttn(nn.Module):
         return ops.msda_fused(value2d, bs, S, shapes, offaw, ref2d, len_q)
 
     def forward(self, query, refer_bbox, value, value_shapes, value_mask=None):
-        if value_mask is not None:
-            raise NotImplementedError("value_mask is always None on this path (SURVEY App. E.8)")
         bs, len_q = query.shape[:2]
         if refer_bbox.shape[-1] != 4:
             raise NotImplementedError("4-d reference boxes (transformer.py:280-282)")
         v2d = self.value_proj.rows(value.reshape(-1, self.d_model).contiguous())
+        if value_mask is not None:
+            # transformer.py:258-259: `value = value.masked_fill(value_mask[..., None], float(0))` on the PROJECTED value (always None
+            # on the tracking path; kept for callers of the module surface)
+            mk = value_mask.reshape(-1).to(device=v2d.device, dtype=torch.uint8).contiguous()
+            if mk.numel() != v2d.shape[0]:
+                raise ValueError(f"value_mask covers {mk.numel()} tokens, value has {v2d.shape[0]}")
+            L.check(L.lib().moy_mask_rows(v2d.data_ptr(), v2d.stride(0), v2d.shape[0], v2d.shape[1], mk.data_ptr(), ops._code(v2d), ops._st()),
+                    "moy_mask_rows")
         ref2d = refer_bbox.reshape(bs * len_q, -1, 4)[:, 0].float().contiguous()   # same box for every level (:644)
         samp = self.core(query.reshape(-1, self.d_model).contiguous(), ref2d, v2d, bs, len_q, [tuple(s) for s in value_shapes])
         return self.output_proj.rows(samp).view(bs, len_q, self.d_model)

@@ -70,6 +70,29 @@ def test_decoder_layer_and_msdeformattn_modules_vs_golden():
         assert np.allclose(o.cpu().numpy(), g["t0.dec0.msda_out"], atol=1e-5)
 
 
+def test_msdeformattn_value_mask_zeroes_the_projected_value():
+    """MSDeformAttn.forward(..., value_mask): `value.masked_fill(value_mask[..., None], 0)` AFTER value_proj (transformer.py:264-266) --
+    against the same module called on explicitly masked projected values through its sampling core, and against no mask."""
+    cfg, arch, sd = fixture("tiny")
+    d = f"model.{len(arch.layers)}.decoder"
+    with torch.no_grad():
+        r = O.forward(net_input(cfg, 0, 1), sd, arch)
+    ca = load(M.MOTRDecoderLayer(256, 8, 1024, 0.0, None, 3, 4), sd, d + ".decoder.layers.0.").cross_attn
+    q = (r["embed"] + r["query_pos"]).to(DEV)
+    ref = r["refer_bbox_logit"].sigmoid().to(DEV).unsqueeze(2)
+    feats = r["feats"].to(DEV)
+    S = feats.shape[1]
+    mask = (torch.arange(S) % 3 == 0)[None]                        # True = zero this token's value
+    got = ca(q, ref, feats, r["shapes"], value_mask=mask.to(DEV))
+    v2d = ca.value_proj.rows(feats.reshape(-1, 256).contiguous())
+    v2d[mask[0].to(DEV)] = 0
+    want = ca.output_proj.rows(ca.core(q.reshape(-1, 256).contiguous(), ref.reshape(-1, 1, 4)[:, 0].float().contiguous(), v2d, 1, q.shape[1],
+                                       [tuple(s) for s in r["shapes"]])).view_as(got)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert not torch.equal(got, ca(q, ref, feats, r["shapes"]))
+
+
 def test_transformer_decoder_module():
     cfg, arch, sd = fixture("tiny")
     d = f"model.{len(arch.layers)}.decoder"
