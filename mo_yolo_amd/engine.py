@@ -63,7 +63,7 @@ class TrackEngine:
                  score_thresh: float = 0.4, scale_boxes: bool = True, head_only: bool = False,
                  level_shapes_override=None, side_state: bool = False, iou: float = 0.7, max_det: int = 300, orig_hw=None,
                  temporal: int = 0, filter_score_thresh: float = 0.5, miss_tolerance: int = 5, n_inputs: int = 1,
-                 split_f16: bool = False):
+                 split_f16: bool = False, track_content: str = "decoder_output"):
         if not torch.cuda.is_available():
             raise L.MoyoloError("TrackEngine needs a HIP device (no CPU path)")
         self.lib = L.lib()
@@ -91,6 +91,12 @@ class TrackEngine:
         self.filter_score_thresh, self.miss_tolerance = filter_score_thresh, miss_tolerance
         if self.n_max and (side_state or head_only):
             raise ValueError("temporal mode excludes side_state / head_only")
+        # temporal mode, CONTENT embedding of a carried track: "decoder_output" = its own decoder output of the
+        # previous frame (upstream MOTR, motr.py:545-577: the default); "class_embed" = the fork's own visible design,
+        # denoising_class_embed.weight[argmax of the track's class scores] (head.py:888-900, 917-919, 1109-1110)
+        if track_content not in ("decoder_output", "class_embed"):
+            raise ValueError(track_content)
+        self.track_content = track_content
         self.shapes = [tuple(s) for s in level_shapes_override] if level_shapes_override else level_shapes(H, W)
         self.S = sum(h * w for h, w in self.shapes)
         self._keep: List[torch.Tensor] = []          # device tensors referenced by raw pointers
@@ -904,7 +910,13 @@ class TrackEngine:
         # the selected rows' decoder output (content embedding of the track from now on), the position embedding and the
         # reference box they were decoded with
         sel = self.sel_rows.data_ptr()
-        out_embed = View(t["embed"])
+        class_content = self.track_content == "class_embed"
+        if class_content and nc != 1:
+            raise NotImplementedError("track_content='class_embed' needs the class of every carried row on the device: built for nc == 1 "
+                                      "(every configuration of this path); the default 'decoder_output' has no such limit")
+        # the selected rows' decoder output: the track's content embedding from now on (default) and, in both modes, what the learned
+        # query update consumes
+        out_embed = View(self._buf(Mq, hd)) if class_content else View(t["embed"])
         qp_prev = View(self._buf(Mq, hd))
         ref_in = self._buf(Mq, 4, torch.float32)
         gm = dict(name=f"gather_rows M{Mq} C{hd}", bytes=Mq * (2 * hd * self._esz + 4), flops=0)
@@ -938,6 +950,15 @@ class TrackEngine:
         g1 = View(self._buf(Mq, dff))
         self._gemm(tgt2, Wf1, dff, hd, g1, Mq, shift=bf1, act=L.ACT_RELU)
         self._gemm(g1, Wf2, hd, dff, View(t["qpos"]), Mq, shift=bf2, R=qp_prev, ln=self._ln(q + ".norm_feat"))
+        if class_content:
+            # head.py:888-900: the carried queries' content = the class embedding of the track's class (nc == 1: row 0 for every slot;
+            # dead slots are zeroed by moy_temporal_assemble whatever the memory holds)
+            d_ = f"model.{len(arch.layers)}.decoder"
+            table = self._dev(sd[d_ + ".denoising_class_embed.weight"].reshape(nc, hd), self.dtype)
+            cls0 = torch.zeros(Mq, device=self.dev, dtype=i32)
+            self._keep.append(cls0)
+            self._add(lib.moy_gather_rows, table.data_ptr(), hd, cls0.data_ptr(), Mq, hd, t["embed"].data_ptr(), hd, code,
+                      meta=dict(name=f"gather_rows M{Mq} C{hd} (class embedding)", bytes=Mq * hd * self._esz + hd * self._esz, flops=0))
         self._add(lib.moy_temporal_commit, sel, self.n_new.data_ptr(), self.obj_idxes.data_ptr(), self.dis_out.data_ptr(),
                   self.boxes.data_ptr(), B, n_max, t["id"].data_ptr(), t["dis"].data_ptr(), t["ref"].data_ptr(), t["n"].data_ptr(),
                   meta=dict(name=f"temporal_commit B{B} N{n_max}", bytes=Mq * (4 + 8 + 4 + 16 + 28), flops=0))

@@ -26,7 +26,12 @@ from . import track_oracle as O
 
 
 class TemporalOracle:
-    def __init__(self, sd, arch, n_max, conf=0.25):
+    def __init__(self, sd, arch, n_max, conf=0.25, content="decoder_output"):
+        """content: what a carried track's CONTENT embedding is in the next frame -- "decoder_output" (upstream MOTR, the default) or
+        "class_embed": the fork's own visible design, denoising_class_embed.weight[argmax of the track's class scores]
+        (head.py:888-900, passed on as track_embed :917-919 and concatenated in front of the detect queries :1109-1110)."""
+        assert content in ("decoder_output", "class_embed")
+        self.content = content
         self.sd, self.arch, self.n_max, self.conf = sd, arch, n_max, conf
         self.d = f"model.{len(arch.layers)}.decoder"
         self.t = f"model.{len(arch.layers)}.track_embed"
@@ -63,6 +68,8 @@ class TemporalOracle:
             k = torch.tensor(keep)
             qf, new_ref = O.qim_update_track_embedding(ref_logit[0, k], hs[0, k], qpos[0, k], boxes[0, k], sd, self.t, arch.nh)
             self.embed, self.qpos, self.ref = hs[0, k].clone(), qf, new_ref
+            if self.content == "class_embed":
+                self.embed = sd[self.d + ".denoising_class_embed.weight"][logits[0, k].argmax(-1)].clone()
         else:
             self.embed, self.qpos, self.ref = torch.zeros(0, 256), torch.zeros(0, 256), torch.zeros(0, 4)
         self.ids, self.dis = [ids[i] for i in keep], [dis[i] for i in keep]

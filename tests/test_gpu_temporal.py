@@ -95,21 +95,23 @@ def test_temporal_assign_vs_reference_loop():
             assert o["tid"][b, :int(o["n_ids"][b])].tolist() == tid.tolist()
 
 
-def _run_oracle(cfg, arch, sd, seq_id, T, n_max):
-    orc = TemporalOracle(sd, arch, n_max)
+def _run_oracle(cfg, arch, sd, seq_id, T, n_max, content="decoder_output"):
+    orc = TemporalOracle(sd, arch, n_max, content=content)
     seq = SyntheticSequence(seq_id, cfg["H"], cfg["W"], cfg["style"])
     return [orc.step(to_network_input(seq.frames(t, 1)), orig_hw=(cfg["H"], cfg["W"])) for t in range(T)], orc
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_temporal_engine_vs_oracle_stream(graph):
+@pytest.mark.parametrize("graph,content", [(False, "decoder_output"), (True, "decoder_output"), (True, "class_embed")])
+def test_temporal_engine_vs_oracle_stream(graph, content):
     """Two sequences in lockstep (batch element = sequence), 7 frames, fp32: per-frame ids, miss counters, boxes, rows and
-    the carried memory against the oracle; with hipGraph replay the state lives in the captured buffers."""
+    the carried memory against the oracle; with hipGraph replay the state lives in the captured buffers.  content = what a carried
+    track's content embedding is: its previous decoder output (upstream MOTR, the default) or the fork's own class embedding
+    (head.py:888-900, 917-919, 1109-1110; round 5)."""
     cfg, arch, sd = fixture("tiny")
     n_max, T, B = 24, 7, 2
-    eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=torch.float32, temporal=n_max)
+    eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=torch.float32, temporal=n_max, track_content=content)
     seqs = [SyntheticSequence(s, cfg["H"], cfg["W"], cfg["style"]) for s in range(B)]
-    want = [_run_oracle(cfg, arch, sd, s, T, n_max)[0] for s in range(B)]
+    want = [_run_oracle(cfg, arch, sd, s, T, n_max, content)[0] for s in range(B)]
     nq = arch.nq
     born_total = 0
     for t in range(T):
@@ -140,7 +142,7 @@ def test_temporal_engine_vs_oracle_stream(graph):
     assert born_total > 0 and int(out["n_tracks"].max()) > 0            # the stream exercises births and carried tracks
     # the memory after the last frame
     for b in range(B):
-        orc = _run_oracle(cfg, arch, sd, b, T, n_max)[1]
+        orc = _run_oracle(cfg, arch, sd, b, T, n_max, content)[1]
         n = len(orc.ids)
         assert int(out["n_tracks"][b]) == n
         assert out["trk_id"][b, :n].cpu().tolist() == orc.ids and out["trk_dis"][b, :n].cpu().tolist() == orc.dis
