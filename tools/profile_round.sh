@@ -23,8 +23,9 @@ run_line c4_bf16 --config c4 --no-cpu-baseline --dump-launches $out/launches_c4_
 run_line c5_f16 --config c5 --no-cpu-baseline &&
 run_line c2_temporal100 --temporal 100 --batch 32 --no-cpu-baseline &&
 run_line c2_bf16_1stream --batch 288 --streams 1 --no-cpu-baseline &&
-run_line c2_f32 --dtype f32 --no-cpu-baseline --no-extra-legs --dump-launches $out/launches_c2_f32.json &&
-run_line full_bf16 --config full --no-cpu-baseline --no-extra-legs --dump-launches $out/launches_full_bf16.json || exit 1
+run_line c2_f32 --dtype f32 --no-cpu-baseline --dump-launches $out/launches_c2_f32.json &&
+run_line c2_f32x3 --dtype f32x3 --no-cpu-baseline --dump-launches $out/launches_c2_f32x3.json &&
+run_line full_bf16 --config full --no-cpu-baseline --dump-launches $out/launches_full_bf16.json || exit 1
 fi
 [ "$stage" = "lines" ] && exit 0
 echo "[profile_round] rocprofv3 kernel stats (default run, 2 streams)" &&
