@@ -2,7 +2,8 @@
 """Long race screen of the LDS-DMA ring kernels (the long form of tests/test_gpu_stress.py).
 
     python tools/stress_rings.py --reps 200                       # the library in the tree
-    MOYOLO_LIB=tools/ab/libmoyolo_r04.so python tools/stress_rings.py --reps 200     # another build, same device (A/B)
+    MOYOLO_LIB=<another build of libmoyolo.so> MOYOLO_LIB_ALLOW_MISSING=1 python tools/stress_rings.py --reps 200     # A/B on one device
+    (round 5's A/B library was the tree at 7b629e6 built with `python -m mo_yolo_amd.build`: profiles/r05_a_*)
     python tools/stress_rings.py --engines 30 --batch 104         # fresh bench-scale engines: NaN-poisoned buffers, repeated passes
 
 Every run of a form is compared BIT FOR BIT with the tiled kernel on the same rows (mo_yolo_amd/stress.py); a bandwidth hog runs on a
