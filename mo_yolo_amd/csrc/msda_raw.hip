@@ -280,6 +280,233 @@ __global__ __launch_bounds__(256, 3) void msda_raw_kernel(const MsdaRawParams p)
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same operator with the TAP SUMS ON THE MATRIX CORES (round 5, second form; three levels, every level at least 2 x 2).
+//
+// The form above is bound by the vector ALU: every tap dword is unpacked and multiplied by its weight with three to four vector
+// instructions per lane (1 527 per query).  A bilinear sum is a [1 x taps] x [taps x channels] product, and the 16 x 16 x 32 MFMA has a
+// shape for it that needs NO data movement between the load and the product:
+//
+//   B operand = the tap data as loaded.  Lane (n = lane & 15, kg = lane >> 4) loads ONE DWORD (channels 2n, 2n+1 of a 32-channel chunk) of
+//     each of the FOUR CORNERS of sampling point kg: its four result registers are k = kg*8 .. kg*8+7 = (corner 0..3) x (even, odd channel)
+//     of column n -- the B fragment, untouched.
+//   A operand = the 16 weights of the (head, level): row 0 carries w[tap] at the even k of its tap and 0 at the odd k, row 1 the reverse,
+//     rows 2 / 3 the same with the REMAINDERS w - T(w) (the weights enter the matrix core in T: two terms keep 16 / 22 bits of them); rows
+//     4-15 are zero.  Lanes n < 4 read their four weights from a per-wave LDS table with one ds_read_b128 and mask them with a lane constant.
+//   D: lanes 0-15 hold, for channel pair n, {even, odd} x {head, remainder} sums: two adds, one pack.
+//
+// One MFMA = one head x one level x 32 channels: level 0 takes 4 per head (128 channels), levels 1 / 2 one each, accumulated into the
+// same D.  The table (corner weights and the byte offset of the clamped 2 x 2 window of every (head, point)) is written by the wave itself
+// with lane = head*8 + sub owning point `sub` (levels 0 / 1) and point 8 + sub (level 2): softmax, location and window arithmetic happen
+// ONCE per point instead of once per head lane, and there are no v_readlane.  Per query ~420 vector instructions instead of 1 527.
+// A block is 16 queries = 8 waves x 2; wave w projects head w.
+#ifndef MOY_MRM_DEPTH
+#define MOY_MRM_DEPTH 1
+#endif
+#ifndef MOY_MRM_AUX
+#define MOY_MRM_AUX 0        // cache-policy bits of the tap loads (measured: DESIGN.md)
+#endif
+constexpr int MRM_NW = 8;                    // waves per block
+constexpr int MRM_ENT = 96;                  // (head, point) entries per query: 8 x 12
+
+template <typename T>
+__global__ __launch_bounds__(64 * MRM_NW, 2) void msda_raw_mfma_kernel(const MsdaRawParams p) {
+  static_assert(sizeof(T) == 2, "16-bit values");
+  __shared__ __attribute__((aligned(16))) unsigned char sG[MR_QB * MR_GP];
+  __shared__ __attribute__((aligned(16))) unsigned char sP[MR_QB * MR_PP];
+  __shared__ __attribute__((aligned(16))) uint32_t sT[MRM_NW * MRM_ENT * 8];     // per wave: [entry][T(w) x 4 | remainder x 4], each 16-bit value in both halves
+  __shared__ uint32_t sB[MRM_NW * MRM_ENT];                                       // per wave: byte offset of the entry's window
+  __shared__ float sS[MR_QB * 8];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nblk = (int)gridDim.x, chunk = (nblk + 7) >> 3;
+  const int lblk = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if (lblk >= p.ngroups) return;
+  const int row0 = lblk * MR_QB;
+  const int m = lane >> 3, sub = lane & 7;           // table building: head m, point sub
+  const int n = lane & 15, kg = lane >> 4;           // matrix layout: column / row n, k group kg
+  const T* planes = static_cast<const T*>(p.planes);
+  const T* x0 = static_cast<const T*>(p.x0);
+  const int H0 = p.lv.H[0], W0 = p.lv.W[0], H1 = p.lv.H[1], W1 = p.lv.W[1], H2 = p.lv.H[2], W2 = p.lv.W[2];
+  const uint32_t pix_pitch = (uint32_t)(p.ld0 * 2), row_pitch = (uint32_t)(W0 * p.ld0 * 2);
+  const uint32_t hs2 = (uint32_t)(p.head_stride * 2);
+  const uint32_t amask = n < 4 ? ((n & 1) ? 0xffff0000u : 0x0000ffffu) : 0u;
+  uint32_t* myT = sT + wave * MRM_ENT * 8;
+  uint32_t* myB = sB + wave * MRM_ENT;
+  const uint32_t* aT = myT + kg * 8 + ((n & 2) ? 4 : 0);      // + entry*8 of the unit's first point
+  const uint32_t* aB = myB + kg;
+  constexpr float LOG2E = 1.4426950408889634f;
+
+  for (int j = 0; j < 2; ++j) {
+    const int ql = wave * 2 + j;
+    const int row = min(row0 + ql, p.nrows - 1);
+    const int b = __builtin_amdgcn_readfirstlane(row / p.Lq);
+    const float* oa = p.offaw + (long)row * p.ld_oa;
+    const float* offp = oa + m * 24;
+    const float* awp = oa + 192 + m * 12;
+    // softmax statistics of the head's 12 logits (every lane of the head)
+    float mx, inv_den;
+    {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(awp), a1 = *reinterpret_cast<const f32x4*>(awp + 4), a2 = *reinterpret_cast<const f32x4*>(awp + 8);
+      mx = fmaxf(fmaxf(fmaxf(a0.x, a0.y), fmaxf(a0.z, a0.w)), fmaxf(fmaxf(fmaxf(a1.x, a1.y), fmaxf(a1.z, a1.w)), fmaxf(fmaxf(a2.x, a2.y), fmaxf(a2.z, a2.w))));
+      float den = 0.f;
+      const float lg[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+#pragma unroll
+      for (int i = 0; i < 12; ++i) den += __builtin_amdgcn_exp2f((lg[i] - mx) * LOG2E);     // same order as the first form
+      inv_den = __builtin_amdgcn_rcpf(den);
+    }
+    const f32x4 rb = *reinterpret_cast<const f32x4*>(p.ref + (long)row * 4);
+    // one sampling point: clamped 2 x 2 window (slot s holds pixel xb + s) with the weights re-dealt to the slots that survive;
+    // returns the point's in-range weight sum
+    auto point = [&](int i, int Hl, int Wl, uint32_t tok0, uint32_t tok_pitch, bool store) -> float {
+      const float2 o = *reinterpret_cast<const float2*>(offp + 2 * i);
+      const float aw = __builtin_amdgcn_exp2f((awp[i] - mx) * LOG2E) * inv_den;
+      // loc = ref_xy + off / n_points * ref_wh * 0.5   (transformer.py:280-282)
+      const float lx = rb.x + o.x / 4.0f * rb.z * 0.5f;
+      const float ly = rb.y + o.y / 4.0f * rb.w * 0.5f;
+      const float x = lx * Wl - 0.5f, y = ly * Hl - 0.5f;
+      const float xf = floorf(x), yf = floorf(y);
+      const float fx = x - xf, fy = y - yf;
+      const int xi = (int)fminf(fmaxf(xf, -2.0f), (float)Wl + 1.0f), yi = (int)fminf(fmaxf(yf, -2.0f), (float)Hl + 1.0f);
+      const float ax0 = (unsigned)xi < (unsigned)Wl ? 1.f - fx : 0.f, ax1 = (unsigned)(xi + 1) < (unsigned)Wl ? fx : 0.f;
+      const float ay0 = (unsigned)yi < (unsigned)Hl ? 1.f - fy : 0.f, ay1 = (unsigned)(yi + 1) < (unsigned)Hl ? fy : 0.f;
+      const int xb = min(max(xi, 0), Wl - 2), yb = min(max(yi, 0), Hl - 2);
+      const float sx0 = xi == xb ? ax0 : (xi + 1 == xb ? ax1 : 0.f), sx1 = xi == xb ? ax1 : (xi == xb + 1 ? ax0 : 0.f);
+      const float sy0 = yi == yb ? ay0 : (yi + 1 == yb ? ay1 : 0.f), sy1 = yi == yb ? ay1 : (yi == yb + 1 ? ay0 : 0.f);
+      const float ws[4] = {aw * sx0 * sy0, aw * sx1 * sy0, aw * sx0 * sy1, aw * sx1 * sy1};
+      uint32_t hi[4], lo[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        hi[c] = DT<T>::pack2(ws[c], ws[c]);
+        const float rem = ws[c] - DT<T>::lo(hi[c]);
+        lo[c] = DT<T>::pack2(rem, rem);
+      }
+      if (store) {
+        const int e = m * 12 + i;
+        *reinterpret_cast<u32x4*>(myT + e * 8) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<u32x4*>(myT + e * 8 + 4) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+        myB[e] = (tok0 + (uint32_t)(yb * Wl + xb)) * tok_pitch;
+      }
+      return aw * (ax0 + ax1) * (ay0 + ay1);
+    };
+    {
+      const bool l1 = sub >= 4;                                                    // points 0-3: level 0, 4-7: level 1
+      float sw = point(sub, l1 ? H1 : H0, l1 ? W1 : W0, l1 ? (uint32_t)p.lv.start[1] : 0u, l1 ? 64u : pix_pitch, true);
+      sw = l1 ? 0.f : sw;
+      sw += __shfl_xor(sw, 1); sw += __shfl_xor(sw, 2);
+      if (sub == 0) sS[ql * 8 + m] = sw;
+      point(8 + (sub & 3), H2, W2, (uint32_t)p.lv.start[2], 64u, sub < 4);          // level 2
+    }
+
+    // ---- the gather: 12 units of 16 dword loads + 4 MFMAs; unit u + 1 is requested before unit u is multiplied
+    //   units 0-7: level 0 of head u (one A operand, four 32-channel chunks);  units 8-11: levels 1 / 2 of heads 2(u-8), 2(u-8)+1
+    const int64_t frame = (int64_t)H0 * W0 * p.ld0;
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x0 + (int64_t)b * frame), 0, (uint32_t)(frame * 2), 0x00020000);
+    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(planes + (int64_t)b * p.S1 * 32), 0, 0x80000000u, 0x00020000);
+    const uint32_t nb = (uint32_t)n * 4u;
+    uint32_t* gdst = reinterpret_cast<uint32_t*>(sG + ql * MR_GP);
+    float* pdst = reinterpret_cast<float*>(sP + ql * MR_PP);
+    constexpr int DEPTH = MOY_MRM_DEPTH;                            // units whose taps are in flight beside the one being multiplied
+    uint32_t tp[DEPTH + 1][16];
+    auto issue = [&](auto uc, uint32_t (&t)[16]) {
+      constexpr int u = decltype(uc)::value;
+      if constexpr (u < 8) {
+        const uint32_t voff = aB[u * 12] + nb;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          t[cc * 4 + 0] = __builtin_amdgcn_raw_buffer_load_b32(rs0, voff + cc * 64, 0, MOY_MRM_AUX);
+          t[cc * 4 + 1] = __builtin_amdgcn_raw_buffer_load_b32(rs0, voff + cc * 64, pix_pitch, MOY_MRM_AUX);
+          t[cc * 4 + 2] = __builtin_amdgcn_raw_buffer_load_b32(rs0, voff + cc * 64, row_pitch, MOY_MRM_AUX);
+          t[cc * 4 + 3] = __builtin_amdgcn_raw_buffer_load_b32(rs0, voff + cc * 64, row_pitch + pix_pitch, MOY_MRM_AUX);
+        }
+      } else {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int l = 1; l < 3; ++l) {
+            constexpr int h0 = (u - 8) * 2;
+            const uint32_t voff = aB[(h0 + hh) * 12 + l * 4] + nb;
+            const uint32_t sh = (uint32_t)(h0 + hh) * hs2, rp = (uint32_t)(l == 1 ? W1 : W2) * 64u;
+            uint32_t* tt = t + (hh * 2 + l - 1) * 4;
+            tt[0] = __builtin_amdgcn_raw_buffer_load_b32(rs1, voff, sh, MOY_MRM_AUX);
+            tt[1] = __builtin_amdgcn_raw_buffer_load_b32(rs1, voff, sh + 64u, MOY_MRM_AUX);
+            tt[2] = __builtin_amdgcn_raw_buffer_load_b32(rs1, voff, sh + rp, MOY_MRM_AUX);
+            tt[3] = __builtin_amdgcn_raw_buffer_load_b32(rs1, voff, sh + rp + 64u, MOY_MRM_AUX);
+          }
+      }
+    };
+    auto weights = [&](int e) {                                    // the A operand of entry e .. e+3 (the four points of a head and level)
+      const u32x4 w = *reinterpret_cast<const u32x4*>(aT + e * 8);
+      return u32x4{w.x & amask, w.y & amask, w.z & amask, w.w & amask};
+    };
+    auto consume = [&](auto uc, const uint32_t (&t)[16]) {
+      constexpr int u = decltype(uc)::value;
+      const f32x4 z{0.f, 0.f, 0.f, 0.f};
+      if constexpr (u < 8) {
+        const u32x4 a = weights(u * 12);
+        f32x4 d[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) d[cc] = mr_mfma<T>(z, a, u32x4{t[cc * 4], t[cc * 4 + 1], t[cc * 4 + 2], t[cc * 4 + 3]});
+        if (lane < 16) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) gdst[u * 64 + cc * 16 + lane] = DT<T>::pack2(d[cc].x + d[cc].z, d[cc].y + d[cc].w);
+        }
+      } else {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          constexpr int h0 = (u - 8) * 2;
+          const u32x4 a1 = weights((h0 + hh) * 12 + 4), a2 = weights((h0 + hh) * 12 + 8);
+          f32x4 d = mr_mfma<T>(z, a1, u32x4{t[hh * 8], t[hh * 8 + 1], t[hh * 8 + 2], t[hh * 8 + 3]});
+          d = mr_mfma<T>(d, a2, u32x4{t[hh * 8 + 4], t[hh * 8 + 5], t[hh * 8 + 6], t[hh * 8 + 7]});
+          if (lane < 16) *reinterpret_cast<float2*>(pdst + (h0 + hh) * 32 + lane * 2) = float2{d.x + d.z, d.y + d.w};
+        }
+      }
+    };
+    [&]<int... Us>(std::integer_sequence<int, Us...>) { (issue(std::integral_constant<int, Us>{}, tp[Us]), ...); }
+    (std::make_integer_sequence<int, DEPTH>{});
+    [&]<int... Us>(std::integer_sequence<int, Us...>) {
+      (([&] {
+         if constexpr (Us + DEPTH < 12) issue(std::integral_constant<int, Us + DEPTH>{}, tp[(Us + DEPTH) % (DEPTH + 1)]);
+         __builtin_amdgcn_sched_barrier(0);
+         consume(std::integral_constant<int, Us>{}, tp[Us % (DEPTH + 1)]);
+       }()), ...);
+    }(std::make_integer_sequence<int, 12>{});
+  }
+  __syncthreads();
+
+  // ---- projection: wave w owns head w.  A = W_h rows (out channel t*16 + r), B = g of the 16 queries (column r = query r)
+  const int r = lane & 15, q4 = lane >> 4;
+  const T* wc = static_cast<const T*>(p.wc);
+  T* out = static_cast<T*>(p.out);
+  {
+    const int h = wave;
+    u32x4 wa[2][4], gb[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int pn = 0; pn < 4; ++pn)
+        wa[t][pn] = *reinterpret_cast<const u32x4*>(wc + (h * 32 + t * 16 + r) * 128 + pn * 32 + q4 * 8);
+#pragma unroll
+    for (int pn = 0; pn < 4; ++pn) gb[pn] = *reinterpret_cast<const u32x4*>(sG + r * MR_GP + h * 256 + pn * 64 + q4 * 16);
+    f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int pn = 0; pn < 4; ++pn)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc2[t] = mr_mfma<T>(acc2[t], wa[t][pn], gb[pn]);
+    const float s = sS[r * 8 + h];
+    const int row = row0 + r;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ch = h * 32 + t * 16 + q4 * 4;
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bc + ch);
+      const f32x4 part = *reinterpret_cast<const f32x4*>(sP + r * MR_PP + ch * 4);
+      const f32x4 v = acc2[t] + bias * s + part;
+      if (row < p.nrows) *reinterpret_cast<u32x2*>(out + (int64_t)row * p.ldo + ch) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+    }
+  }
+}
+
 }  // namespace moy
 
 using namespace moy;
@@ -308,6 +535,16 @@ extern "C" int moy_msda_raw0(const moy_msda_raw_args* a, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   p.ngroups = (p.nrows + MR_QB - 1) / MR_QB;
   const int nblk = (p.ngroups + 7) / 8 * 8;          // a multiple of the 8 XCDs: XCD x walks the x-th eighth of the groups
+  // the tap sums on the matrix cores: three levels, every one with a 2 x 2 window inside it (MOY_MR_MFMA=0: the vector-ALU form)
+  static int mfma = -1;
+  if (mfma < 0) { const char* e = getenv("MOY_MR_MFMA"); mfma = e ? atoi(e) : 1; }
+  bool small = false;
+  for (int l = 0; l < a->L; ++l) small |= p.lv.H[l] < 2 || p.lv.W[l] < 2;
+  if (mfma && a->L == 3 && !small) {
+    if (a->dtype == MOY_BF16) hipLaunchKernelGGL((msda_raw_mfma_kernel<bf16_t>), dim3(nblk), dim3(64 * MRM_NW), 0, st, p);
+    else hipLaunchKernelGGL((msda_raw_mfma_kernel<f16_t>), dim3(nblk), dim3(64 * MRM_NW), 0, st, p);
+    return launch_status();
+  }
   if (a->dtype == MOY_BF16) hipLaunchKernelGGL((msda_raw_kernel<bf16_t>), dim3(nblk), dim3(256), 0, st, p);
   else hipLaunchKernelGGL((msda_raw_kernel<f16_t>), dim3(nblk), dim3(256), 0, st, p);
   return launch_status();

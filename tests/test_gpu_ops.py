@@ -937,13 +937,16 @@ def test_msda_fused_vs_oracle(dt):
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,Lq,shapes,ld0", [(2, 37, [(12, 20), (6, 10), (3, 5)], 128), (3, 300, [(76, 136), (38, 68), (19, 34)], 128),
-                                            (1, 21, [(9, 7)], 192), (2, 50, [(2, 2), (4, 4)], 136)])
+                                            (1, 21, [(9, 7)], 192), (2, 50, [(2, 2), (4, 4)], 136), (2, 45, [(5, 2), (2, 3), (2, 2)], 128),
+                                            (1, 33, [(7, 9), (1, 5), (3, 3)], 128)])
 def test_msda_raw_level0_gather_then_project_vs_oracle(dt, B, Lq, shapes, ld0):
     """Round 5: level 0 of the deformable attention gathered RAW and projected after the bilinear sum (csrc/msda_raw.hip):
     W_h . (sum_p a_p bilinear(x)(loc_p)) + c_h . sum_p a_p (in-range corner weights) == sum_p a_p bilinear(W x + c)(loc_p)
     (transformer.py:255-287 over nn/modules/utils.py:41-78, zero padding of the PROJECTED map).  Against the oracle's sampling core on
     the explicitly projected level-0 map (fp32 product of the same 16-bit operands) + the given planes of the other levels; offsets large
-    enough that samples leave the level on every side, a box in a corner, one level only, a level of 2 x 2, level 0 as a channel slice."""
+    enough that samples leave the level on every side, a box in a corner, one level only, a level of 2 x 2, level 0 as a channel slice.
+    Three levels of at least 2 x 2 run the form with the tap sums on the matrix cores (weights enter it as T(w) + T(w - T(w))), every other
+    shape (one / two levels, a level one pixel high) the vector-ALU form."""
     H0, W0 = shapes[0]
     S1 = sum(h * w for h, w in shapes[1:])
     nl = len(shapes)
