@@ -256,7 +256,9 @@ int moy_mlp_head(const void* X, int64_t ldx, const int32_t* x_rows, int M, const
  * T = bf16 / fp16 (fp32 returns MOY_ENOSYS: moy_gemm x 3 + moy_mlp_head / moy_rowdot, the parity path).  All weight matrices
  * are T, [out features, in features] row-major with the in-feature pitch of their own width (256, or d_ffn for W2);
  * biases / LayerNorm vectors fp32; w2 fp32 [4, 256]; d_ffn a multiple of 256; hidden width 256.  Every intermediate is rounded
- * to T where the separate launches store it; the LayerNorm statistics are one-pass (E[v^2] - mean^2). */
+ * to T where the separate launches store it; the LayerNorm statistics are one-pass (E[v^2] - mean^2).  d_ffn <= 2048 (MOY_ENOSYS
+ * beyond: linear1's bias is staged on chip whole); every T matrix 16-byte aligned with a row pitch that is a multiple of 8 elements
+ * (samp, e1, out, out_xp, qpos: whole 512-byte rows move in 16-byte pieces). */
 typedef struct moy_decoder_tail_args {
   const void* samp; int64_t ld_samp;   /* T [M, 256] */
   const void* e1;   int64_t ld_e1;     /* T [M, 256] residual */
@@ -285,7 +287,8 @@ int moy_decoder_tail(const moy_decoder_tail_args* args, void* stream);
  *                                                        attention_weights of with_pos_embed(embed, query_pos), :644
  * Woa = [sampling_offsets.weight ; attention_weights.weight] as [rows, 256] T with rows = max(256, n_oa) (zero rows past n_oa),
  * boa fp32 [n_oa]; n_oa = 8 heads * levels * 4 points * 3 (a multiple of 32, <= 512).  e1 is rounded to T exactly where the
- * separate launches store it; e1 + qpos is formed as moy_gemm forms its A2 operand.  MOY_ENOSYS for fp32 (moy_gemm x 2). */
+ * separate launches store it; e1 + qpos is formed as moy_gemm forms its A2 operand.  MOY_ENOSYS for fp32 (moy_gemm x 2).
+ * attn, x, qpos, e1: 16-byte aligned, row pitch a multiple of 8 elements. */
 typedef struct moy_decoder_mid_args {
   const void* attn; int64_t ld_attn;   /* T [M, 256]: self-attention output before out_proj */
   const void* x;    int64_t ld_x;      /* T [M, 256]: the layer input (residual) */

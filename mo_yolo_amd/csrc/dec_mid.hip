@@ -30,7 +30,9 @@ __device__ __forceinline__ f32x4 mid_mfma<f16_t>(f32x4 acc, u32x4 w, u32x4 a) {
 }
 
 constexpr int MID_BM = 128, MID_NW = 8;
-constexpr int MID_LDS = 2 * MID_BM * 512 + MID_BM * MID_NW * 8;
+// fp32 vectors staged in LDS once per block (round 5, as dec_tail.hip): [bo | ln_g | ln_b | boa[0 .. 512)]
+constexpr int MID_V_BO = 0, MID_V_LNG = 256, MID_V_LNB = 512, MID_V_BOA = 768, MID_V_N = 768 + 512;
+constexpr int MID_LDS = 2 * MID_BM * 512 + MID_BM * MID_NW * 8 + MID_V_N * 4;
 
 template <typename T>
 __global__ __launch_bounds__(64 * MID_NW) void decoder_mid_kernel(const moy_decoder_mid_args p) {
@@ -40,6 +42,7 @@ __global__ __launch_bounds__(64 * MID_NW) void decoder_mid_kernel(const moy_deco
   unsigned char* XA = smem;
   unsigned char* XB = smem + BM * 512;
   float* P = reinterpret_cast<float*>(smem + 2 * BM * 512);      // [BM][NW][2] floats: LayerNorm partials
+  const float* V = reinterpret_cast<const float*>(smem + 2 * BM * 512 + BM * NW * 8);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
@@ -84,13 +87,24 @@ __global__ __launch_bounds__(64 * MID_NW) void decoder_mid_kernel(const moy_deco
   auto put4 = [&](unsigned char* X, int row, int n, f32x4 v) {
     *reinterpret_cast<u32x2*>(tile_ptr(X, row, n)) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
   };
+  auto get4 = [&](unsigned char* X, int row, int n) {
+    const u32x2 w = *reinterpret_cast<const u32x2*>(tile_ptr(X, row, n));
+    return f32x4{DT<T>::lo(w.x), DT<T>::hi(w.x), DT<T>::lo(w.y), DT<T>::hi(w.y)};
+  };
 
-  // ---- P0: attention output tile -> XA, out_proj weights -> registers
+  // ---- P0: attention output tile -> XA, the residual tile x -> XB (e1 replaces it in place), the fp32 vectors -> V, out_proj weights ->
+  //      registers; the query_pos tile is requested here too and waits in registers until the LayerNorm is through.  Round 5, as in
+  //      dec_tail.hip: no epilogue reads global memory -- vector-memory results return in issue order, so a bias / residual / LayerNorm /
+  //      query_pos load issued after a product came back only behind the weights of the NEXT product requested during it.
+  constexpr int NLD = BM * 32 / NTHR;
+  u32x4 qr[NLD];
   {
     const T* Xg = static_cast<const T*>(p.attn);
-    u32x4 xr[BM * 32 / NTHR];
+    const T* Rg = static_cast<const T*>(p.x);
+    const T* Qg = static_cast<const T*>(p.qpos);
+    u32x4 xr[NLD], rr[NLD];
 #pragma unroll
-    for (int k = 0; k < BM * 32 / NTHR; ++k) {
+    for (int k = 0; k < NLD; ++k) {
       const int id = tid + k * NTHR, row = id >> 5, c = id & 31;
       const int m = min(m0 + row, p.M - 1);
       xr[k] = *reinterpret_cast<const u32x4*>(Xg + (int64_t)m * p.ld_attn + c * 8);
@@ -98,9 +112,32 @@ __global__ __launch_bounds__(64 * MID_NW) void decoder_mid_kernel(const moy_deco
     req_half(0, p.Wo, wave * WC);
     req_half(1, p.Wo, wave * WC);
 #pragma unroll
-    for (int k = 0; k < BM * 32 / NTHR; ++k) {
+    for (int k = 0; k < NLD; ++k) {
+      const int id = tid + k * NTHR, row = id >> 5, c = id & 31;
+      const int m = min(m0 + row, p.M - 1);
+      rr[k] = *reinterpret_cast<const u32x4*>(Rg + (int64_t)m * p.ld_x + c * 8);
+    }
+    {
+      float* Vw = const_cast<float*>(V);
+      const float* src = wave == 0 ? p.bo : wave == 1 ? p.ln_g : p.ln_b;
+      if (wave < 3) *reinterpret_cast<f32x4*>(Vw + wave * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(src + lane * 4);
+      if (tid * 4 < p.n_oa) *reinterpret_cast<f32x4*>(Vw + MID_V_BOA + tid * 4) = *reinterpret_cast<const f32x4*>(p.boa + tid * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int id = tid + k * NTHR, row = id >> 5, c = id & 31;
+      const int m = min(m0 + row, p.M - 1);
+      qr[k] = *reinterpret_cast<const u32x4*>(Qg + (int64_t)m * p.ld_qpos + c * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
       const int id = tid + k * NTHR, row = id >> 5, c = id & 31;
       *reinterpret_cast<u32x4*>(XA + row * 512 + ((c ^ (row & 15)) << 4)) = xr[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int id = tid + k * NTHR, row = id >> 5, c = id & 31;
+      *reinterpret_cast<u32x4*>(XB + row * 512 + ((c ^ (row & 15)) << 4)) = rr[k];
     }
   }
   __syncthreads();
@@ -113,17 +150,12 @@ __global__ __launch_bounds__(64 * MID_NW) void decoder_mid_kernel(const moy_deco
   // ---- P1: e1 = LN1(attn . Wo^T + bo + x) -> XB and global
   gemm_acc(XA, acc, p.Woa, wave * WC);               // next: offsets | weights, columns [wave*32, +32) of the first 256
   {
-    const T* Rg = static_cast<const T*>(p.x);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
+    for (int j = 0; j < NT; ++j) {                   // residual rows: from the x tile in XB, the very bytes e1 replaces below
       const int n = wave * WC + j * 16 + q * 4;
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bo + n);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(V + MID_V_BO + n);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int m = min(m0 + i * 16 + r, p.M - 1);
-        const u32x2 rs = *reinterpret_cast<const u32x2*>(Rg + (int64_t)m * p.ld_x + n);
-        acc[i][j] = acc[i][j] + bb + f32x4{DT<T>::lo(rs.x), DT<T>::hi(rs.x), DT<T>::lo(rs.y), DT<T>::hi(rs.y)};
-      }
+      for (int i = 0; i < MT; ++i) acc[i][j] = acc[i][j] + bb + get4(XB, i * 16 + r, n);
     }
     // one-pass LayerNorm over the 256 columns of every row (as dec_tail.hip)
 #pragma unroll
@@ -144,8 +176,8 @@ __global__ __launch_bounds__(64 * MID_NW) void decoder_mid_kernel(const moy_deco
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = wave * WC + j * 16 + q * 4;
-      gg[j] = *reinterpret_cast<const f32x4*>(p.ln_g + n);
-      bb2[j] = *reinterpret_cast<const f32x4*>(p.ln_b + n);
+      gg[j] = *reinterpret_cast<const f32x4*>(V + MID_V_LNG + n);
+      bb2[j] = *reinterpret_cast<const f32x4*>(V + MID_V_LNB + n);
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -168,14 +200,6 @@ __global__ __launch_bounds__(64 * MID_NW) void decoder_mid_kernel(const moy_deco
   // e1 rows leave in whole 512-byte rows; A' = e1 + query_pos -> XA (the attention tile is no longer needed)
   {
     T* Eg = static_cast<T*>(p.e1);
-    const T* Qg = static_cast<const T*>(p.qpos);
-    u32x4 qr[BM * 32 / NTHR];
-#pragma unroll
-    for (int k = 0; k < BM * 32 / NTHR; ++k) {
-      const int id = tid + k * NTHR, row = id >> 5, c = id & 31;
-      const int m = min(m0 + row, p.M - 1);
-      qr[k] = *reinterpret_cast<const u32x4*>(Qg + (int64_t)m * p.ld_qpos + c * 8);
-    }
 #pragma unroll
     for (int k = 0; k < BM * 32 / NTHR; ++k) {
       const int id = tid + k * NTHR, row = id >> 5, c = id & 31;
@@ -202,7 +226,7 @@ __global__ __launch_bounds__(64 * MID_NW) void decoder_mid_kernel(const moy_deco
   for (int j = 0; j < NT; ++j) {
     const int n = wave * WC + j * 16 + q * 4;
     if (n < p.n_oa) {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(p.boa + n);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(V + MID_V_BOA + n);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int m = m0 + i * 16 + r;
@@ -225,7 +249,7 @@ __global__ __launch_bounds__(64 * MID_NW) void decoder_mid_kernel(const moy_deco
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = 256 + g + j * 16 + q * 4;
-      if (m < p.M) *reinterpret_cast<f32x4*>(p.offaw + (int64_t)m * p.ld_oa + n) = a2[j] + *reinterpret_cast<const f32x4*>(p.boa + n);
+      if (m < p.M) *reinterpret_cast<f32x4*>(p.offaw + (int64_t)m * p.ld_oa + n) = a2[j] + *reinterpret_cast<const f32x4*>(V + MID_V_BOA + n);
     }
   }
 }
@@ -239,11 +263,11 @@ extern "C" int moy_decoder_mid(const moy_decoder_mid_args* a, void* stream) {
     return MOY_EINVAL;
   if (a->M <= 0 || a->n_oa <= 0 || (a->n_oa % 32) || a->n_oa > 512) return MOY_EINVAL;
   if (a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_ENOSYS;   // fp32: the separate launches (the parity path)
-  if ((a->ld_attn % 8) || (a->ld_x % 4) || (a->ld_qpos % 8) || (a->ld_e1 % 8) || (a->ld_oa % 4) || a->ld_attn < 256 || a->ld_x < 256 ||
+  if ((a->ld_attn % 8) || (a->ld_x % 8) || (a->ld_qpos % 8) || (a->ld_e1 % 8) || (a->ld_oa % 4) || a->ld_attn < 256 || a->ld_x < 256 ||
       a->ld_qpos < 256 || a->ld_e1 < 256 || a->ld_oa < a->n_oa)
     return MOY_EINVAL;
   if (!aligned16(a->attn) || !aligned16(a->qpos) || !aligned16(a->e1) || !aligned16(a->Wo) || !aligned16(a->Woa) || !aligned16(a->bo) ||
-      !aligned16(a->boa) || !aligned16(a->ln_g) || !aligned16(a->ln_b) || !aligned16(a->offaw) || (reinterpret_cast<uintptr_t>(a->x) & 7))
+      !aligned16(a->boa) || !aligned16(a->ln_g) || !aligned16(a->ln_b) || !aligned16(a->offaw) || !aligned16(a->x))
     return MOY_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   static bool attr_set = false;          // > 64 KiB of dynamic LDS: opt in once per kernel symbol

@@ -34,20 +34,48 @@ __device__ __forceinline__ float tail_inv_sigmoid(float x) {   // nn/modules/uti
   return logf(fmaxf(x, 1e-5f) / fmaxf(1.f - x, 1e-5f));
 }
 
-constexpr int TAIL_BM = 128, TAIL_NW = 8;
-constexpr int TAIL_LDS = 2 * TAIL_BM * 512 + TAIL_BM * TAIL_NW * 16;
+#ifndef MOY_TAIL_NW
+#define MOY_TAIL_NW 8       // waves of a block: 8 (two per SIMD, 32 output columns each) or 4 (one per SIMD, 64 columns, 512 registers)
+#endif
+#ifndef MOY_TAIL_PD
+#define MOY_TAIL_PD 1       // steps of activation fragments requested ahead of the MFMAs that use them
+#endif
+constexpr int TAIL_BM = 128, TAIL_NW = MOY_TAIL_NW;
+#ifndef MOY_TAIL_RS
+#define MOY_TAIL_RS 8       // row parts of a product's step walk: 8 = one 16-row fragment per step.  With 4 (two fragments in flight per buffer) the
+#endif                      // kernel needed 38 registers more than it has, and one of the spilled values was reloaded INSIDE the FFN loop: a scratch
+                            // load is a vector-memory operation, results return in order, so that reload waited for the weight prefetch of the next product
+
+// fp32 vectors of the chain staged in LDS once per block (round 5): [bp | ln2_g | ln2_b | b2 | ln3_g | ln3_b | c0 | b1[0 .. 2048)]
+constexpr int TAIL_V_BP = 0, TAIL_V_LN2G = 256, TAIL_V_LN2B = 512, TAIL_V_B2 = 768, TAIL_V_LN3G = 1024, TAIL_V_LN3B = 1280, TAIL_V_C0 = 1536,
+              TAIL_V_B1 = 1792, TAIL_MAX_FFN = 2048, TAIL_V_N = 1792 + TAIL_MAX_FFN;
+constexpr int TAIL_LDS = 2 * TAIL_BM * 512 + TAIL_BM * TAIL_NW * 16 + TAIL_V_N * 4;
 
 template <typename T, int ABL = 0>       // ABL 1: timing-only build that keeps the FIRST weight chunk for every product (MOY_TAIL_ABL=1; results garbage)
+                                         // ABL 2: s_memtime stamps of wave 0 per phase, written over the head of `out` (MOY_TAIL_ABL=2; tools/probes/tail_diag.py)
 __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_decoder_tail_args p) {
-  constexpr int BM = TAIL_BM, NW = TAIL_NW, NTHR = 64 * NW, MT = BM / 16, NT = 2, WC = 32;
+  constexpr int BM = TAIL_BM, NW = TAIL_NW, NTHR = 64 * NW, MT = BM / 16, NT = 16 / NW, WC = 256 / NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* XA = smem;
   unsigned char* XB = smem + BM * 512;
   float* P = reinterpret_cast<float*>(smem + 2 * BM * 512);      // [BM][NW][4] floats: LayerNorm / box-head partials
+  const float* V = reinterpret_cast<const float*>(smem + 2 * BM * 512 + BM * NW * 16);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.x * BM;
+  const int ntiles = (p.M + BM - 1) / BM;
+  unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+  unsigned long long wt[6] = {0, 0, 0, 0, 0, 0};        // ABL 2: every wave's clock through FFN chunk 1 (block 0, its last tile)
+  auto stamp = [&](int i) {
+    if constexpr (ABL >= 2) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long tt = __builtin_amdgcn_s_memtime();
+      ph[i] += tt - tprev;
+      tprev = tt;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if constexpr (ABL >= 2) tprev = __builtin_amdgcn_s_memtime();
 
   // This wave's 32 output rows of the current [*, pitch] weight matrix (k columns koff .. koff+255) as two K HALVES of four
   // 32-wide panels: wa[0] = panels 0-3, wa[1] = panels 4-7.  Round 3: a product walks its K halves OUTERMOST (both row halves of
@@ -59,7 +87,7 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
   struct WSrc { const void* W; int row0, pitch, koff; };
   bool w_loaded = false;
   auto req_half = [&](int h, const WSrc& w) {
-    if constexpr (ABL == 1) { if (w_loaded) return; }
+    if constexpr (ABL == 1 || ABL == 3) { if (w_loaded) return; }
     if (!w.W) return;
     const T* Wg = static_cast<const T*>(w.W) + (int64_t)(w.row0 + wave * WC) * w.pitch + w.koff + h * 128;
 #pragma unroll
@@ -67,29 +95,50 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
 #pragma unroll
       for (int pn = 0; pn < 4; ++pn) wa[h][j][pn] = *reinterpret_cast<const u32x4*>(Wg + (int64_t)(j * 16 + r) * w.pitch + pn * 32 + q * 8);
   };
+  // Round 5: one 32-wide PANEL at a time.  A product now walks its panels outermost (panel pn over every row part, then pn + 1; every
+  // accumulator still sees its panels in the order 0..7, so results are unchanged) and the moment a panel has been consumed its registers
+  // are re-requested with that panel of the NEXT product: every request is 7/8 of a product + the epilogue ahead of its use (by halves it
+  // was 1/2), and the requests are spread over the product instead of arriving at the texture unit in two bursts of 16 per wave.  The
+  // per-wave clocks (MOY_TAIL_ABL=2) had shown the second wave of every SIMD finishing a product at 6.1-7.7 k cycles against 3.1-3.6 k of
+  // the first, and 5.0 k with the weight traffic ablated: its weights, served after the first waves', arrived late.
+  const uint32_t voff_256 = (uint32_t)((r * 256 + q * 8) * 2), voff_ffn = (uint32_t)((r * p.d_ffn + q * 8) * 2);
+  auto req_panel = [&](int pn, const WSrc& w) {
+    if constexpr (ABL == 1 || ABL == 3) { if (w_loaded) return; }
+    if (!w.W) return;
+    // buffer loads: the matrix as the descriptor's base, the lane part of the address one 32-bit register per row pitch (r * pitch + q * 8),
+    // everything else wave-uniform in the scalar offset -- no 64-bit per-lane pointers held across the products
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w.W), 0, 0x7fffffff, 0x00020000);
+    const uint32_t voff = w.pitch == 256 ? voff_256 : voff_ffn;
+    const uint32_t so = (uint32_t)(((w.row0 + wave * WC) * w.pitch + w.koff + pn * 32) * 2);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      wa[pn >> 2][j][pn & 3] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, so + (uint32_t)(j * 16 * w.pitch * 2), 0));
+  };
   const int lbase = r * 512 + ((q ^ r) << 4);      // fragment of row i*16 + r, chunk (pn*4 + q) ^ r
   // rows in two halves of 64: 16 fragment registers live instead of 32
   auto gemm_acc = [&](const unsigned char* As, f32x4 (&acc)[MT][NT], const WSrc& next) {
-    constexpr int RS = 4, HM = MT / RS, NSTEP = 8 * RS;   // step s = (K half kh, row part rp, panel kh * 4 + s % 4), K half outermost;
-    u32x4 af[2][HM];                                      // the fragments of step s+1 are requested before the MFMAs of step s
+    constexpr int RS = MOY_TAIL_RS, HM = MT / RS, NSTEP = 8 * RS;   // step s = (panel s / RS, row part s % RS), panel outermost
+    constexpr int PD = MOY_TAIL_PD;
+    u32x4 af[PD + 1][HM];                                 // the fragments of step s+PD are requested before the MFMAs of step s
     auto frag = [&](int s_, u32x4 (&buf)[HM]) {
-      const int kh = s_ / (4 * RS), rp = (s_ >> 2) % RS, pn = kh * 4 + (s_ & 3);
+      const int pn = s_ / RS, rp = s_ % RS;
 #pragma unroll
       for (int i = 0; i < HM; ++i) buf[i] = *reinterpret_cast<const u32x4*>(As + ((lbase ^ (pn * 64)) + (rp * HM + i) * 8192));
     };
-    frag(0, af[0]);
+#pragma unroll
+    for (int s_ = 0; s_ < PD; ++s_) frag(s_, af[s_]);
 #pragma unroll
     for (int s_ = 0; s_ < NSTEP; ++s_) {
-      const int kh = s_ / (4 * RS), rp = (s_ >> 2) % RS, p4 = s_ & 3;
-      if (s_ + 1 < NSTEP) frag(s_ + 1, af[(s_ + 1) & 1]);
+      const int pn = s_ / RS, rp = s_ % RS, kh = pn >> 2, p4 = pn & 3;
+      if (s_ + PD < NSTEP) frag(s_ + PD, af[(s_ + PD) % (PD + 1)]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < HM; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[rp * HM + i][j] = tail_mfma<T>(acc[rp * HM + i][j], wa[kh][j][p4], af[s_ & 1][i]);
+        for (int j = 0; j < NT; ++j) acc[rp * HM + i][j] = tail_mfma<T>(acc[rp * HM + i][j], wa[kh][j][p4], af[s_ % (PD + 1)][i]);
       __builtin_amdgcn_sched_barrier(0);
-      if (s_ == NSTEP / 2 - 1) { req_half(0, next); __builtin_amdgcn_sched_barrier(0); }   // K half 0 consumed: its registers take the next product's
-      if (s_ == NSTEP - 1) { req_half(1, next); __builtin_amdgcn_sched_barrier(0); if constexpr (ABL == 1) w_loaded = true; }
+      if (rp == RS - 1) { req_panel(pn, next); __builtin_amdgcn_sched_barrier(0); }        // panel pn consumed: its registers take the next product's
+      if (s_ == NSTEP - 1) { if constexpr (ABL == 1 || ABL == 3) w_loaded = true; }
     }
   };
   auto zero = [&](f32x4 (&acc)[MT][NT]) {
@@ -127,7 +176,7 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = wave * WC + j * 16 + q * 4;
-      gg[j] = *reinterpret_cast<const f32x4*>(g + n);
+      gg[j] = *reinterpret_cast<const f32x4*>(g + n);             // (LDS: the staged vectors)
       bb[j] = *reinterpret_cast<const f32x4*>(be + n);
     }
 #pragma unroll
@@ -148,84 +197,144 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
     }
   };
 
-  // ---- P0: sampling output tile -> XA, output_proj weights -> registers
+  // ---- P0: sampling output tile -> XA, residual tile e1 -> XB (e2 overwrites it in place), the fp32 vectors -> V, output_proj
+  //      weights -> registers.  Round 5: NO epilogue of the chain reads global memory any more.  Vector-memory results return in issue
+  //      order, so a bias / residual / LayerNorm load issued in an epilogue came back only after BOTH weight halves of the NEXT product,
+  //      requested just before it (32 x 16-byte loads per lane): the stamps (MOY_TAIL_ABL=2) showed the epilogues at twice the time of
+  //      the products they follow.  The weight requests now overlap the epilogues instead of gating them.
+  constexpr int NREF = BM * 4 / NTHR;              // (row, output) pairs of the box refinement per thread
+  constexpr int NLD = BM * 32 / NTHR;              // 16-byte pieces of a 128 x 256 tile per thread
+  if ((int)blockIdx.x >= ntiles) return;
+  const int m0 = blockIdx.x * BM;
+  // ---- P0: sampling output tile -> XA, residual tile e1 -> XB (e2 overwrites it in place), the fp32 vectors -> V, output_proj weights ->
+  //      registers.  NO epilogue of the chain reads global memory (round 5): vector-memory results return in issue order, so a bias /
+  //      residual / LayerNorm load issued in an epilogue came back only after the weights of the NEXT product requested just before it;
+  //      the stamps (MOY_TAIL_ABL=2) showed the epilogues at twice the time of the products they follow.
+  //      (Measured and dropped: the block persistent over its row tiles with the next tile's rows requested into registers during the
+  //      box head -- the cold start of a tile is 17-18 k of its 136 k cycles -- : 32-64 more registers live across the tile loop, the
+  //      allocator spilled 130-190 values and their reloads queue behind the weight requests: 264 us against 207.)
+  float ref_in_r[NREF];
   {
     const T* Xg = static_cast<const T*>(p.samp);
-    u32x4 xr[BM * 32 / NTHR];
+    const T* Eg = static_cast<const T*>(p.e1);
+    u32x4 xr[NLD], er[NLD];
 #pragma unroll
-    for (int k = 0; k < BM * 32 / NTHR; ++k) {
+    for (int k = 0; k < NLD; ++k) {
       const int id = tid + k * NTHR, row = id >> 5, c = id & 31;
       const int m = min(m0 + row, p.M - 1);
       xr[k] = *reinterpret_cast<const u32x4*>(Xg + (int64_t)m * p.ld_samp + c * 8);
     }
     { const WSrc w0{p.Wp, 0, 256, 0}; req_half(0, w0); req_half(1, w0); }
 #pragma unroll
-    for (int k = 0; k < BM * 32 / NTHR; ++k) {
+    for (int k = 0; k < NLD; ++k) {
+      const int id = tid + k * NTHR, row = id >> 5, c = id & 31;
+      const int m = min(m0 + row, p.M - 1);
+      er[k] = *reinterpret_cast<const u32x4*>(Eg + (int64_t)m * p.ld_e1 + c * 8);
+    }
+    {
+      float* Vw = const_cast<float*>(V);
+#pragma unroll
+      for (int v = 0; v < 7; v += NW) {
+        const int vv = v + wave;
+        const float* src = vv == 0 ? p.bp : vv == 1 ? p.ln2_g : vv == 2 ? p.ln2_b : vv == 3 ? p.b2 : vv == 4 ? p.ln3_g : vv == 5 ? p.ln3_b : p.c0;
+        if (vv < 7) *reinterpret_cast<f32x4*>(Vw + vv * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(src + lane * 4);
+      }
+      for (int i = tid * 4; i < p.d_ffn; i += NTHR * 4) *reinterpret_cast<f32x4*>(Vw + TAIL_V_B1 + i) = *reinterpret_cast<const f32x4*>(p.b1 + i);
+    }
+#pragma unroll
+    for (int k = 0; k < NREF; ++k) {
+      const int m = m0 + ((tid + k * NTHR) >> 2);
+      ref_in_r[k] = m < p.M ? p.ref_in[(int64_t)m * 4 + (tid & 3)] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
       const int id = tid + k * NTHR, row = id >> 5, c = id & 31;
       *reinterpret_cast<u32x4*>(XA + row * 512 + ((c ^ (row & 15)) << 4)) = xr[k];
     }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int id = tid + k * NTHR, row = id >> 5, c = id & 31;
+      *reinterpret_cast<u32x4*>(XB + row * 512 + ((c ^ (row & 15)) << 4)) = er[k];
+    }
   }
   __syncthreads();
+  stamp(0);
 
   f32x4 acc[MT][NT];
   // ---- P1: e2 = LN2(samp . Wp^T + bp + e1) -> XB
   {
     zero(acc);
     gemm_acc(XA, acc, WSrc{p.W1, 0, 256, 0});         // next: the first FFN chunk, in flight under the second K half and the LayerNorm
+    stamp(1);
     __builtin_amdgcn_sched_barrier(0);
-    const T* Eg = static_cast<const T*>(p.e1);       // residual rows: 8 bytes per lane and sub-tile
+
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
+    for (int j = 0; j < NT; ++j) {                   // residual rows: from the e1 tile in XB, the very bytes e2 replaces below
       const int n = wave * WC + j * 16 + q * 4;
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bp + n);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(V + TAIL_V_BP + n);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int m = min(m0 + i * 16 + r, p.M - 1);
-        const u32x2 rs = *reinterpret_cast<const u32x2*>(Eg + (int64_t)m * p.ld_e1 + n);
-        acc[i][j] = acc[i][j] + bb + f32x4{DT<T>::lo(rs.x), DT<T>::hi(rs.x), DT<T>::lo(rs.y), DT<T>::hi(rs.y)};
-      }
+      for (int i = 0; i < MT; ++i) acc[i][j] = acc[i][j] + bb + get4(XB, i * 16 + r, n);
     }
-    layer_norm(acc, p.ln2_g, p.ln2_b);
+    layer_norm(acc, V + TAIL_V_LN2G, V + TAIL_V_LN2B);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) put4(XB, i * 16 + r, wave * WC + j * 16 + q * 4, acc[i][j]);
   }
+  stamp(12);
   __syncthreads();
+  stamp(2);
 
   // ---- P2: FFN in chunks of 256 hidden units; acc3 accumulates linear2
   f32x4 acc3[MT][NT];
   zero(acc3);
   const int nchunk = p.d_ffn >> 8;
+  auto wstamp = [&](int c, int i) {
+    if constexpr (ABL >= 2) {
+      if (c == 1) { __builtin_amdgcn_sched_barrier(0); wt[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+    }
+  };
   for (int c = 0; c < nchunk; ++c) {
     zero(acc);
-    gemm_acc(XB, acc, WSrc{p.W2, 0, p.d_ffn, c * 256});   // weights: W1 rows [c*256 + wave*32, +32); next: linear2, this wave's 32 output rows, k slice of chunk c
+    wstamp(c, 0);
+    gemm_acc(XB, acc, WSrc{p.W2, 0, p.d_ffn, c * 256});
+    wstamp(c, 1);   // weights: W1 rows [c*256 + wave*32, +32); next: linear2, this wave's 32 output rows, k slice of chunk c
+    stamp(3);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = wave * WC + j * 16 + q * 4;
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b1 + c * 256 + n);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(V + TAIL_V_B1 + c * 256 + n);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
         put4(XA, i * 16 + r, n, __builtin_elementwise_max(acc[i][j] + bb, f32x4{0.f, 0.f, 0.f, 0.f}));
     }
+    stamp(13);
+    wstamp(c, 2);
     __syncthreads();
+    wstamp(c, 3);
+    stamp(4);
     gemm_acc(XA, acc3, c + 1 < nchunk ? WSrc{p.W1, (c + 1) * 256, 256, 0} : WSrc{p.B0, 0, 256, 0});   // next: the following chunk, or the box head's first layer
+    stamp(14);
+    wstamp(c, 4);
     __syncthreads();                                 // XA is rewritten by the next chunk (or by e3 below)
+    wstamp(c, 5);
+    stamp(5);
   }
   // e3 = LN3(acc3 + b2 + e2) -> XA, and out
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = wave * WC + j * 16 + q * 4;
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b2 + n);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(V + TAIL_V_B2 + n);
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc3[i][j] = acc3[i][j] + bb + get4(XB, i * 16 + r, n);
   }
-  layer_norm(acc3, p.ln3_g, p.ln3_b);
+  layer_norm(acc3, V + TAIL_V_LN3G, V + TAIL_V_LN3B);
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) put4(XA, i * 16 + r, wave * WC + j * 16 + q * 4, acc3[i][j]);
   __syncthreads();
+  stamp(6);
   {
     T* Og = static_cast<T*>(p.out);
     // round 3: optionally also out + query_pos (the q = k operand of the NEXT layer's self-attention, transformer.py:637-638),
@@ -252,19 +361,31 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
   }
 
   // ---- P3: box head on e3 (XA): t1 -> XB, t2 in registers, 4 dots per row, refinement
+  stamp(7);
   zero(acc);
   gemm_acc(XA, acc, WSrc{p.B1, 0, 256, 0});
+  stamp(8);
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = wave * WC + j * 16 + q * 4;
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(p.c0 + n);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(V + TAIL_V_C0 + n);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
       put4(XB, i * 16 + r, n, __builtin_elementwise_max(acc[i][j] + bb, f32x4{0.f, 0.f, 0.f, 0.f}));
   }
   __syncthreads();
+  stamp(9);
+  f32x4 c1v[NT], w2v[NT][4];                       // the last epilogue's vectors: requested before the product (nothing is queued ahead of them)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = wave * WC + j * 16 + q * 4;
+    c1v[j] = *reinterpret_cast<const f32x4*>(p.c1 + n);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) w2v[j][o] = *reinterpret_cast<const f32x4*>(p.w2 + o * 256 + n);
+  }
   zero(acc);
   gemm_acc(XB, acc, WSrc{nullptr, 0, 0, 0});
+  stamp(10);
   float part[MT][4];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -272,18 +393,14 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
     for (int o = 0; o < 4; ++o) part[i][o] = 0.f;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int n = wave * WC + j * 16 + q * 4;
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(p.c1 + n);
-    f32x4 w2v[4];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) w2v[o] = *reinterpret_cast<const f32x4*>(p.w2 + o * 256 + n);
+    const f32x4 bb = c1v[j];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       f32x4 v = __builtin_elementwise_max(acc[i][j] + bb, f32x4{0.f, 0.f, 0.f, 0.f});
       const uint32_t lo = DT<T>::pack2(v.x, v.y), hi = DT<T>::pack2(v.z, v.w);
       v = f32x4{DT<T>::lo(lo), DT<T>::hi(lo), DT<T>::lo(hi), DT<T>::hi(hi)};
 #pragma unroll
-      for (int o = 0; o < 4; ++o) part[i][o] += (v.x * w2v[o].x + v.y * w2v[o].y) + (v.z * w2v[o].z + v.w * w2v[o].w);
+      for (int o = 0; o < 4; ++o) part[i][o] += (v.x * w2v[j][o].x + v.y * w2v[j][o].y) + (v.z * w2v[j][o].z + v.w * w2v[j][o].w);
     }
   }
 #pragma unroll
@@ -301,16 +418,27 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
       *reinterpret_cast<f32x4*>(P + ((i * 16 + r) * NW + wave) * 4) = f32x4{part[i][0], part[i][1], part[i][2], part[i][3]};
   }
   __syncthreads();
-  static_assert(BM * 4 == NTHR, "one (row, output) per thread");
-  {
-    const int row = tid >> 2, o = tid & 3, m = m0 + row;
+#pragma unroll
+  for (int k = 0; k < NREF; ++k) {
+    const int row = (tid + k * NTHR) >> 2, o = tid & 3, m = m0 + row;
     if (m < p.M) {
       const float* pr = P + row * NW * 4 + o;
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) v += pr[w * 4];
       v += p.c2[o];
-      p.ref_out[(int64_t)m * 4 + o] = sigmoidf_(v + tail_inv_sigmoid(p.ref_in[(int64_t)m * 4 + o]));
+      p.ref_out[(int64_t)m * 4 + o] = sigmoidf_(v + tail_inv_sigmoid(ref_in_r[k]));
+    }
+  }
+  stamp(11);
+  if constexpr (ABL >= 2) {
+    if ((blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && tid == 0) {
+      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.out) + (blockIdx.x ? 16 : 0);
+      for (int i = 0; i < 16; ++i) dbg[i] = ph[i];
+    }
+    if (blockIdx.x == 0 && lane == 0) {
+      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.out) + 64 + wave * 8;
+      for (int i = 0; i < 6; ++i) dbg[i] = wt[i];
     }
   }
 }
@@ -324,14 +452,15 @@ extern "C" int moy_decoder_tail(const moy_decoder_tail_args* a, void* stream) {
       !a->ln3_b || !a->out || !a->B0 || !a->c0 || !a->B1 || !a->c1 || !a->w2 || !a->c2 || !a->ref_in || !a->ref_out)
     return MOY_EINVAL;
   if (a->M <= 0 || a->d_ffn <= 0 || (a->d_ffn % 256)) return MOY_EINVAL;
+  if (a->d_ffn > TAIL_MAX_FFN) return MOY_ENOSYS;                       // linear1's bias is staged in LDS whole (512 threads x 4 floats)
   if (a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_ENOSYS;   // fp32: the separate launches (the parity path)
-  if ((a->ld_samp % 8) || (a->ld_e1 % 4) || (a->ld_out % 8) || a->ld_samp < 256 || a->ld_e1 < 256 || a->ld_out < 256) return MOY_EINVAL;
+  if ((a->ld_samp % 8) || (a->ld_e1 % 8) || (a->ld_out % 8) || a->ld_samp < 256 || a->ld_e1 < 256 || a->ld_out < 256) return MOY_EINVAL;
   if (a->out_xp && (!a->qpos || (a->ld_xp % 8) || (a->ld_qpos % 8) || a->ld_xp < 256 || a->ld_qpos < 256 || !aligned16(a->out_xp) || !aligned16(a->qpos)))
     return MOY_EINVAL;
   if (!aligned16(a->samp) || !aligned16(a->out) || !aligned16(a->Wp) || !aligned16(a->W1) || !aligned16(a->W2) || !aligned16(a->B0) ||
       !aligned16(a->B1) || !aligned16(a->w2) || !aligned16(a->bp) || !aligned16(a->b1) || !aligned16(a->b2) || !aligned16(a->c0) ||
       !aligned16(a->c1) || !aligned16(a->ln2_g) || !aligned16(a->ln2_b) || !aligned16(a->ln3_g) || !aligned16(a->ln3_b) ||
-      (reinterpret_cast<uintptr_t>(a->e1) & 7))
+      !aligned16(a->e1))
     return MOY_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   static bool attr_set = false;          // > 64 KiB of dynamic LDS: opt in once per kernel symbol
@@ -344,6 +473,18 @@ extern "C" int moy_decoder_tail(const moy_decoder_tail_args* a, void* stream) {
   const int blocks = (a->M + TAIL_BM - 1) / TAIL_BM;
   static int abl = -1;
   if (abl < 0) abl = garbage_mode_env("MOY_TAIL_ABL");
+  if (abl == 3 && a->dtype == MOY_BF16) {          // stamps + no weight traffic after the first product
+    auto k3 = decoder_tail_kernel<bf16_t, 3>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) != hipSuccess) return MOY_ELAUNCH;
+    hipLaunchKernelGGL(k3, dim3(blocks), dim3(64 * TAIL_NW), TAIL_LDS, st, *a);
+    return launch_status();
+  }
+  if (abl == 2 && a->dtype == MOY_BF16) {
+    auto k2 = decoder_tail_kernel<bf16_t, 2>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) != hipSuccess) return MOY_ELAUNCH;
+    hipLaunchKernelGGL(k2, dim3(blocks), dim3(64 * TAIL_NW), TAIL_LDS, st, *a);
+    return launch_status();
+  }
   if (abl == 1 && a->dtype == MOY_BF16) {
     auto k1 = decoder_tail_kernel<bf16_t, 1>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) != hipSuccess) return MOY_ELAUNCH;

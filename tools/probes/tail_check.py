@@ -2,7 +2,7 @@
 """Bit-identity check of two builds of moy_decoder_tail (MOYOLO_LIB selects the library: one process per build):
     MOYOLO_LIB=.../libmoyolo_base.so python tools/probes/tail_check.py --save /tmp/a.pt
     python tools/probes/tail_check.py --save /tmp/b.pt ;  python tools/probes/tail_check.py --compare /tmp/a.pt /tmp/b.pt"""
-import argparse, os, sys
+import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
@@ -25,6 +25,19 @@ def run():
             o, ro = ops.decoder_tail(*args)
             torch.cuda.synchronize()
             outs[f"{dtn}.M{M}.ffn{dffn}.out"], outs[f"{dtn}.M{M}.ffn{dffn}.ref"] = o.cpu(), ro.cpu()
+            if dffn == 1024:                      # moy_decoder_mid on the same row counts (n_oa 288 = three levels, 384 = four)
+                for n_oa in (288, 384):
+                    woa = torch.zeros(max(256, n_oa), 256)
+                    woa[:n_oa] = (torch.rand(n_oa, 256, generator=g) - 0.5) * 0.1
+                    margs = (samp, e1, r(M, 256).to(dt), pw(r(256, 256, sc=0.1)), vec(), (vec() + 1, vec()), pw(woa.cuda()), vec(n_oa), n_oa)
+                    em, oa = ops.decoder_mid(*margs)
+                    em, oa = ops.decoder_mid(*margs)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(10): ops.decoder_mid(*margs)
+                    torch.cuda.synchronize()
+                    if M == 86400: print(f"decoder_mid {dtn} M={M} n_oa={n_oa}: {(time.perf_counter() - t0) / 10 * 1e6:.1f} us per launch")
+                    outs[f"{dtn}.M{M}.mid{n_oa}.e1"], outs[f"{dtn}.M{M}.mid{n_oa}.offaw"] = em.cpu(), oa.cpu()
     return outs
 
 
