@@ -734,10 +734,12 @@ class TrackEngine:
         self.layer_out = []
         cur, nxt = 0, 1
         ecur, enxt = 0, 1
-        # x + query_pos of the next layer, written by the fused tail (16-bit engines).  OFF by default (MOY_QKV_SPLIT=1 switches it on, 2
-        # forces it at any size): measured -0.2 ms on the sum of a pass's kernels and +-0 on the two-stream step (three interleaved pairs)
+        # x + query_pos of the next layer, written by the fused tail (16-bit engines), at the sizes where the plain products take the
+        # weight-stationary kernel (MOY_QKV_SPLIT=0 switches it off, 2 forces it at any size).  Round 3 measured -0.2 ms on the sum of a
+        # pass's kernels and +-0 on the two-stream step and left it off; round 5 (two interleaved pairs on one device): 33.45 / 33.33 ->
+        # 33.24 / 33.28 ms per step, on by default
         use_xp = (self.dtype != torch.float32 and arch.d_ffn % 256 == 0 and os.environ.get("MOY_DEC_TAIL", "1") != "0"
-                  and os.environ.get("MOY_QKV_SPLIT", "0") != "0" and (M >= 65536 or os.environ.get("MOY_QKV_SPLIT") == "2"))
+                  and os.environ.get("MOY_QKV_SPLIT", "1") != "0" and (M >= 65536 or os.environ.get("MOY_QKV_SPLIT") == "2"))
         xp = View(self._buf(M, hd)) if use_xp else None
         xp_ready = False
         for i in range(ndl):
