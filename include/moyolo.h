@@ -259,6 +259,12 @@ int moy_mlp_head(const void* X, int64_t ldx, const int32_t* x_rows, int M, const
  * to T where the separate launches store it; the LayerNorm statistics are one-pass (E[v^2] - mean^2).  d_ffn <= 2048 (MOY_ENOSYS
  * beyond: linear1's bias is staged on chip whole); every T matrix 16-byte aligned with a row pitch that is a multiple of 8 elements
  * (samp, e1, out, out_xp, qpos: whole 512-byte rows move in 16-byte pieces). */
+/* MFMA-fragment order of a row-major 16-bit matrix W [N][K] (N, K multiples of 32): 2 KB blocks [N/32][K/32], a block = the two
+ * 16-row halves j of its 32 rows, each 64 lanes x 16 bytes: lane (r = lane & 15, q = lane >> 4) holds W[32 g + 16 j + r][32 pn + 8 q .. + 7].
+ * Byte offset of that piece: (((g * (K/32) + pn) * 2 + j) * 64 + lane) * 16.  It is the order in which the row-wise decoder kernels
+ * (moy_decoder_tail, moy_decoder_mid, moy_msda_raw0) hold weights in registers: a wave's request for a panel is 2 KB CONTIGUOUS instead
+ * of 32 rows x 64 bytes.  Measured on MI355X (tools/probes/l2_segments.hip, every CU streaming the same L2-resident table): 37.5 GB/s per
+ * CU for the row-major request shape, 132 GB/s for the contiguous one.  mo_yolo_amd.ops.pack_mfma_a() produces it. */
 typedef struct moy_decoder_tail_args {
   const void* samp; int64_t ld_samp;   /* T [M, 256] */
   const void* e1;   int64_t ld_e1;     /* T [M, 256] residual */
@@ -276,6 +282,8 @@ typedef struct moy_decoder_tail_args {
    * (with_pos_embed, transformer.py:637-638), element pairs added in fp32 and rounded once, as moy_gemm forms A + A2 */
   const void* qpos; int64_t ld_qpos;
   void* out_xp; int64_t ld_xp;
+  /* round 5: 1 = Wp, W1, W2, B0, B1 are given in MFMA-FRAGMENT ORDER (below) instead of row-major; results are identical */
+  int32_t w_packed;
 } moy_decoder_tail_args;
 
 int moy_decoder_tail(const moy_decoder_tail_args* args, void* stream);
@@ -299,6 +307,7 @@ typedef struct moy_decoder_mid_args {
   void* e1; int64_t ld_e1;             /* out: T [M, 256] */
   float* offaw; int64_t ld_oa;         /* out: fp32 [M, n_oa] */
   int32_t dtype;
+  int32_t w_packed;                    /* round 5: 1 = Wo and Woa in MFMA-fragment order (above moy_decoder_tail_args) */
 } moy_decoder_mid_args;
 
 int moy_decoder_mid(const moy_decoder_mid_args* args, void* stream);
@@ -367,6 +376,7 @@ typedef struct moy_msda_raw_args {
   void* out;
   int64_t ldo;
   int32_t dtype;
+  int32_t wc_packed;          /* round 5: 1 = wc in MFMA-fragment order (above moy_decoder_tail_args; N = 256 rows, K = 128) */
 } moy_msda_raw_args;
 int moy_msda_raw0(const moy_msda_raw_args* a, void* stream);
 

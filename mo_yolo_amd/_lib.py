@@ -45,7 +45,7 @@ class DecoderTailArgs(C.Structure):
         ("ln3_g", vp), ("ln3_b", vp), ("out", vp), ("ld_out", i64),
         ("B0", vp), ("c0", vp), ("B1", vp), ("c1", vp), ("w2", vp), ("c2", vp),
         ("ref_in", vp), ("ref_out", vp), ("dtype", i32),
-        ("qpos", vp), ("ld_qpos", i64), ("out_xp", vp), ("ld_xp", i64),
+        ("qpos", vp), ("ld_qpos", i64), ("out_xp", vp), ("ld_xp", i64), ("w_packed", i32),
     ]
 
 
@@ -54,7 +54,7 @@ class DecoderMidArgs(C.Structure):
     _fields_ = [
         ("attn", vp), ("ld_attn", i64), ("x", vp), ("ld_x", i64), ("qpos", vp), ("ld_qpos", i64), ("M", i32),
         ("Wo", vp), ("bo", vp), ("ln_g", vp), ("ln_b", vp), ("Woa", vp), ("boa", vp), ("n_oa", i32),
-        ("e1", vp), ("ld_e1", i64), ("offaw", vp), ("ld_oa", i64), ("dtype", i32),
+        ("e1", vp), ("ld_e1", i64), ("offaw", vp), ("ld_oa", i64), ("dtype", i32), ("w_packed", i32),
     ]
 
 
@@ -63,7 +63,7 @@ class MsdaRawArgs(C.Structure):
     _fields_ = [
         ("x0", vp), ("ld0", i64), ("wc", vp), ("bc", vp), ("planes", vp), ("head_stride", i64), ("S1", i32),
         ("B", i32), ("Lq", i32), ("L", i32), ("shapes_hw", vp), ("offaw", vp), ("ld_oa", i64), ("ref", vp),
-        ("out", vp), ("ldo", i64), ("dtype", i32),
+        ("out", vp), ("ldo", i64), ("dtype", i32), ("wc_packed", i32),
     ]
 
 

@@ -52,6 +52,14 @@ __global__ __launch_bounds__(64 * MID_NW) void decoder_mid_kernel(const moy_deco
   u32x4 wa[2][NT][4];
   auto req_half = [&](int h, const void* W, int row0) {
     if (!W) return;
+    if (p.w_packed) {        // MFMA-fragment order (include/moyolo.h): the 32-row group row0 / 32, panels 4h .. 4h+3: 8 KB contiguous
+      const unsigned char* Wg = static_cast<const unsigned char*>(W) + ((int64_t)(row0 >> 5) * 8 + h * 4) * 2048 + lane * 16;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int pn = 0; pn < 4; ++pn) wa[h][j][pn] = *reinterpret_cast<const u32x4*>(Wg + pn * 2048 + j * 1024);
+      return;
+    }
     const T* Wg = static_cast<const T*>(W) + (int64_t)row0 * 256 + h * 128;
 #pragma unroll
     for (int j = 0; j < NT; ++j)

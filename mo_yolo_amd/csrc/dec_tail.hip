@@ -86,15 +86,7 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
   u32x4 wa[2][NT][4];
   struct WSrc { const void* W; int row0, pitch, koff; };
   bool w_loaded = false;
-  auto req_half = [&](int h, const WSrc& w) {
-    if constexpr (ABL == 1 || ABL == 3) { if (w_loaded) return; }
-    if (!w.W) return;
-    const T* Wg = static_cast<const T*>(w.W) + (int64_t)(w.row0 + wave * WC) * w.pitch + w.koff + h * 128;
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int pn = 0; pn < 4; ++pn) wa[h][j][pn] = *reinterpret_cast<const u32x4*>(Wg + (int64_t)(j * 16 + r) * w.pitch + pn * 32 + q * 8);
-  };
+
   // Round 5: one 32-wide PANEL at a time.  A product now walks its panels outermost (panel pn over every row part, then pn + 1; every
   // accumulator still sees its panels in the order 0..7, so results are unchanged) and the moment a panel has been consumed its registers
   // are re-requested with that panel of the NEXT product: every request is 7/8 of a product + the epilogue ahead of its use (by halves it
@@ -108,12 +100,17 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
     // buffer loads: the matrix as the descriptor's base, the lane part of the address one 32-bit register per row pitch (r * pitch + q * 8),
     // everything else wave-uniform in the scalar offset -- no 64-bit per-lane pointers held across the products
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w.W), 0, 0x7fffffff, 0x00020000);
-    const uint32_t voff = w.pitch == 256 ? voff_256 : voff_ffn;
-    const uint32_t so = (uint32_t)(((w.row0 + wave * WC) * w.pitch + w.koff + pn * 32) * 2);
+    // w_packed: the matrix in MFMA-fragment order (include/moyolo.h) -- this wave's panel is 2 KB contiguous, 16 bytes per lane.  Row-major,
+    // a request is 32 rows x 64 bytes: 37.5 GB/s per CU against 132 (tools/probes/l2_segments.hip), and the weights are 128 KB per product
+    const uint32_t voff = p.w_packed ? (uint32_t)lane * 16u : (w.pitch == 256 ? voff_256 : voff_ffn);
+    const uint32_t so = p.w_packed ? (uint32_t)((((w.row0 >> 5) + wave) * (w.pitch >> 5) + (w.koff >> 5) + pn) * 2048)
+                                   : (uint32_t)(((w.row0 + wave * WC) * w.pitch + w.koff + pn * 32) * 2);
+    const uint32_t sj = p.w_packed ? 1024u : (uint32_t)(16 * w.pitch * 2);
 #pragma unroll
     for (int j = 0; j < NT; ++j)
-      wa[pn >> 2][j][pn & 3] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, so + (uint32_t)(j * 16 * w.pitch * 2), 0));
+      wa[pn >> 2][j][pn & 3] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, so + (uint32_t)j * sj, 0));
   };
+  static_assert(NT == 2 && WC == 32, "the fragment order is defined for 32-row groups of two 16-row halves");
   const int lbase = r * 512 + ((q ^ r) << 4);      // fragment of row i*16 + r, chunk (pn*4 + q) ^ r
   // rows in two halves of 64: 16 fragment registers live instead of 32
   auto gemm_acc = [&](const unsigned char* As, f32x4 (&acc)[MT][NT], const WSrc& next) {
@@ -224,7 +221,11 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
       const int m = min(m0 + row, p.M - 1);
       xr[k] = *reinterpret_cast<const u32x4*>(Xg + (int64_t)m * p.ld_samp + c * 8);
     }
-    { const WSrc w0{p.Wp, 0, 256, 0}; req_half(0, w0); req_half(1, w0); }
+    {
+      const WSrc w0{p.Wp, 0, 256, 0};
+#pragma unroll
+      for (int pn = 0; pn < 8; ++pn) req_panel(pn, w0);
+    }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int id = tid + k * NTHR, row = id >> 5, c = id & 31;

@@ -35,7 +35,8 @@ struct LevelInfoR {
 struct MsdaRawParams {
   const void* x0;        // level 0, raw: [B, H0, W0, >= 128] channels-last, pixel pitch ld0 elements
   int64_t ld0;
-  const void* wc;        // composed weights of this layer: T [256][128]
+  const void* wc;        // composed weights of this layer: T [256][128] (wc_packed: in MFMA-fragment order, include/moyolo.h)
+  int wc_packed;
   const float* bc;       // composed bias fp32 [256]
   const void* planes;    // head planes of levels 1..: T [8][B * S1][32] (head_stride elements between heads)
   int64_t head_stride;
@@ -259,7 +260,8 @@ __global__ __launch_bounds__(256, 3) void msda_raw_kernel(const MsdaRawParams p)
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int pn = 0; pn < 4; ++pn)
-        wa[t][pn] = *reinterpret_cast<const u32x4*>(wc + (h * 32 + t * 16 + r) * 128 + pn * 32 + q4 * 8);
+        wa[t][pn] = p.wc_packed ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wc) + ((h * 4 + pn) * 2 + t) * 1024 + lane * 16)   // fragment order: 8 KB contiguous per head
+                                : *reinterpret_cast<const u32x4*>(wc + (h * 32 + t * 16 + r) * 128 + pn * 32 + q4 * 8);
 #pragma unroll
     for (int pn = 0; pn < 4; ++pn) gb[pn] = *reinterpret_cast<const u32x4*>(sG + r * MR_GP + h * 256 + pn * 64 + q4 * 16);
     f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -486,7 +488,8 @@ __global__ __launch_bounds__(64 * MRM_NW, 2) void msda_raw_mfma_kernel(const Msd
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int pn = 0; pn < 4; ++pn)
-        wa[t][pn] = *reinterpret_cast<const u32x4*>(wc + (h * 32 + t * 16 + r) * 128 + pn * 32 + q4 * 8);
+        wa[t][pn] = p.wc_packed ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wc) + ((h * 4 + pn) * 2 + t) * 1024 + lane * 16)   // fragment order: 8 KB contiguous per head
+                                : *reinterpret_cast<const u32x4*>(wc + (h * 32 + t * 16 + r) * 128 + pn * 32 + q4 * 8);
 #pragma unroll
     for (int pn = 0; pn < 4; ++pn) gb[pn] = *reinterpret_cast<const u32x4*>(sG + r * MR_GP + h * 256 + pn * 64 + q4 * 16);
     f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -530,6 +533,7 @@ extern "C" int moy_msda_raw0(const moy_msda_raw_args* a, void* stream) {
   if (a->L > 1 && (a->head_stride < 32 || (a->head_stride % 8) || a->head_stride * 8 * 2 > 0x7fffffffLL || !aligned16(a->planes))) return MOY_EINVAL;
   if (a->ld_oa < 8 * a->L * 4 * 3 || (a->ld_oa % 4) || a->ldo < 256 || (a->ldo % 4) || !aligned16(a->ref) || !aligned16(a->offaw)) return MOY_EINVAL;
   if (!aligned16(a->wc) || !aligned16(a->bc) || (reinterpret_cast<uintptr_t>(a->out) % 8)) return MOY_EINVAL;
+  p.wc_packed = a->wc_packed;
   p.x0 = a->x0; p.ld0 = a->ld0; p.wc = a->wc; p.bc = a->bc; p.planes = a->planes; p.head_stride = a->head_stride; p.S1 = a->S1;
   p.L = a->L; p.offaw = a->offaw; p.ld_oa = a->ld_oa; p.ref = a->ref; p.Lq = a->Lq; p.nrows = a->B * a->Lq; p.out = a->out; p.ldo = a->ldo;
   hipStream_t st = static_cast<hipStream_t>(stream);

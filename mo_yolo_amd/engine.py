@@ -571,6 +571,8 @@ class TrackEngine:
                         # level 0 is sampled raw: its composed weights [ndl * 256, 128] / biases go to the gather, layer by layer
                         self.p3raw = dict(view=src_view, wc=self._weight(Wc), bc=self._dev(bc))
                         assert self.p3raw["wc"].shape == (ndl * hd, 128)
+                        from .ops import pack_mfma_a
+                        self.p3raw["wc_packed"] = pack_mfma_a(self.p3raw["wc"])     # a layer's [256, 128] slice stays at the same byte offset
                         continue
                     self._gemm(src_view, self._weight(Wc), ndl * hd, arch.head_ch[li], View(self.value_planes[off:]), B * h_ * w_,
                                shift=self._dev(bc), planes=(dh, B * Sv * dh), c_rpb=h_ * w_, c_bstride=Sv)
@@ -741,6 +743,8 @@ class TrackEngine:
         use_xp = (self.dtype != torch.float32 and arch.d_ffn % 256 == 0 and os.environ.get("MOY_DEC_TAIL", "1") != "0"
                   and os.environ.get("MOY_QKV_SPLIT", "1") != "0" and (M >= 65536 or os.environ.get("MOY_QKV_SPLIT") == "2"))
         xp = View(self._buf(M, hd)) if use_xp else None
+        from .ops import pack_mfma_a
+        packed_w = os.environ.get("MOY_W_PACKED", "1") != "0"       # the row-wise decoder kernels' weights in MFMA-fragment order
         xp_ready = False
         for i in range(ndl):
             q = f"{d}.decoder.layers.{i}"
@@ -774,11 +778,14 @@ class TrackEngine:
                 Woa_d, boa_d = self._weight(Wpad), self._dev(boa)
                 ln1 = self._ln(q + ".norm1")
                 t = L.DecoderMidArgs()
+                if packed_w:
+                    Wo, Woa_d = pack_mfma_a(Wo), pack_mfma_a(Woa_d)
+                    t.w_packed = 1
                 t.attn, t.ld_attn, t.x, t.ld_x, t.qpos, t.ld_qpos, t.M = attn.ptr, attn.ld, x.ptr, x.ld, qpos.ptr, qpos.ld, M
                 t.Wo, t.bo, t.ln_g, t.ln_b = Wo.data_ptr(), bo.data_ptr(), ln1[0].data_ptr(), ln1[1].data_ptr()
                 t.Woa, t.boa, t.n_oa = Woa_d.data_ptr(), boa_d.data_ptr(), n_oa
                 t.e1, t.ld_e1, t.offaw, t.ld_oa, t.dtype = e1.ptr, e1.ld, offaw.data_ptr(), offaw.shape[1], code
-                self._keep.append(t)
+                self._keep += [t, Wo, Woa_d]
                 self._add(lib.moy_decoder_mid, C.byref(t),
                           meta=dict(name=f"decoder_mid M{M}", bytes=4 * M * hd * 2 + M * n_oa * 4 + (hd + n_oa) * hd * 2,
                                     flops=2 * M * hd * (hd + n_oa)))
@@ -802,7 +809,8 @@ class TrackEngine:
                 t = L.MsdaRawArgs()
                 pv = self.p3raw["view"]
                 t.x0, t.ld0 = pv.ptr, pv.ld
-                t.wc = self.p3raw["wc"].data_ptr() + i * hd * 128 * self._esz
+                t.wc = self.p3raw["wc_packed" if packed_w else "wc"].data_ptr() + i * hd * 128 * self._esz
+                t.wc_packed = int(packed_w)
                 t.bc = self.p3raw["bc"].data_ptr() + i * hd * 4
                 t.planes, t.head_stride, t.S1 = vslice.ptr, vhs, self.value_tokens
                 t.B, t.Lq, t.L, t.shapes_hw = B, Lq, nl, C.cast(shapes_c, C.c_void_p)
@@ -830,6 +838,9 @@ class TrackEngine:
                 B1, c1 = self._linear_w(hp + ".layers.1")
                 w2h, c2 = self._dev(sd[hp + ".layers.2.weight"]), self._dev(sd[hp + ".layers.2.bias"])
                 t = L.DecoderTailArgs()
+                if packed_w:     # MFMA-fragment order (include/moyolo.h): a wave's weight request is 2 KB contiguous, not 32 rows x 64 bytes
+                    Wp, W1, W2, B0, B1 = (pack_mfma_a(w) for w in (Wp, W1, W2, B0, B1))
+                    t.w_packed = 1
                 t.samp, t.ld_samp, t.e1, t.ld_e1, t.M = samp.ptr, samp.ld, e1.ptr, e1.ld, M
                 t.Wp, t.bp, t.ln2_g, t.ln2_b = Wp.data_ptr(), bp.data_ptr(), ln2[0].data_ptr(), ln2[1].data_ptr()
                 t.W1, t.b1, t.W2, t.b2, t.d_ffn = W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), arch.d_ffn
@@ -840,7 +851,7 @@ class TrackEngine:
                 if use_xp and i + 1 < ndl:
                     t.qpos, t.ld_qpos, t.out_xp, t.ld_xp = qpos.ptr, qpos.ld, xp.ptr, xp.ld
                     xp_ready = True
-                self._keep.append(t)
+                self._keep += [t, Wp, W1, W2, B0, B1]
                 wb = (3 * hd * hd + 2 * hd * arch.d_ffn) * 2
                 self._add(lib.moy_decoder_tail, C.byref(t),
                           meta=dict(name=f"decoder_tail M{M}", bytes=3 * M * hd * 2 + wb + M * 32,

@@ -245,9 +245,17 @@ def mlp_head(X, W0p, b0, W1p, b1, w2, b2, mode=0, aux=None, aux_rows=None, x_row
     return y
 
 
-def decoder_tail(samp, e1, Wp, bp, ln2, W1, b1, W2, b2, ln3, B0, c0, B1, c1, w2, c2, ref_in):
-    """See moy_decoder_tail.  samp / e1 [M, 256] 16-bit; weights in that dtype ([out, in]); vectors fp32; ref_in fp32 [M, 4].
-    Returns (out [M, 256], ref_out fp32 [M, 4])."""
+def pack_mfma_a(W):
+    """Row-major 16-bit W [N, K] (N, K multiples of 32) -> the same elements in MFMA-fragment order (include/moyolo.h, above
+    moy_decoder_tail_args): blocks [N/32][K/32] of 2 KB = [j][lane = q*16 + r][8 elements] with row 32 g + 16 j + r, column 32 pn + 8 q + e."""
+    N, K = W.shape
+    assert N % 32 == 0 and K % 32 == 0 and W.element_size() == 2
+    return W.contiguous().view(N // 32, 2, 16, K // 32, 4, 8).permute(0, 3, 1, 4, 2, 5).contiguous().view(N, K)
+
+
+def decoder_tail(samp, e1, Wp, bp, ln2, W1, b1, W2, b2, ln3, B0, c0, B1, c1, w2, c2, ref_in, packed=False):
+    """See moy_decoder_tail.  samp / e1 [M, 256] 16-bit; weights in that dtype ([out, in]; packed=True: each through pack_mfma_a);
+    vectors fp32; ref_in fp32 [M, 4].  Returns (out [M, 256], ref_out fp32 [M, 4])."""
     _need_gpu(samp, e1)
     M = samp.shape[0]
     out = torch.empty(M, 256, device=samp.device, dtype=samp.dtype)
@@ -258,12 +266,12 @@ def decoder_tail(samp, e1, Wp, bp, ln2, W1, b1, W2, b2, ln3, B0, c0, B1, c1, w2,
     t.W1, t.b1, t.W2, t.b2, t.d_ffn = W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W1.shape[0]
     t.ln3_g, t.ln3_b, t.out, t.ld_out = ln3[0].data_ptr(), ln3[1].data_ptr(), out.data_ptr(), 256
     t.B0, t.c0, t.B1, t.c1, t.w2, t.c2 = B0.data_ptr(), c0.data_ptr(), B1.data_ptr(), c1.data_ptr(), w2.data_ptr(), c2.data_ptr()
-    t.ref_in, t.ref_out, t.dtype = ref_in.data_ptr(), ref_out.data_ptr(), _code(samp)
+    t.ref_in, t.ref_out, t.dtype, t.w_packed = ref_in.data_ptr(), ref_out.data_ptr(), _code(samp), int(packed)
     L.check(L.lib().moy_decoder_tail(C.byref(t), _st()), "moy_decoder_tail")
     return out, ref_out
 
 
-def decoder_mid(attn, x, qpos, Wo, bo, ln1, Woa, boa, n_oa):
+def decoder_mid(attn, x, qpos, Wo, bo, ln1, Woa, boa, n_oa, packed=False):
     """See moy_decoder_mid.  attn / x / qpos [M, 256] 16-bit; Wo [256, 256], Woa [max(256, n_oa), 256] in that dtype (zero rows past
     n_oa); vectors fp32.  Returns (e1 [M, 256], offaw fp32 [M, n_oa])."""
     _need_gpu(attn, x, qpos)
@@ -274,7 +282,7 @@ def decoder_mid(attn, x, qpos, Wo, bo, ln1, Woa, boa, n_oa):
     t.attn, t.ld_attn, t.x, t.ld_x, t.qpos, t.ld_qpos, t.M = attn.data_ptr(), _ld(attn), x.data_ptr(), _ld(x), qpos.data_ptr(), _ld(qpos), M
     t.Wo, t.bo, t.ln_g, t.ln_b = Wo.data_ptr(), bo.data_ptr(), ln1[0].data_ptr(), ln1[1].data_ptr()
     t.Woa, t.boa, t.n_oa = Woa.data_ptr(), boa.data_ptr(), n_oa
-    t.e1, t.ld_e1, t.offaw, t.ld_oa, t.dtype = e1.data_ptr(), 256, offaw.data_ptr(), n_oa, _code(attn)
+    t.e1, t.ld_e1, t.offaw, t.ld_oa, t.dtype, t.w_packed = e1.data_ptr(), 256, offaw.data_ptr(), n_oa, _code(attn), int(packed)
     L.check(L.lib().moy_decoder_mid(C.byref(t), _st()), "moy_decoder_mid")
     return e1, offaw
 
@@ -321,7 +329,7 @@ def msda_fused(value, B, S, shapes, offaw, ref, Lq, head_planes=False):
     return out
 
 
-def msda_raw0(x0, wc, bc, planes, B, shapes, offaw, ref, Lq):
+def msda_raw0(x0, wc, bc, planes, B, shapes, offaw, ref, Lq, packed=False):
     """moy_msda_raw0: level 0 gathered raw from x0 [B*H0*W0, >= 128] (channel-slice view) and projected with wc [256, 128] / bc [256]
     after the bilinear sum; levels 1.. from head planes [8, B*S1, 32] (None when there is one level)."""
     _need_gpu(x0, wc, bc, offaw, ref)
@@ -336,6 +344,7 @@ def msda_raw0(x0, wc, bc, planes, B, shapes, offaw, ref, Lq):
         a.planes, a.head_stride = planes.data_ptr(), B * S1 * 32
     a.S1, a.B, a.Lq, a.L, a.shapes_hw = S1, B, Lq, nl, C.cast(sh, C.c_void_p)
     a.offaw, a.ld_oa, a.ref, a.out, a.ldo, a.dtype = offaw.data_ptr(), _ld(offaw), ref.data_ptr(), out.data_ptr(), 256, _code(x0)
+    a.wc_packed = int(packed)          # wc through pack_mfma_a
     assert wc.is_contiguous() and tuple(wc.shape) == (256, 128) and wc.dtype == x0.dtype and bc.dtype == torch.float32
     L.check(L.lib().moy_msda_raw0(C.byref(a), _st()), "moy_msda_raw0")
     return out

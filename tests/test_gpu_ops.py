@@ -811,6 +811,11 @@ def test_decoder_tail_one_launch_equals_separate(dt, M, dffn):
     sd_, e1d = samp.to(DEV, dt), e1.to(DEV, dt)
     out, ref_out = ops.decoder_tail(sd_, e1d, pw(Wp), d(bp), (d(g2), d(be2)), pw(W1), d(b1), pw(W2), d(b2), (d(g3), d(be3)),
                                     pw(B0), d(c0), pw(B1), d(c1), d(w2), d(c2), d(ref_in))
+    # the same call with the five matrices in MFMA-fragment order (include/moyolo.h; what the engine passes): the same bits
+    pk = lambda w: ops.pack_mfma_a(pw(w))
+    out_p, ref_p = ops.decoder_tail(sd_, e1d, pk(Wp), d(bp), (d(g2), d(be2)), pk(W1), d(b1), pk(W2), d(b2), (d(g3), d(be3)),
+                                    pk(B0), d(c0), pk(B1), d(c1), d(w2), d(c2), d(ref_in), packed=True)
+    assert torch.equal(out_p, out) and torch.equal(ref_p, ref_out)
     # separate launches
     e2 = ops.gemm(sd_, pw(Wp), 256, 256, shift=d(bp), R=e1d, ln=(d(g2), d(be2)))
     h = ops.gemm(e2, pw(W1), dffn, 256, shift=d(b1), act=L.ACT_RELU)
@@ -849,6 +854,8 @@ def test_decoder_mid_one_launch_equals_separate(dt, M, n_oa):
     Wpad = torch.zeros(max(256, n_oa), 256)
     Wpad[:n_oa] = Woa
     e1, offaw = ops.decoder_mid(ad, xd, qd, pw(Wo), d(bo), (d(g1), d(be1)), pw(Wpad), d(boa), n_oa)
+    e1p, offawp = ops.decoder_mid(ad, xd, qd, ops.pack_mfma_a(pw(Wo)), d(bo), (d(g1), d(be1)), ops.pack_mfma_a(pw(Wpad)), d(boa), n_oa, packed=True)
+    assert torch.equal(e1p, e1) and torch.equal(offawp, offaw)          # weights in MFMA-fragment order: the same bits
     # separate launches (the fp32 engines' path)
     e1s = ops.gemm(ad, pw(Wo), 256, 256, shift=d(bo), R=xd, ln=(d(g1), d(be1)))
     oas = ops.gemm(e1s, pw(Woa), n_oa, 256, shift=d(boa), A2=qd, out_f32=True)
@@ -962,7 +969,9 @@ def test_msda_raw_level0_gather_then_project_vs_oracle(dt, B, Lq, shapes, ld0):
     xbuf[:, :128] = x.to(DEV, dt)
     planes = v1.view(B * S1, 8, 32).permute(1, 0, 2).contiguous().to(DEV, dt) if S1 else None
     y = ops.msda_raw0(xbuf[:, :128], wc.to(DEV, dt).contiguous(), bc.to(DEV), planes, B, shapes, offaw.to(DEV), ref_box.to(DEV), Lq)
+    yp = ops.msda_raw0(xbuf[:, :128], ops.pack_mfma_a(wc.to(DEV, dt)), bc.to(DEV), planes, B, shapes, offaw.to(DEV), ref_box.to(DEV), Lq, packed=True)
     torch.cuda.synchronize()
+    assert torch.equal(yp, y)                                            # composed weights in MFMA-fragment order: the same bits
     v0 = (x @ wc.T + bc).view(B, H0 * W0, 256)
     value = torch.cat([v0, v1[:, :S1]], 1) if S1 else v0
     off = offaw[:, :8 * nl * 8].view(B, Lq, 8, nl, 4, 2)

@@ -25,7 +25,9 @@ planes = torch.randn(8, B * S1, 32, device="cuda", generator=g).to(dt)
 offaw = torch.cat([torch.randn(B * Lq, 192, device="cuda", generator=g) * a.spread, torch.randn(B * Lq, 96, device="cuda", generator=g)], 1).contiguous()
 ref = torch.rand(B * Lq, 4, device="cuda", generator=g)
 ref[:, 2:] = ref[:, 2:] * 0.3 + 0.02
-f = lambda: ops.msda_raw0(x, wc, bc, planes, B, shapes, offaw, ref, Lq)
+PACKED = os.environ.get("WC_PACKED", "1") != "0"
+wcp = ops.pack_mfma_a(wc) if PACKED else wc
+f = lambda: ops.msda_raw0(x, wcp, bc, planes, B, shapes, offaw, ref, Lq, packed=PACKED)
 y = f(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ts = []
@@ -34,7 +36,7 @@ for _ in range(5):
     for _ in range(10): f()
     e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1) / 10 * 1e3)
-print(f"msda_raw0 MOY_MR_MFMA={os.environ.get('MOY_MR_MFMA', '(default)')} {a.dtype} B={B} Lq={Lq}: " + " ".join(f"{t:.1f}" for t in ts) + " us per launch", flush=True)
+print(f"msda_raw0 MOY_MR_MFMA={os.environ.get('MOY_MR_MFMA', '(default)')} wc {'fragment order' if PACKED else 'row-major'} {a.dtype} B={B} Lq={Lq}: " + " ".join(f"{t:.1f}" for t in ts) + " us per launch", flush=True)
 if a.save:
     torch.save(y.cpu(), a.save)
 if a.cmp:

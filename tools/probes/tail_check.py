@@ -30,11 +30,13 @@ def run():
                     woa = torch.zeros(max(256, n_oa), 256)
                     woa[:n_oa] = (torch.rand(n_oa, 256, generator=g) - 0.5) * 0.1
                     margs = (samp, e1, r(M, 256).to(dt), pw(r(256, 256, sc=0.1)), vec(), (vec() + 1, vec()), pw(woa.cuda()), vec(n_oa), n_oa)
-                    em, oa = ops.decoder_mid(*margs)
-                    em, oa = ops.decoder_mid(*margs)
+                    PK = os.environ.get("W_PACKED", "0") == "1"
+                    if PK: margs = margs[:3] + (ops.pack_mfma_a(margs[3]),) + margs[4:6] + (ops.pack_mfma_a(margs[6]),) + margs[7:]
+                    em, oa = ops.decoder_mid(*margs, packed=PK)
+                    em, oa = ops.decoder_mid(*margs, packed=PK)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    for _ in range(10): ops.decoder_mid(*margs)
+                    for _ in range(10): ops.decoder_mid(*margs, packed=PK)
                     torch.cuda.synchronize()
                     if M == 86400: print(f"decoder_mid {dtn} M={M} n_oa={n_oa}: {(time.perf_counter() - t0) / 10 * 1e6:.1f} us per launch")
                     outs[f"{dtn}.M{M}.mid{n_oa}.e1"], outs[f"{dtn}.M{M}.mid{n_oa}.offaw"] = em.cpu(), oa.cpu()

@@ -10,9 +10,17 @@ pw = lambda w: ops.pad_weight(w, dt)
 vec = lambda n=256: r(n, sc=0.2)
 samp, e1 = r(M, 256).to(dt), r(M, 256).to(dt)
 ref = torch.rand(M, 4, generator=g).cuda()
-args = (samp, e1, pw(r(256, 256, sc=0.1)), vec(), (vec() + 1, vec()), pw(r(dffn, 256, sc=0.1)), vec(dffn), pw(r(256, dffn, sc=0.05)), vec(),
-        (vec() + 1, vec()), pw(r(256, 256, sc=0.1)), vec(), pw(r(256, 256, sc=0.1)), vec(), r(4, 256, sc=0.1), vec(4), ref)
+args = [samp, e1, pw(r(256, 256, sc=0.1)), vec(), (vec() + 1, vec()), pw(r(dffn, 256, sc=0.1)), vec(dffn), pw(r(256, dffn, sc=0.05)), vec(),
+        (vec() + 1, vec()), pw(r(256, 256, sc=0.1)), vec(), pw(r(256, 256, sc=0.1)), vec(), r(4, 256, sc=0.1), vec(4), ref]
+o0, ro0 = ops.decoder_tail(*args); torch.cuda.synchronize()
+PACKED = os.environ.get("TAIL_PACKED", "1") != "0"
+if PACKED:
+    for i in (2, 5, 7, 10, 12): args[i] = ops.pack_mfma_a(args[i])
+_tail = ops.decoder_tail
+ops.decoder_tail = lambda *a: _tail(*a, packed=PACKED)
 o, ro = ops.decoder_tail(*args); torch.cuda.synchronize()
+if not os.environ.get("MOY_TAIL_ABL"):
+    print("fragment-ordered weights" if PACKED else "row-major weights", "- outputs equal to the row-major call:", torch.equal(o, o0) and torch.equal(ro, ro0))
 e0, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(10): o, ro = ops.decoder_tail(*args)
