@@ -29,6 +29,8 @@ __global__ __launch_bounds__(512) void k(const unsigned char* __restrict__ tab, 
         else if (MODE == 1) off = ((i >> 2) * 8 + (lane & 7)) * 512 + (i & 3) * 128 + (lane >> 3) * 16;     // 128-B pieces
         else if (MODE == 5) off = ((i >> 1) * 4 + (lane & 3)) * 512 + (i & 1) * 256 + (lane >> 2) * 16;      // 256-B pieces x 4 rows
         else if (MODE == 6) off = (i * 2 + (lane & 1)) * 512 + (lane >> 1) * 16;                            // 512-B rows x 2
+        else if (MODE == 7) off = i * 1024 + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) * 16);      // 1 KB contiguous, 16-B chunks XOR-permuted inside each 128-B line
+        else if (MODE == 8) off = i * 1024 + (lane >> 4) * 256 + (((lane & 15) ^ ((i * 4 + (lane >> 4)) & 15)) * 16);   // ... inside each 256-B row
         else off = i * 1024 + lane * 16;
         v[i] = *reinterpret_cast<const u32x4*>(sl + off);
       }
@@ -67,7 +69,9 @@ int main(int argc, char** argv) {
         case 3: k<3><<<256, 512>>>(tab, tab_bytes, iters, sink); break;
         case 4: k<4><<<256, 512>>>(tab, tab_bytes, iters, sink); break;
         case 5: k<5><<<256, 512>>>(tab, tab_bytes, iters, sink); break;
-        default: k<6><<<256, 512>>>(tab, tab_bytes, iters, sink); break;
+        case 6: k<6><<<256, 512>>>(tab, tab_bytes, iters, sink); break;
+        case 7: k<7><<<256, 512>>>(tab, tab_bytes, iters, sink); break;
+        default: k<8><<<256, 512>>>(tab, tab_bytes, iters, sink); break;
       }
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -83,5 +87,7 @@ int main(int argc, char** argv) {
   run(4, "8 B/lane, 4 x 128-B segments");
   run(5, "16 B/lane, 256-B segments x 4 rows");
   run(6, "16 B/lane, 512-B rows x 2");
+  run(7, "16 B/lane, 1 KB contiguous, chunks XOR-permuted per 128-B line");
+  run(8, "16 B/lane, 1 KB contiguous, chunks XOR-permuted per 256-B row");
   return 0;
 }
