@@ -217,7 +217,10 @@ class TrackEngine:
         else:
             a_elems = M * K * (2 if A2 is not None else 1)
         alg = (a_elems + N * K) * esz + (M * n_out * (4 if out_f32 else esz) if C_ is not None else 0) + (M * N * esz if R is not None else 0)
-        tag = f"gemm{ksize}x{ksize}" + ("s2" if stride == 2 else "") + ("+ln" if ln is not None else "") + ("+1x1" if post is not None else "")
+        # (a name = one kernel template as `rocprofv3 --stats` lists it: bench.py ranks kernels by the total time of a NAME; the 3x3 convs with
+        #  the bottleneck shortcut are a template of their own)
+        tag = (f"gemm{ksize}x{ksize}" + ("s2" if stride == 2 else "") + ("+ln" if ln is not None else "") + ("+1x1" if post is not None else "")
+               + ("+res" if R is not None and ksize == 3 else ""))
         fl = 2 * M * N * K + (2 * M * N * n_out if post is not None else 0)
         if post is not None:
             alg += N * n_out * esz

@@ -47,8 +47,12 @@ if os.path.exists(f"{src}/traffic_step.json") and os.path.exists(f"{src}/traffic
             key = "stem+conv1 fused M11907072 N64"
         elif "c2f_fused_kernel" in r["kernel"] and r["dispatches"] == 5:
             key = "c2f fused M11907072 64->[32|32]->64"
-        elif "msda_raw_kernel" in r["kernel"] and r["dispatches"] == 30:      # round 5: six calls per pass (the dominant kernel by total time)
+        elif ("msda_raw_kernel" in r["kernel"] or "msda_raw_mfma_kernel" in r["kernel"]) and r["dispatches"] == 30:      # round 5: six calls per pass
             key = "msda_raw0 M86400"
+        elif "conv_ws_kernel" in r["kernel"] and "128, 128, 8, 8, 2, false" in r["kernel"] and r["dispatches"] == 30:
+            # the 3x3 stride-1 convolutions with 128 channels at the P4 level (six plain calls per pass; the two with the shortcut are a template
+            # and a launch name of their own): the runner-up of the raw gather by total time (round 5)
+            key = "gemm3x3 M744192 N128 K1152"
         if key:
             doc["launches"][key] = dict(
                 hbm_bytes=r["hbm_bytes"], source=f"profiles/{tag}_b288_hbm_traffic_pmc.json ({r['kernel'][:70]}, grid {r['grid']}, "
