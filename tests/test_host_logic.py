@@ -133,12 +133,12 @@ def test_bench_control_flow_c3_eight_ranks_gloo_dry_run():
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["frames_per_step_per_gpu"] == 576
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["frames_per_step_per_gpu"] == 1152
     rm = sorted(d["config"]["rank_map"], key=lambda e: e["rank"])
     assert [e["rank"] for e in rm] == list(range(8))
     assert [e["hip_visible_devices"] for e in rm] == [str(i) for i in range(8)]      # one GPU per rank, pinned before HIP starts
     assert [e["sequences"] for e in rm] == [[i] for i in range(8)]                   # sequence i -> rank i, nothing shared
-    assert abs(d["value"] - 576 * 4 * 8 / (d["ms_per_step"] * 4 * 1e-3)) < 1e-4 * d["value"]
+    assert abs(d["value"] - 1152 * 4 * 8 / (d["ms_per_step"] * 4 * 1e-3)) < 1e-4 * d["value"]
     # the per-rank table that makes the first hardware run diagnosable -- 8 distinct devices, 8 sequences, 8 timings
     assert len(lines[0]) < 4096
     assert [e["rank"] for e in d["config"]["ranks"]] == list(range(8))          # the line carries the short per-rank records ...
@@ -177,7 +177,7 @@ def test_bench_gpus_n_self_launches_n_ranks_without_torchrun(n, tmp_path):
     rk = d["config"]["ranks"]
     assert [e["rank"] for e in rk] == list(range(n)) and [e["hip_visible_devices"] for e in rk] == [str(i) for i in range(n)]
     assert sorted(sq for e in rk for sq in e["sequences"]) == list(range(n))
-    assert abs(d["value"] - 576 * 3 * n / (d["ms_per_step"] * 3 * 1e-3)) < 1e-4 * d["value"]
+    assert abs(d["value"] - 1152 * 3 * n / (d["ms_per_step"] * 3 * 1e-3)) < 1e-4 * d["value"]
     full = json.load(open(tmp_path / "full.json"))                 # the side file the line names holds the same headline
     assert d["full"] == str(tmp_path / "full.json") and full["value"] == d["value"] and full["n_gpus"] == n
 
