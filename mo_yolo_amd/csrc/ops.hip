@@ -511,7 +511,11 @@ __device__ __forceinline__ void mma16<float>(f32x4& acc, u32x4 afrag, u32x4 bfra
 // keys (zero rows past L, masked to -inf), so the key loops are branch-free and the compiler keeps the fragment reads in
 // flight under the MFMAs; all K/V staging loads and the wave's Q fragments are issued before anything is waited for.
 template <typename T, int NKT, bool MASKED>   // NKT (even): 16-key tiles held in LDS and in the score registers
-__global__ __launch_bounds__(256) void mha_kernel(const T* __restrict__ qkv, int64_t ld, int L, int nh, int E,
+// (launch bound: two blocks per CU = a budget of 256 registers per wave.  With the default budget of 512 hipcc put the MFMA results -- the
+//  80 score registers -- into AccVGPRs and fetched every one of them with a v_accvgpr_read before the softmax could touch it: 440 extra
+//  vector instructions per block beside 400 v_exp_f32, in a kernel that is bound by exactly that vector work (round 5).  The fp32 form
+//  with 32 key tiles needs 254 registers: it keeps the wide budget.)
+__global__ __launch_bounds__(256, (sizeof(T) == 4 && NKT > 20) ? 1 : 2) void mha_kernel(const T* __restrict__ qkv, int64_t ld, int L, int nh, int E,
                                                   T* __restrict__ out, int64_t ldo, int tiles_per_block,
                                                   const int32_t* __restrict__ n_prefix, int split) {
   constexpr int KPB = DT<T>::KPB;
