@@ -26,30 +26,49 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SIGNATURES) == syms, "ctypes SIGNATURES drifted from the header"
 
 
-def test_gemm_args_layout_matches_header():
-    """Field order of the ctypes mirror == field order of struct moy_gemm_args."""
+def _header_fields(struct):
     txt = open(os.path.join(ROOT, "include", "moyolo.h")).read()
-    body = txt[txt.index("typedef struct moy_gemm_args {"):txt.index("} moy_gemm_args;")]
+    body = txt[txt.index(f"typedef struct {struct} {{"):txt.index(f"}} {struct};")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = []
     for decl in body.split("{", 1)[1].split(";"):
         decl = decl.strip()
         if not decl:
             continue
-        parts = decl.replace("*", " ").split()
-        first = parts[-1] if "," not in decl else None
         if "," in decl:
             head, *rest = decl.split(",")
             names.append(head.replace("*", " ").split()[-1])
-            names += [r.strip().lstrip("*") for r in rest]
+            names += [r.strip().lstrip("*").strip() for r in rest]
         else:
-            names.append(first)
+            names.append(decl.replace("*", " ").split()[-1])
+    return names
+
+
+@pytest.mark.parametrize("struct,mirror", [("moy_gemm_args", "GemmArgs"), ("moy_c2f_args", "C2fArgs"), ("moy_decoder_tail_args", "DecoderTailArgs"),
+                                           ("moy_decoder_mid_args", "DecoderMidArgs"), ("moy_msda_raw_args", "MsdaRawArgs")])
+def test_args_layout_matches_header(struct, mirror):
+    """Field order of every ctypes mirror == field order of its struct in include/moyolo.h (round 5: w_packed / wc_packed appended)."""
     # arrays: `int32_t run_tok0[4]` in the header <-> ("run_tok0", c_int32 * 4) in the mirror
     want = []
-    for f in _lib.GemmArgs._fields_:
+    for f in getattr(_lib, mirror)._fields_:
         n_el = getattr(f[1], "_length_", None)
         want.append(f"{f[0]}[{n_el}]" if n_el else f[0])
-    assert names == want
+    assert _header_fields(struct) == want
+
+
+def test_pack_mfma_a_is_the_layout_the_header_states():
+    """ops.pack_mfma_a against the definition in include/moyolo.h (above moy_decoder_tail_args): the 16-byte piece of lane (r, q), half j,
+    32-row group g, 32-column panel pn sits at byte (((g * (K/32) + pn) * 2 + j) * 64 + lane) * 16 and holds W[32 g + 16 j + r][32 pn + 8 q .. + 7]."""
+    import torch
+    from mo_yolo_amd.ops import pack_mfma_a
+    N, K = 96, 128
+    W = torch.arange(N * K, dtype=torch.int32).view(N, K).to(torch.int16)        # distinct 16-bit values
+    P = pack_mfma_a(W).reshape(-1)
+    for g, pn, j, lane in [(0, 0, 0, 0), (2, 3, 1, 63), (1, 2, 0, 17), (2, 0, 1, 48), (0, 3, 1, 5)]:
+        r, q = lane & 15, lane >> 4
+        off = (((g * (K // 32) + pn) * 2 + j) * 64 + lane) * 8                      # in 16-bit elements
+        assert torch.equal(P[off:off + 8], W[32 * g + 16 * j + r, 32 * pn + 8 * q:32 * pn + 8 * q + 8])
+    assert sorted(P.tolist()) == sorted(W.reshape(-1).tolist())                   # a permutation
 
 
 def test_version_and_errors_no_gpu_needed():
