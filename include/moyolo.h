@@ -282,8 +282,13 @@ typedef struct moy_decoder_tail_args {
    * (with_pos_embed, transformer.py:637-638), element pairs added in fp32 and rounded once, as moy_gemm forms A + A2 */
   const void* qpos; int64_t ld_qpos;
   void* out_xp; int64_t ld_xp;
-  /* round 5: 1 = Wp, W1, W2, B0, B1 are given in MFMA-FRAGMENT ORDER (below) instead of row-major; results are identical */
+  /* round 5: 1 = Wp, W1, W2, B0, B1 (and Wqkv) are given in MFMA-FRAGMENT ORDER (above) instead of row-major; results are identical */
   int32_t w_packed;
+  /* round 5, optional (qkv = NULL: off): the in_proj of the NEXT layer's self-attention on the rows while they are on chip --
+   * qkv[:, 0:512] = (out + qpos) Wqkv[0:512]^T + bqkv[0:512] (q | k, transformer.py:637-639), qkv[:, 512:768] = out Wqkv[512:768]^T +
+   * bqkv[512:768] (v, :640); Wqkv T [768, 256] (in_proj_weight), bqkv fp32 [768], qkv T [M, >= 768]; needs qpos; the same bits as
+   * moy_gemm over out / out_xp */
+  const void* Wqkv; const float* bqkv; void* qkv; int64_t ld_qkv;
 } moy_decoder_tail_args;
 
 int moy_decoder_tail(const moy_decoder_tail_args* args, void* stream);

@@ -46,6 +46,7 @@ class DecoderTailArgs(C.Structure):
         ("B0", vp), ("c0", vp), ("B1", vp), ("c1", vp), ("w2", vp), ("c2", vp),
         ("ref_in", vp), ("ref_out", vp), ("dtype", i32),
         ("qpos", vp), ("ld_qpos", i64), ("out_xp", vp), ("ld_xp", i64), ("w_packed", i32),
+        ("Wqkv", vp), ("bqkv", vp), ("qkv", vp), ("ld_qkv", i64),
     ]
 
 

@@ -314,7 +314,8 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
     __syncthreads();
     wstamp(c, 3);
     stamp(4);
-    gemm_acc(XA, acc3, c + 1 < nchunk ? WSrc{p.W1, (c + 1) * 256, 256, 0} : WSrc{p.B0, 0, 256, 0});   // next: the following chunk, or the box head's first layer
+    gemm_acc(XA, acc3, c + 1 < nchunk ? WSrc{p.W1, (c + 1) * 256, 256, 0}
+                                      : (p.qkv ? WSrc{p.Wqkv, 512, 256, 0} : WSrc{p.B0, 0, 256, 0}));   // next: the following chunk; then v of the next layer, or the box head's first layer
     stamp(14);
     wstamp(c, 4);
     __syncthreads();                                 // XA is rewritten by the next chunk (or by e3 below)
@@ -348,17 +349,46 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
       if (m0 + row < p.M) {
         const u32x4 e = *reinterpret_cast<const u32x4*>(XA + row * 512 + ((c ^ (row & 15)) << 4));
         *reinterpret_cast<u32x4*>(Og + (int64_t)(m0 + row) * p.ld_out + c * 8) = e;
-        if (Xg) {
+        if (Xg || p.qkv) {
           const u32x4 qv = *reinterpret_cast<const u32x4*>(Qg + (int64_t)(m0 + row) * p.ld_qpos + c * 8);
           u32x4 sx;
           sx.x = DT<T>::pack2(DT<T>::lo(e.x) + DT<T>::lo(qv.x), DT<T>::hi(e.x) + DT<T>::hi(qv.x));
           sx.y = DT<T>::pack2(DT<T>::lo(e.y) + DT<T>::lo(qv.y), DT<T>::hi(e.y) + DT<T>::hi(qv.y));
           sx.z = DT<T>::pack2(DT<T>::lo(e.z) + DT<T>::lo(qv.z), DT<T>::hi(e.z) + DT<T>::hi(qv.z));
           sx.w = DT<T>::pack2(DT<T>::lo(e.w) + DT<T>::lo(qv.w), DT<T>::hi(e.w) + DT<T>::hi(qv.w));
-          *reinterpret_cast<u32x4*>(Xg + (int64_t)(m0 + row) * p.ld_xp + c * 8) = sx;
+          if (Xg) *reinterpret_cast<u32x4*>(Xg + (int64_t)(m0 + row) * p.ld_xp + c * 8) = sx;
+          if (p.qkv) *reinterpret_cast<u32x4*>(XB + row * 512 + ((c ^ (row & 15)) << 4)) = sx;     // XB: e2 is no longer needed
         }
       }
     }
+  }
+  // ---- round 5, optional: q | k | v of the NEXT layer's self-attention (transformer.py:637-640: q = k = (out + query_pos) Wq|k^T + b,
+  //      v = out Wv^T + b) while the layer output is still on chip: three more products of the kind above instead of two launches that
+  //      read out / out + query_pos back (0.075 ms per layer at 86 400 rows against ~0.03 ms here); the bits are those of moy_gemm
+  if (p.qkv) {
+    __syncthreads();                                   // out + query_pos complete in XB
+    T* Qg = static_cast<T*>(p.qkv);
+    auto project = [&](const unsigned char* As, int row0, const WSrc& next) {
+      f32x4 bq[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bq[j] = *reinterpret_cast<const f32x4*>(p.bqkv + row0 + wave * WC + j * 16 + q * 4);   // before the product: nothing queued ahead
+      zero(acc);
+      gemm_acc(As, acc, next);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = row0 + wave * WC + j * 16 + q * 4;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int m = m0 + i * 16 + r;
+          const f32x4 v = acc[i][j] + bq[j];
+          if (m < p.M) *reinterpret_cast<u32x2*>(Qg + (int64_t)m * p.ld_qkv + n) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+        }
+      }
+    };
+    project(XA, 512, WSrc{p.Wqkv, 0, 256, 0});        // v from out; next: q
+    project(XB, 0, WSrc{p.Wqkv, 256, 256, 0});        // q from out + query_pos; next: k
+    project(XB, 256, WSrc{p.B0, 0, 256, 0});          // k; next: the box head's first layer
+    __syncthreads();                                   // XB is rewritten by the box head
   }
 
   // ---- P3: box head on e3 (XA): t1 -> XB, t2 in registers, 4 dots per row, refinement
@@ -456,6 +486,9 @@ extern "C" int moy_decoder_tail(const moy_decoder_tail_args* a, void* stream) {
   if (a->d_ffn > TAIL_MAX_FFN) return MOY_ENOSYS;                       // linear1's bias is staged in LDS whole (512 threads x 4 floats)
   if (a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_ENOSYS;   // fp32: the separate launches (the parity path)
   if ((a->ld_samp % 8) || (a->ld_e1 % 8) || (a->ld_out % 8) || a->ld_samp < 256 || a->ld_e1 < 256 || a->ld_out < 256) return MOY_EINVAL;
+  if (a->qkv && (!a->Wqkv || !a->bqkv || !a->qpos || (a->ld_qkv % 4) || a->ld_qkv < 768 || (a->ld_qpos % 8) || a->ld_qpos < 256 || !aligned16(a->Wqkv) ||
+                 !aligned16(a->bqkv) || !aligned16(a->qpos) || (reinterpret_cast<uintptr_t>(a->qkv) & 7)))
+    return MOY_EINVAL;
   if (a->out_xp && (!a->qpos || (a->ld_xp % 8) || (a->ld_qpos % 8) || a->ld_xp < 256 || a->ld_qpos < 256 || !aligned16(a->out_xp) || !aligned16(a->qpos)))
     return MOY_EINVAL;
   if (!aligned16(a->samp) || !aligned16(a->out) || !aligned16(a->Wp) || !aligned16(a->W1) || !aligned16(a->W2) || !aligned16(a->B0) ||

@@ -745,7 +745,13 @@ class TrackEngine:
         # 33.24 / 33.28 ms per step, on by default
         use_xp = (self.dtype != torch.float32 and arch.d_ffn % 256 == 0 and os.environ.get("MOY_DEC_TAIL", "1") != "0"
                   and os.environ.get("MOY_QKV_SPLIT", "1") != "0" and (M >= 65536 or os.environ.get("MOY_QKV_SPLIT") == "2"))
-        xp = View(self._buf(M, hd)) if use_xp else None
+        # round 5, OFF by default (MOY_QKV_FUSE=1): the fused tail of layer i can also PROJECT q | k | v of layer i + 1 while its rows are on
+        # chip, instead of the two plain products over `xp`.  Bit-identical (tests), 10 launches fewer per pass -- and measured neutral: the three
+        # extra products cost the tail what the two launches cost (sum of a pass's kernels 17.795 against 17.771 ms, step 64.40 / 64.51 against
+        # 64.25 / 64.76 ms, two interleaved pairs): 1.4 MB of weights per 128-row tile is the tail's price per product, the plain products pay it once
+        fuse_qkv = use_xp and os.environ.get("MOY_QKV_FUSE", "0") == "1"
+        qkv_ready = False
+        xp = View(self._buf(M, hd)) if use_xp and not fuse_qkv else None
         from .ops import pack_mfma_a
         packed_w = os.environ.get("MOY_W_PACKED", "1") != "0"       # the row-wise decoder kernels' weights in MFMA-fragment order
         xp_ready = False
@@ -753,7 +759,9 @@ class TrackEngine:
             q = f"{d}.decoder.layers.{i}"
             # q | k | v in one launch: q = k = x + pos for the first 2*hd columns, v = x for the rest (transformer.py:637-640)
             x = embed[ecur]
-            if i > 0 and xp_ready:
+            if i > 0 and qkv_ready:
+                pass                                   # the previous layer's tail wrote q | k | v of this layer
+            elif i > 0 and xp_ready:
                 # the previous layer's tail left x + query_pos in `xp`: q | k and v as two PLAIN products (at bench scale they take
                 # the weight-stationary kernel, which has no second A operand)
                 Wi, bi = sd[q + ".self_attn.in_proj_weight"], sd[q + ".self_attn.in_proj_bias"]
@@ -851,14 +859,25 @@ class TrackEngine:
                 t.B0, t.c0, t.B1, t.c1, t.w2, t.c2 = (B0.data_ptr(), c0.data_ptr(), B1.data_ptr(), c1.data_ptr(), w2h.data_ptr(),
                                                       c2.data_ptr())
                 t.ref_in, t.ref_out, t.dtype = refs[cur].data_ptr(), refs[nxt].data_ptr(), code
-                if use_xp and i + 1 < ndl:
+                wq_next = None
+                if fuse_qkv and i + 1 < ndl:
+                    qn = f"{d}.decoder.layers.{i + 1}"
+                    wq_next, bq_next = self._linear_w_raw(sd[qn + ".self_attn.in_proj_weight"], sd[qn + ".self_attn.in_proj_bias"])
+                    if packed_w:
+                        wq_next = pack_mfma_a(wq_next)
+                    t.Wqkv, t.bqkv, t.qkv, t.ld_qkv = wq_next.data_ptr(), bq_next.data_ptr(), qkv.ptr, qkv.ld
+                    t.qpos, t.ld_qpos = qpos.ptr, qpos.ld
+                    self._keep += [wq_next, bq_next]
+                    qkv_ready = True
+                elif use_xp and i + 1 < ndl:
                     t.qpos, t.ld_qpos, t.out_xp, t.ld_xp = qpos.ptr, qpos.ld, xp.ptr, xp.ld
                     xp_ready = True
                 self._keep += [t, Wp, W1, W2, B0, B1]
-                wb = (3 * hd * hd + 2 * hd * arch.d_ffn) * 2
+                wb = (3 * hd * hd + 2 * hd * arch.d_ffn + (3 * hd * hd if wq_next is not None else 0)) * 2
                 self._add(lib.moy_decoder_tail, C.byref(t),
-                          meta=dict(name=f"decoder_tail M{M}", bytes=3 * M * hd * 2 + wb + M * 32,
-                                    flops=2 * M * hd * (3 * hd + 2 * arch.d_ffn)))
+                          meta=dict(name=f"decoder_tail{'+qkv' if wq_next is not None else ''} M{M}",
+                                    bytes=(3 + (4 if wq_next is not None else 0)) * M * hd * 2 + wb + M * 32,
+                                    flops=2 * M * hd * (3 * hd + 2 * arch.d_ffn + (3 * hd if wq_next is not None else 0))))
             else:
                 self._gemm(samp, Wp, hd, hd, e2, M, shift=bp, R=e1, ln=self._ln(q + ".norm2"))
                 self._gemm(e2, W1, arch.d_ffn, hd, ffn, M, shift=b1, act=L.ACT_RELU)

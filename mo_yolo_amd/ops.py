@@ -253,9 +253,10 @@ def pack_mfma_a(W):
     return W.contiguous().view(N // 32, 2, 16, K // 32, 4, 8).permute(0, 3, 1, 4, 2, 5).contiguous().view(N, K)
 
 
-def decoder_tail(samp, e1, Wp, bp, ln2, W1, b1, W2, b2, ln3, B0, c0, B1, c1, w2, c2, ref_in, packed=False):
+def decoder_tail(samp, e1, Wp, bp, ln2, W1, b1, W2, b2, ln3, B0, c0, B1, c1, w2, c2, ref_in, packed=False, next_qkv=None):
     """See moy_decoder_tail.  samp / e1 [M, 256] 16-bit; weights in that dtype ([out, in]; packed=True: each through pack_mfma_a);
-    vectors fp32; ref_in fp32 [M, 4].  Returns (out [M, 256], ref_out fp32 [M, 4])."""
+    vectors fp32; ref_in fp32 [M, 4].  Returns (out [M, 256], ref_out fp32 [M, 4]); with next_qkv = (Wqkv [768, 256], bqkv fp32 [768],
+    qpos [M, 256]) also the next layer's q | k | v [M, 768]."""
     _need_gpu(samp, e1)
     M = samp.shape[0]
     out = torch.empty(M, 256, device=samp.device, dtype=samp.dtype)
@@ -267,8 +268,13 @@ def decoder_tail(samp, e1, Wp, bp, ln2, W1, b1, W2, b2, ln3, B0, c0, B1, c1, w2,
     t.ln3_g, t.ln3_b, t.out, t.ld_out = ln3[0].data_ptr(), ln3[1].data_ptr(), out.data_ptr(), 256
     t.B0, t.c0, t.B1, t.c1, t.w2, t.c2 = B0.data_ptr(), c0.data_ptr(), B1.data_ptr(), c1.data_ptr(), w2.data_ptr(), c2.data_ptr()
     t.ref_in, t.ref_out, t.dtype, t.w_packed = ref_in.data_ptr(), ref_out.data_ptr(), _code(samp), int(packed)
+    qkv = None
+    if next_qkv is not None:
+        Wqkv, bqkv, qpos = next_qkv
+        qkv = torch.empty(M, 768, device=samp.device, dtype=samp.dtype)
+        t.Wqkv, t.bqkv, t.qkv, t.ld_qkv, t.qpos, t.ld_qpos = Wqkv.data_ptr(), bqkv.data_ptr(), qkv.data_ptr(), 768, qpos.data_ptr(), _ld(qpos)
     L.check(L.lib().moy_decoder_tail(C.byref(t), _st()), "moy_decoder_tail")
-    return out, ref_out
+    return (out, ref_out) if qkv is None else (out, ref_out, qkv)
 
 
 def decoder_mid(attn, x, qpos, Wo, bo, ln1, Woa, boa, n_oa, packed=False):

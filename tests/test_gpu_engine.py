@@ -466,6 +466,12 @@ def test_decoder_plan_variants_are_bit_identical(dt, monkeypatch):
     assert len(nb) == len(na) + (arch.ndl - 1), (len(na), len(nb))                  # one more launch per layer after the first
     for k in keys:
         assert torch.equal(a[k], b[k]), ("qkv split", k)
+    # (iii, round 5) the next layer's q | k | v projected by the fused tail itself (`MOY_QKV_FUSE=1`): one launch fewer per layer after the first
+    f, nf, _ = run("tiny", 3, {"MOY_QKV_SPLIT": "2", "MOY_QKV_FUSE": "1"})
+    assert len(nf) == len(na) - (arch.ndl - 1) and sum("decoder_tail+qkv" in n for n in nf) == arch.ndl - 1, nf
+    for k in keys:
+        assert torch.equal(a[k], f[k]), ("qkv fused into the tail", k)
+    monkeypatch.setenv("MOY_QKV_FUSE", "0")
     monkeypatch.setenv("MOY_QKV_SPLIT", "0")
     c, nc_, _ = run("c2", 5, {"MOY_SCORE_RUNS": "0"})
     d, nd, _ = run("c2", 5, {"MOY_SCORE_RUNS": "1"})

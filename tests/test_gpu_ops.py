@@ -816,6 +816,18 @@ def test_decoder_tail_one_launch_equals_separate(dt, M, dffn):
     out_p, ref_p = ops.decoder_tail(sd_, e1d, pk(Wp), d(bp), (d(g2), d(be2)), pk(W1), d(b1), pk(W2), d(b2), (d(g3), d(be3)),
                                     pk(B0), d(c0), pk(B1), d(c1), d(w2), d(c2), d(ref_in), packed=True)
     assert torch.equal(out_p, out) and torch.equal(ref_p, ref_out)
+    # ... and with the NEXT layer's q | k | v projection on the rows while they are on chip (round 5): the bits of moy_gemm over
+    # out / out + query_pos (transformer.py:637-640)
+    Wqkv, bqkv, qpos = g(768, 256, seed=21, scale=1 / 16), g(768, seed=22, scale=0.2), g(M, 256, seed=23).to(DEV, dt)
+    for pack in (False, True):
+        wq = ops.pack_mfma_a(pw(Wqkv)) if pack else pw(Wqkv)
+        ws = [pk(w) if pack else pw(w) for w in (Wp, W1, W2, B0, B1)]
+        o3, r3_, qkv = ops.decoder_tail(sd_, e1d, ws[0], d(bp), (d(g2), d(be2)), ws[1], d(b1), ws[2], d(b2), (d(g3), d(be3)),
+                                        ws[3], d(c0), ws[4], d(c1), d(w2), d(c2), d(ref_in), packed=pack, next_qkv=(wq, d(bqkv), qpos))
+        assert torch.equal(o3, out) and torch.equal(r3_, ref_out)
+        qk_ref = ops.gemm(out, pw(Wqkv[:512]), 512, 256, shift=d(bqkv[:512]), A2=qpos)
+        v_ref = ops.gemm(out, pw(Wqkv[512:]), 256, 256, shift=d(bqkv[512:]))
+        assert torch.equal(qkv[:, :512], qk_ref) and torch.equal(qkv[:, 512:], v_ref)
     # separate launches
     e2 = ops.gemm(sd_, pw(Wp), 256, 256, shift=d(bp), R=e1d, ln=(d(g2), d(be2)))
     h = ops.gemm(e2, pw(W1), dffn, 256, shift=d(b1), act=L.ACT_RELU)
