@@ -49,6 +49,8 @@ __device__ __forceinline__ f32x4 sl1_mfma<f16_t>(f32x4 acc, u32x4 w, u32x4 a) {
 constexpr int SL1_TH = 8;
 
 template <typename T, int DIAG = 0>     // DIAG = 1: s_memtime stamps of wave 0 (diagnostic build, MOY_SL1_DIAG=1; output garbage at the head of `out`)
+                                        // DIAG = 2 / 3 / 4: stamps + timing-only ablations of the stem phase (results garbage): 2 = no SiLU (BN only),
+                                        // 3 = no fragment build (the window dwords go to the MFMA as they are), 4 = both
 __global__ __launch_bounds__(512, 4) void stem_l1_kernel(const StemL1Params p) {
   constexpr int TH = SL1_TH, C1 = 32, N1 = 64;
   constexpr int PW = 33, PH = 2 * TH + 1, NPIX = PH * PW;              // layer-1 patch of stem pixels
@@ -208,14 +210,15 @@ __global__ __launch_bounds__(512, 4) void stem_l1_kernel(const StemL1Params p) {
         hi = 0;
       }
       // bytes -> the halfs 1024 + x: [b, 0x64] per 16-bit slot, one v_perm_b32 per pair (selector byte 4 = a byte of the constant)
-      const u32x4 af = {__builtin_amdgcn_perm(0x64646464u, lo, 0x04010400u), __builtin_amdgcn_perm(0x64646464u, lo, 0x04030402u),
-                        __builtin_amdgcn_perm(0x64646464u, hi, 0x04010400u), __builtin_amdgcn_perm(0x64646464u, hi, 0x04030402u)};
+      u32x4 af = {__builtin_amdgcn_perm(0x64646464u, lo, 0x04010400u), __builtin_amdgcn_perm(0x64646464u, lo, 0x04030402u),
+                  __builtin_amdgcn_perm(0x64646464u, hi, 0x04010400u), __builtin_amdgcn_perm(0x64646464u, hi, 0x04030402u)};
+      if constexpr (DIAG == 3 || DIAG == 4) af = u32x4{d0, d1, d2, d0};      // ablation: one aligned read of three dwords, nothing built
       const int sy = 2 * t.y0 - 1 + row, sx = 2 * t.x0 - 1 + col;
       const bool inside = pix < NPIX && (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws;   // outside: layer 1's zero padding
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         f32x4 v = sl1_mfma<f16_t>(f32x4{0.f, 0.f, 0.f, 0.f}, w0f[j], af) * sc0[j] + sh0[j];
-        v.x = siluf_(v.x); v.y = siluf_(v.y); v.z = siluf_(v.z); v.w = siluf_(v.w);
+        if constexpr (DIAG != 2 && DIAG != 4) { v.x = siluf_(v.x); v.y = siluf_(v.y); v.z = siluf_(v.z); v.w = siluf_(v.w); }
         u32x2 o = {DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
         if (!inside) o = u32x2{0u, 0u};
         if (pix < NPIX)
@@ -306,11 +309,11 @@ static int launch_stem_l1(StemL1Params& p, hipStream_t st) {
   constexpr int LDS = WIN_B + PATCH_B + STG_B + 128;
   static int diag = -1;
   if (diag < 0) diag = garbage_mode_env("MOY_SL1_DIAG");
-  auto kern = diag ? stem_l1_kernel<T, 1> : stem_l1_kernel<T, 0>;
+  auto kern = diag == 4 ? stem_l1_kernel<T, 4> : diag == 3 ? stem_l1_kernel<T, 3> : diag == 2 ? stem_l1_kernel<T, 2> : diag ? stem_l1_kernel<T, 1> : stem_l1_kernel<T, 0>;
   static bool attr_set = false;
   if (!attr_set) {
     if (LDS > 65536 && (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_l1_kernel<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
-                        hipFuncSetAttribute(reinterpret_cast<const void*>(stem_l1_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess))
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess))
       return MOY_ELAUNCH;
     attr_set = true;
   }

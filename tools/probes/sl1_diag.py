@@ -17,7 +17,7 @@ e0.record()
 for _ in range(5): f()
 e1.record(); torch.cuda.synchronize()
 print(f"stem+l1 fused B={B}: {e0.elapsed_time(e1) / 5 * 1e3:.1f} us")
-if os.environ.get("MOY_SL1_DIAG") == "1":
+if os.environ.get("MOY_SL1_DIAG") in ("1", "2", "3", "4"):
     d = out.view(torch.int64).flatten()[:8].cpu().tolist()
     n = max(d[7], 1)
     names = ["store_window", "barrier W", "stem", "barrier P", "layer1+epilogue", "barrier S", "stores"]
