@@ -199,13 +199,15 @@ __global__ __launch_bounds__(512, 4) void stem_l1_kernel(const StemL1Params p) {
       const int col = s33 < 17 ? 2 * s33 : 2 * (s33 - 17) + 1;
       // window coordinates of the stem pixel's 3x3 input patch: rows 2 row .. +2, bytes 6 col .. +8 (+ the row phase)
       const int rsel = min(2 * row + min(q, 2), WR - 1);
-      const int p0 = rsel * ROWB + PHASE + 6 * col;
+      // (24-bit multiplies: v_mul_lo_u32 / v_mad_u64_u32 issue at a quarter of the rate, and this loop is bound by vector issue)
+      const int c6 = __mul24(col, 6);
+      const int p0 = __mul24(rsel, ROWB) + PHASE + c6;
       const uint32_t* wp = reinterpret_cast<const uint32_t*>(win + (p0 & ~3));
       const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2];
       const int sh = p0 & 3;
       uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
       if (q == 3) {                                     // slice 3: the ninth byte of the three rows, then zeros
-        const int pb = min(2 * row, WR - 3) * ROWB + PHASE + 6 * col + 8;
+        const int pb = __mul24(min(2 * row, WR - 3), ROWB) + PHASE + c6 + 8;
         lo = (uint32_t)win[pb] | ((uint32_t)win[pb + ROWB] << 8) | ((uint32_t)win[pb + 2 * ROWB] << 16);
         hi = 0;
       }
