@@ -5,7 +5,8 @@
 // As two launches (out_proj + LayerNorm 66 us, offsets + weights 60 us per layer at 288 frames x 300 rows, both on the tiled GEMM:
 // K = 256 is four k steps, so each is mostly pipeline fill, epilogue and drain) this was 0.75 ms of a 22.3 ms pass.  Structure =
 // csrc/dec_tail.hip (a block owns 128 rows for the whole chain, activation tiles in LDS with XOR-swizzled 512-byte rows, each of the 8
-// waves holds its 32 output columns of the current weight matrix in registers, K halves re-requested as soon as consumed):
+// waves holds its 32 output columns of the current weight matrix in registers, K halves re-requested as soon as consumed; round 5: weights in
+// MFMA-fragment order when the caller says so, the residual tile / fp32 vectors / query_pos tile requested up front -- no epilogue reads global memory):
 //   * P1: attn tile . Wo^T, + bias + residual rows of x, one-pass LayerNorm (lane partials, xor-shuffles, per-wave partials in LDS)
 //         -> e1, rounded to the storage type: to LDS (the next product's operand) and, in whole 512-byte rows, to global memory
 //         (decoder_tail's residual);

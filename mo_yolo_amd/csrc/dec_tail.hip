@@ -7,7 +7,11 @@
 // 96 frames x 300 rows: latency chains over a problem that does not fill the chip, with e2, the 1024-wide hidden activation and
 // e3 making round trips through memory.  Structure = csrc/mlp_head.hip, extended:
 //   * a block owns 128 rows for the whole chain; the current activation tile lives in LDS (two 64 KB tiles, XOR-swizzled 512-byte
-//     rows); each of the 8 waves keeps its 32 output columns of the current weight chunk in registers (MFMA A operand);
+//     rows); each of the 8 waves keeps its 32 output columns of the current weight chunk in registers (MFMA A operand), requested
+//     panel by panel 7/8 of a product ahead, from weights in MFMA-fragment order when the caller says so (round 5: a row-major
+//     fragment load is 32 isolated 16-byte pieces per instruction);
+//   * no epilogue reads global memory (round 5): the fp32 vectors are staged in LDS once per block, the residual tile sits in the
+//     buffer the LayerNorm output replaces in place -- a load issued in an epilogue returned only behind the next product's weights;
 //   * the FFN runs in d_ffn/256 chunks: h_c = relu(e2 . W1_c^T) -> LDS tile, acc3 += h_c . W2[:, c]^T, so the 1024-wide hidden
 //     activation never exists outside LDS; every intermediate is rounded to the storage type exactly where the separate launches
 //     stored it, and every product uses their k order;
@@ -77,12 +81,10 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
   };
   if constexpr (ABL >= 2) tprev = __builtin_amdgcn_s_memtime();
 
-  // This wave's 32 output rows of the current [*, pitch] weight matrix (k columns koff .. koff+255) as two K HALVES of four
-  // 32-wide panels: wa[0] = panels 0-3, wa[1] = panels 4-7.  Round 3: a product walks its K halves OUTERMOST (both row halves of
-  // half 0, then both of half 1; every accumulator still sees its panels in the order 0..7, so results are unchanged), and the
-  // moment a half has been consumed the SAME registers are re-requested with that half of the NEXT product's weights -- the load
-  // is in flight under the remaining MFMAs of this product, its epilogue and the barrier.  Round 2 fetched a whole chunk after
-  // the product that used the previous one (two chunks live = spills) and measured 36 % of the kernel waiting for those loads.
+  // This wave's 32 output rows of the current [*, pitch] weight matrix (k columns koff .. koff+255) as eight 32-wide panels:
+  // wa[0] = panels 0-3, wa[1] = panels 4-7.  Round 2 fetched a whole chunk after the product that used the previous one (two chunks
+  // live = spills) and measured 36 % of the kernel waiting for those loads; round 3 re-requested the registers by K HALVES the moment
+  // a half had been consumed; round 5 does it panel by panel (below).
   u32x4 wa[2][NT][4];
   struct WSrc { const void* W; int row0, pitch, koff; };
   bool w_loaded = false;
