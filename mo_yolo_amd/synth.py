@@ -68,6 +68,49 @@ class SyntheticSequence:
     def frames(self, t0: int, n: int) -> np.ndarray:
         return np.stack([self.frame(t) for t in range(t0, t0 + n)])
 
+    def frames_torch(self, t0: int, n: int, device="cpu", chunk: int = 48) -> torch.Tensor:
+        """uint8 [n, H, W, 3] frames t0 .. t0+n-1 drawn ON `device` with torch integer ops: the same bytes as `frames` (integer
+        arithmetic only; tests/test_host_logic.py holds the two to each other), without the host loop -- a rank that starts with
+        3 x 1152 frames spends seconds instead of half a minute, and eight ranks do not queue for the host cores.
+        A later rectangle overwrites an earlier one exactly as the painting loop of `frame` does."""
+        dev = torch.device(device)
+        H, W = self.H, self.W
+        i16 = torch.int16
+        bg = torch.as_tensor(self.bg, dtype=i16, device=dev).repeat_interleave(16, 0).repeat_interleave(16, 1)       # [H, W, 3]
+        tex = torch.as_tensor(self.tex, dtype=i16, device=dev)
+        noise = torch.as_tensor(self.noise, dtype=i16, device=dev)
+        col = torch.as_tensor(self.col, dtype=i16, device=dev)
+        ys = torch.arange(H, device=dev, dtype=torch.int32)[None, :, None]
+        xs = torch.arange(W, device=dev, dtype=torch.int32)[None, None, :]
+        out = torch.empty(n, H, W, 3, dtype=torch.uint8, device=dev)
+        for c0 in range(0, n, chunk):
+            ts = list(range(t0 + c0, t0 + min(n, c0 + chunk)))
+            m = len(ts)
+            img = bg[None].repeat(m, 1, 1, 1)
+            for k, t in enumerate(ts):                         # (two cheap ops per frame; the per-rectangle work below is batched)
+                img[k] += torch.roll(tex, t % 32, 1).repeat(H // 32, W // 32, 1)
+                oy, ox = (17 * t) % 64, (29 * t) % 64
+                img[k] += noise[oy:oy + H, ox:ox + W]
+            tt = np.asarray(ts, dtype=np.int64)[:, None]
+            x = (self.x0[None] + self.vx[None] * tt) // 16
+            y = (self.y0[None] + self.vy[None] * tt) // 16
+            x1 = np.clip(x, 0, W - 1); y1 = np.clip(y, 0, H - 1)
+            x2 = np.clip(x + self.w[None], 0, W); y2 = np.clip(y + self.h[None], 0, H)
+            vis = (x2 - x1 >= 4) & (y2 - y1 >= 4)
+            # an invisible rectangle becomes an empty one
+            x2 = np.where(vis, x2, x1); y2 = np.where(vis, y2, y1)
+            X1, Y1, X2, Y2 = (torch.as_tensor(v, dtype=torch.int32, device=dev) for v in (x1, y1, x2, y2))    # [m, n_obj]
+            for i in range(self.n_obj):                        # painting order = object order (frame(): later objects on top)
+                ry = (ys >= Y1[:, i, None, None]) & (ys < Y2[:, i, None, None])                                 # [m, H, 1]
+                rx = (xs >= X1[:, i, None, None]) & (xs < X2[:, i, None, None])                                 # [m, 1, W]
+                if not bool((ry.any(1) & rx.any(2)).any()):
+                    continue
+                stripe = ((ys - Y1[:, i, None, None]) & 3) == 0
+                inside = (ry & rx)[..., None]
+                img = torch.where(inside, torch.where((ry & stripe & rx)[..., None], 255 - col[i], col[i]), img)
+            out[c0:c0 + m] = img.clamp_(0, 255).to(torch.uint8)
+        return out
+
 
 def to_network_input(frames_u8: np.ndarray | torch.Tensor) -> torch.Tensor:
     """[T,H,W,3] uint8 BGR -> [T,3,H,W] float32 RGB in [0,1]; arithmetic of predictor.py:125-133."""

@@ -137,7 +137,9 @@ def test_bench_control_flow_c3_eight_ranks_gloo_dry_run():
     rm = sorted(d["config"]["rank_map"], key=lambda e: e["rank"])
     assert [e["rank"] for e in rm] == list(range(8))
     assert [e["hip_visible_devices"] for e in rm] == [str(i) for i in range(8)]      # one GPU per rank, pinned before HIP starts
-    assert [e["sequences"] for e in rm] == [[i] for i in range(8)]                   # sequence i -> rank i, nothing shared
+    # round 6: the default 1152-frame batch is cut from TWO sequences per GPU (every frame inside its 600-frame sequence):
+    # sequence i -> rank i mod 8, nothing shared
+    assert [e["sequences"] for e in rm] == [[i, i + 8] for i in range(8)]
     assert abs(d["value"] - 1152 * 4 * 8 / (d["ms_per_step"] * 4 * 1e-3)) < 1e-4 * d["value"]
     # the per-rank table that makes the first hardware run diagnosable -- 8 distinct devices, 8 sequences, 8 timings
     assert len(lines[0]) < 4096
@@ -145,8 +147,8 @@ def test_bench_control_flow_c3_eight_ranks_gloo_dry_run():
     rk = json.load(open(d["full"]))["config"]["ranks"]                           # ... the side file it names the full ones
     assert [e["rank"] for e in rk] == list(range(8)) and [e["local_rank"] for e in rk] == list(range(8))
     assert len({e["hip_visible_devices"] for e in rk}) == 8
-    assert sorted(sq for e in rk for sq in e["sequences"]) == list(range(8))
-    assert all(e["dt_local_s"] > 0 and e["fps_local"] > 0 for e in rk)
+    assert sorted(sq for e in rk for sq in e["sequences"]) == list(range(16))
+    assert all(e["dt_local_s"] > 0 and e["fps_local"] > 0 and e["startup_s"] > 0 for e in rk)
     assert max(e["dt_local_s"] for e in rk) <= d["ms_per_step"] * 4 * 1e-3 * 1.0001       # the line's time is the MAX over ranks
     cpus = [e["cpus"] for e in rk]
     assert all(c for c in cpus)
@@ -176,10 +178,88 @@ def test_bench_gpus_n_self_launches_n_ranks_without_torchrun(n, tmp_path):
     assert d["n_gpus"] == n and d["config"]["dry_run"] is True
     rk = d["config"]["ranks"]
     assert [e["rank"] for e in rk] == list(range(n)) and [e["hip_visible_devices"] for e in rk] == [str(i) for i in range(n)]
-    assert sorted(sq for e in rk for sq in e["sequences"]) == list(range(n))
+    assert sorted(sq for e in rk for sq in e["sequences"]) == list(range(2 * n))
     assert abs(d["value"] - 1152 * 3 * n / (d["ms_per_step"] * 3 * 1e-3)) < 1e-4 * d["value"]
     full = json.load(open(tmp_path / "full.json"))                 # the side file the line names holds the same headline
     assert d["full"] == str(tmp_path / "full.json") and full["value"] == d["value"] and full["n_gpus"] == n
+
+
+def _pids_with_env(tag):
+    """PIDs of live processes whose ENVIRONMENT carries MOY_TEST_TAG=<tag> (the launcher's ranks inherit it) -- never a match on
+    command lines, which would also find whatever shell happens to quote the pattern."""
+    out = []
+    needle = f"MOY_TEST_TAG={tag}".encode()
+    for d in os.listdir("/proc"):
+        if d.isdigit():
+            try:
+                with open(f"/proc/{d}/environ", "rb") as f:
+                    if needle in f.read().split(b"\0"):
+                        with open(f"/proc/{d}/stat") as g:
+                            if g.read().rsplit(")", 1)[1].split()[0] != "Z":
+                                out.append(int(d))
+            except OSError:
+                pass
+    return out
+
+
+def test_bench_self_launch_tears_the_job_down_when_a_rank_dies_at_start_up():
+    """a rank that exits before the rendezvous (a HIP_VISIBLE_DEVICES entry that does not exist, ...) must not leave rank 0
+    waiting in init_process_group for its timeout with the launcher blocked behind it: the launcher polls its ranks, terminates the
+    others on the first non-zero exit and returns that code -- in seconds, with no rank left running."""
+    import time
+    tag = f"fail{os.getpid()}"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HIP_VISIBLE_DEVICES", "LOCAL_WORLD_SIZE",
+                                                            "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="1", MOY_TEST_TAG=tag)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1", "--dry-run", "--backend", "gloo",
+                        "--fail-rank", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 7, (p.returncode, p.stderr.decode()[-1500:])
+    assert time.time() - t0 < 60
+    assert b"rank 2 failed first" in p.stderr and not [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    for _ in range(50):
+        left = _pids_with_env(tag)
+        if not left:
+            break
+        time.sleep(0.1)
+    assert not left, left
+
+
+def test_bench_self_launch_kills_its_ranks_when_it_is_terminated():
+    """... and a launcher that is itself killed (the driver's `timeout -k`) takes its ranks with it instead of leaving them on the GPUs."""
+    import signal
+    import time
+    tag = f"term{os.getpid()}"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HIP_VISIBLE_DEVICES", "LOCAL_WORLD_SIZE",
+                                                            "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="1", MOY_TEST_TAG=tag)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "100000", "--warmup", "1", "--dry-run", "--backend", "gloo"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    for _ in range(300):                                           # wait for the two ranks to exist
+        kids = [v for v in _pids_with_env(tag) if v != p.pid]
+        if len(kids) >= 2:
+            break
+        time.sleep(0.1)
+    assert len(kids) >= 2, kids
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) == 128 + signal.SIGTERM
+    for _ in range(100):
+        left = _pids_with_env(tag)
+        if not left:
+            break
+        time.sleep(0.1)
+    assert not left, left
+
+
+def test_synthetic_frames_drawn_with_torch_equal_the_numpy_definition():
+    """Round 6: bench.py draws its frames on the device (`SyntheticSequence.frames_torch`: integer torch ops, no host loop -- the
+    start-up of a rank no longer costs half a minute of host time); the numpy generator stays the definition and the two are equal
+    byte for byte, incl. rectangles that leave the frame and the striping of clipped rectangles."""
+    for sid, style, H, W in ((0, "mot17", 608, 1088), (5, "mot17", 96, 160), (1, "dancetrack", 320, 480)):
+        sq = SyntheticSequence(sid, H, W, style)
+        for t0 in (0, 297, 596):
+            n = 4 if H > 400 else 4
+            assert np.array_equal(sq.frames(t0, n), sq.frames_torch(t0, n, chunk=3).numpy()), (sid, style, t0)
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus():
