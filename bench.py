@@ -849,6 +849,8 @@ def main(argv=None):
             #                                       box      hs     score   births / active        (profiles/r04_f_bench_*.json)
             measured = {("c2", "bf16"): (4.08e-3, 0.673, 0.147, 0.0744), ("c2", "f16"): (1.07e-3, 0.115, 0.0256, 0.0153),
                         ("c4", "bf16"): (4.89e-3, 0.638, 0.0650, 0.0293)}.get((cfg_name, dtype_name))
+            if small:
+                measured = None          # (the committed windows are those of the bench-scale plan; a small-batch engine runs the classic plan)
             if measured is not None:
                 rb = tuple(round(1.5 * v, 5) for v in measured)
                 parity["regression"] = {"kind": "1.5 x this window's committed measurement (profiles/r04_f_bench_*.json)",

@@ -141,13 +141,14 @@ typedef struct moy_gemm_args {
    * value_proj outputs of the decoder layers: a layer's slice is then dense in HBM for the deformable gather). */
   int32_t plane_cols;
   int64_t plane_stride;
-  /* optional ROW RUNS (run_levels = 0: off; only with the narrow head and C == NULL, i.e. the score pass; no a_mask; 16-bit):
+  /* optional ROW RUNS (run_levels = 0: off; only with the narrow head and C == NULL, i.e. the score pass; no a_mask; 16-bit types in the
+   * weight-stationary score kernel, round 6: MOY_F32 / MOY_F32X3 in the tiled kernel at any launch size):
    * the launch visits only the rows
    *     b * run_period + run_tok0[l] + y * run_pitch[l] + x      b < M / run_period, l < run_levels, y < run_rows[l], x < run_len[l]
    * -- per batch element one rectangle of every pyramid level: the tokens whose anchors are VALID (`_generate_anchors`,
    * nn/modules/head.py:1007).  A masked token's feature is LN(enc_output.bias) whatever the frame shows (head.py:1039), so its
    * score is a constant that the caller writes once; at 1088x608 that is 46 % of the rows.  Rows outside the runs are
-   * neither read nor written.  MOY_ENOSYS when the shape does not take the weight-stationary score kernel. */
+   * neither read nor written.  MOY_ENOSYS when a 16-bit shape does not take the weight-stationary score kernel. */
   int32_t run_levels, run_period;
   int32_t run_tok0[4], run_pitch[4], run_len[4], run_rows[4];
   /* round 4: the rows of A may be numbered differently from the rows the scores are written to (A = one pyramid level's own
@@ -361,8 +362,10 @@ int moy_msda_fused(const void* value, int64_t ldv, int64_t head_stride, int B, i
  *   x0 T: level 0 as the backbone left it, [B, H0, W0, 128] channels-last with pixel pitch ld0 (>= 128) elements;
  *   wc T [256][128] / bc fp32 [256]: value_proj o BN o input_proj of THIS layer composed by the caller (W = Wv diag(s) Wp, c = Wv t + bv);
  *   planes T: head planes of levels 1 .. L-1, [8][B * S1][32] with head_stride elements between heads, S1 = tokens per frame of
- *   those levels (level-major); offaw / ref / out / shapes_hw as moy_msda_fused (shapes_hw[0] = (H0, W0)).  16-bit types only
- *   (MOY_ENOSYS otherwise: the fp32 engine keeps the projected planes); H0, W0 >= 2; a frame of level 0 below 2 GiB.
+ *   those levels (level-major; head_stride >= B * S1 * 32 or MOY_EINVAL); offaw / ref / out / shapes_hw as moy_msda_fused
+ *   (shapes_hw[0] = (H0, W0)).  H0, W0 >= 2; a frame of level 0 below 2 GiB.
+ *   Round 6: MOY_F32 / MOY_F32X3 -- fp32 x0 / wc (row-major, wc_packed = 0) / planes / out, every sum in fp32, the projection on the exact
+ *   fp32 matrix instruction (the fp32 engines' folded head; the split-fp16 engine takes this exact form too).
  *   Numerics vs moy_msda_fused over projected planes: the level-0 contribution is rounded to T once (the gathered vector, before
  *   its product) instead of once per projected value; sums in fp32. */
 typedef struct moy_msda_raw_args {
@@ -382,6 +385,9 @@ typedef struct moy_msda_raw_args {
   int64_t ldo;
   int32_t dtype;
   int32_t wc_packed;          /* round 5: 1 = wc in MFMA-fragment order (above moy_decoder_tail_args; N = 256 rows, K = 128) */
+  const int32_t* perm;        /* round 6, optional (NULL: query order): device int32 [B, Lq], perm[b][i] = the query of frame b that is
+                               * processed i-th (moy_query_order: spatial neighbours share a block, hence L1 / L2 lines).  MUST be a
+                               * permutation of 0 .. Lq-1 per frame: a row named twice is written twice, a row not named is not written. */
 } moy_msda_raw_args;
 int moy_msda_raw0(const moy_msda_raw_args* a, void* stream);
 
@@ -572,6 +578,13 @@ int moy_gather_rows(const void* src, int64_t lds, const int32_t* rows, int M, in
 int moy_cast_f32_to(const float* src, int64_t lds, int M, int N, void* dst, int64_t ldd, int dtype, void* stream);
 /* out fp32 [M, 4] = sigmoid(in fp32 [M, 4])  (refer_bbox.sigmoid(), transformer.py:694; enc_bboxes head.py:1080) */
 int moy_sigmoid_f32(const float* in, int n, float* out, void* stream);
+
+/* Round 6: processing order of a frame's decoder queries for moy_msda_raw0 (`perm`).  ref fp32 [B * Lq, 4] = the queries' reference boxes
+ * (cx, cy, w, h in [0, 1], transformer.py:676-728 refines them little from layer to layer); perm int32 [B, Lq]: perm[b][i] = the query
+ * of frame b to process i-th = the frame's queries sorted by the Morton code of the (H0 x W0)-grid cell of their centre (ties: query
+ * index).  Lq <= 1024.  A permutation of every frame by construction; it changes the order in which the gather walks the queries and
+ * nothing else (outputs bit for bit the same rows). */
+int moy_query_order(const float* ref, int B, int Lq, int H0, int W0, int32_t* perm, void* stream);
 
 /* Upstream MSDeformAttn.forward between its linears and the native op (MOTR/models/ops/modules/ms_deform_attn.py:98-116; used by
  * MOTRDeformableTransformerEncoderLayer, MOTR/models/deformable_transformer_plus.py:347-386):

@@ -64,7 +64,7 @@ class MsdaRawArgs(C.Structure):
     _fields_ = [
         ("x0", vp), ("ld0", i64), ("wc", vp), ("bc", vp), ("planes", vp), ("head_stride", i64), ("S1", i32),
         ("B", i32), ("Lq", i32), ("L", i32), ("shapes_hw", vp), ("offaw", vp), ("ld_oa", i64), ("ref", vp),
-        ("out", vp), ("ldo", i64), ("dtype", i32), ("wc_packed", i32),
+        ("out", vp), ("ldo", i64), ("dtype", i32), ("wc_packed", i32), ("perm", vp),
     ]
 
 
@@ -126,6 +126,7 @@ SIGNATURES = {
     "moy_set_cu_limit": (C.c_int, [C.c_int]),
     "moy_cast_f32_to": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
     "moy_sigmoid_f32": (C.c_int, [vp, C.c_int, vp, vp]),
+    "moy_query_order": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "moy_msda_prep": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]),
     "moy_mask_rows": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, C.c_int, vp]),
 }

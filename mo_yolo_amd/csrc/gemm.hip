@@ -60,7 +60,32 @@ struct GemmParams {
   int plane_cols;      // 0, or: column n lives in plane n / plane_cols at C + plane * plane_stride (column n % plane_cols)
   int64_t plane_stride;
   FastDiv fd_pre_hw, fd_pre_w;
+  // ROW RUNS of a score-only launch (moy_gemm_args.run_*; round 6: also in this kernel, for the fp32 engines' folded head): M counts
+  // COMPACT rows; compact row c -> b = c / run_nv, v = c % run_nv -> level l by the compact starts -> (y, x) by the run length ->
+  // token = tok0[l] + y * pitch[l] + x; A row = b * run_a_period + token - run_a_off, score row = b * run_period + token
+  int run_levels, run_period, run_nv, run_a_period, run_a_off;
+  int run_cstart[4], run_len[4], run_tok0[4], run_pitch[4];
+  FastDiv fd_nv, fd_len[4];
 };
+
+// compact row -> token of its frame and the frame index (see GemmParams.run_*).  Select chains, no dynamic index: indexing a by-value
+// kernel-parameter array with a runtime value makes hipcc copy the whole struct to scratch (the first version of this function did,
+// and the score launches ran 2.5 x slower per row)
+__device__ __forceinline__ void run_token(const GemmParams& p, int c, int& b, int& tok) {
+  b = (int)fdiv((uint32_t)c, p.fd_nv);
+  const int v = c - b * p.run_nv;
+  int cs = 0, len = p.run_len[0], tok0 = p.run_tok0[0], pitch = p.run_pitch[0];
+  uint32_t mg = p.fd_len[0].magic, shf = p.fd_len[0].shift;
+#pragma unroll
+  for (int l = 1; l < 4; ++l) {
+    const bool in = l < p.run_levels && v >= p.run_cstart[l];
+    cs = in ? p.run_cstart[l] : cs; len = in ? p.run_len[l] : len; tok0 = in ? p.run_tok0[l] : tok0; pitch = in ? p.run_pitch[l] : pitch;
+    mg = in ? p.fd_len[l].magic : mg; shf = in ? p.fd_len[l].shift : shf;
+  }
+  const uint32_t vv = (uint32_t)(v - cs);
+  const uint32_t y = (uint32_t)(((uint64_t)__umulhi(vv, mg) + vv) >> shf);
+  tok = tok0 + (int)y * pitch + (int)(vv - y * (uint32_t)len);
+}
 
 // 16-B column swizzle: lanes of one ds_read_b128 lane group hit distinct bank quartets.
 __device__ __forceinline__ int swz(int row, int q) { return q ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3); }
@@ -265,7 +290,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const float* 
         for (int c = 0; c < 8; ++c)
           if (c < p.dot_n) {
             const float sdot = wave_sum(v.x * dw[c].x + v.y * dw[c].y + v.z * dw[c].z + v.w * dw[c].w);
-            if (lane == 0 && m < p.M) p.dot_out[(int64_t)m * p.dot_n + c] = sdot + p.dot_b[c];
+            if (lane == 0 && m < p.M) {
+              int64_t mr = m;
+              if (p.run_levels) { int rb_, tok_; run_token(p, m, rb_, tok_); mr = (int64_t)rb_ * p.run_period + tok_; }
+              p.dot_out[mr * p.dot_n + c] = sdot + p.dot_b[c];
+            }
           }
       }
     }
@@ -413,7 +442,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
   int b0 = 0;
   int64_t a_base = 0;                          // element offset of the descriptor base inside A
   if (KS == 1) {
-    if (!p.a_rows) a_base = (int64_t)m0 * p.lda;
+    if (!p.a_rows && !(LN && p.run_levels)) a_base = (int64_t)m0 * p.lda;
   } else {
     b0 = (int)fdiv(m0, p.fd_hw);
     a_base = (int64_t)b0 * p.Hin * p.Win * p.lda;
@@ -440,10 +469,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
     a_taps[j] = 0;
     if (m < p.M) {
       if (KS == 1) {
+        if (LN && p.run_levels) {                         // score pass over row runs: compact row -> A row (descriptor base = A itself)
+          int rb_, tok_;
+          run_token(p, m, rb_, tok_);
+          a_voff[j] = (uint32_t)(((int64_t)(rb_ * p.run_a_period + tok_ - p.run_a_off) * p.lda + kc0) * ESZ);
+        } else {
         const int arow = p.a_rows ? p.a_rows[m] : m;     // the mask belongs to the A rows (tokens), gathered or not
         const bool masked = p.a_mask && p.a_mask[arow - (int)fdiv(arow, p.fd_mask) * p.mask_period] == 0;
         const int64_t row = p.a_rows ? (int64_t)arow : (int64_t)(m - m0);
         if (!masked) a_voff[j] = (uint32_t)((row * p.lda + kc0) * ESZ);
+        }
       } else {
         const int hw = p.Hout * p.Wout;
         const int b = (int)fdiv(m, p.fd_hw), rem = m - b * hw;
@@ -1140,7 +1175,33 @@ extern "C" int moy_gemm(const moy_gemm_args* a, void* stream) {
     const int rc = gemm_wreg_try(a, st);
     if (rc != MOY_ENOSYS) return rc;
   }
-  if (a->run_levels) return MOY_ENOSYS;      // row runs exist in the weight-stationary score kernel only: the caller falls back to a_mask
+  if (a->run_levels) {
+    // row runs outside the weight-stationary score kernel (round 6): the tiled kernel takes them for the same launch kind -- LayerNorm +
+    // narrow head, rows not stored, no mask / gather / second operand -- with fp32 tensors (the folded head of the fp32 engines); a 16-bit
+    // launch the weight-stationary kernel declined stays MOY_ENOSYS (its caller falls back to a_mask, as before)
+    if (!is32 || !ln || a->C || a->a_mask || a->a_rows || a->A2 || a->pre || a->ksize != 1 || a->dot_n < 1) return MOY_ENOSYS;
+    if (a->run_levels > 4 || a->run_period <= 0 || (a->M % a->run_period)) return MOY_EINVAL;
+    if (a->run_a_period < 0 || (a->run_a_period && a->run_levels != 1)) return MOY_EINVAL;
+    int nv = 0;
+    for (int l = 0; l < 4; ++l) {
+      const bool on = l < a->run_levels;
+      if (on && (a->run_len[l] <= 0 || a->run_rows[l] <= 0 || a->run_pitch[l] < a->run_len[l] || a->run_tok0[l] < 0 ||
+                 a->run_tok0[l] + (a->run_rows[l] - 1) * a->run_pitch[l] + a->run_len[l] > a->run_period))
+        return MOY_EINVAL;
+      p.run_cstart[l] = nv; p.run_len[l] = on ? a->run_len[l] : 1; p.run_tok0[l] = on ? a->run_tok0[l] : 0; p.run_pitch[l] = on ? a->run_pitch[l] : 1;
+      p.fd_len[l] = make_fastdiv((uint32_t)p.run_len[l]);
+      if (on) nv += a->run_len[l] * a->run_rows[l];
+    }
+    const int nb_ = a->M / a->run_period;
+    p.run_levels = a->run_levels; p.run_period = a->run_period; p.run_nv = nv; p.fd_nv = make_fastdiv((uint32_t)nv);
+    p.run_a_period = a->run_a_period ? a->run_a_period : a->run_period;
+    p.run_a_off = a->run_a_period ? a->run_a_off : 0;
+    // A rows reach b * run_a_period + token - run_a_off: the descriptor spans the frames' A rows from row 0, inside one 2 GiB window
+    const int64_t a_rows_max = (int64_t)(nb_ - 1) * p.run_a_period + (a->run_period - p.run_a_off);
+    p.a_bytes = ((a_rows_max > 0 ? a_rows_max : 1) * a->lda) * esz;
+    if (p.a_bytes > 0x7fffffffLL) return MOY_ENOSYS;
+    p.M = nb_ * nv;                          // the launch walks the COMPACT rows
+  }
   if (a->ksize == 3 && !is32 && !ln) {
     const int rc = conv_ws_try(a, st);
     if (rc != MOY_ENOSYS) return rc;

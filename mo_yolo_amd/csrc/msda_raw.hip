@@ -47,9 +47,11 @@ struct MsdaRawParams {
   int64_t ld_oa;
   const float* ref;
   int Lq, nrows;
-  int ngroups;           // ceil(nrows / 16)
+  int ngroups;           // ceil(nrows / queries per block)
   void* out;
   int64_t ldo;
+  int B;
+  const int32_t* perm;   // optional [B * Lq]: position (b, i) of the walk -> query perm[b * Lq + i] of frame b (moy_query_order); NULL: identity
 };
 
 template <typename T>
@@ -76,6 +78,7 @@ __global__ __launch_bounds__(256, 3) void msda_raw_kernel(const MsdaRawParams p)
   __shared__ __attribute__((aligned(16))) unsigned char sG[MR_QB * MR_GP];
   __shared__ __attribute__((aligned(16))) unsigned char sP[MR_QB * MR_PP];
   __shared__ float sS[MR_QB * 8];
+  __shared__ int sRow[MR_QB];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // XCD-aware walk: workgroup i runs on XCD i % 8, and every XCD has its own L2 -- XCD x takes the x-th eighth of the query groups,
@@ -94,8 +97,10 @@ __global__ __launch_bounds__(256, 3) void msda_raw_kernel(const MsdaRawParams p)
 
   for (int j = 0; j < 4; ++j) {
     const int ql = wave * 4 + j;                                   // query of the block
-    const int row = min(row0 + ql, p.nrows - 1);                   // rows past the end recompute the last one (never stored)
-    const int b = __builtin_amdgcn_readfirstlane(row / p.Lq);
+    const int pos = min(row0 + ql, p.nrows - 1);                   // positions past the end recompute the last one (never stored)
+    const int b = __builtin_amdgcn_readfirstlane(pos / p.Lq);
+    const int row = p.perm ? b * p.Lq + __builtin_amdgcn_readfirstlane(p.perm[pos]) : pos;      // the walk visits the frame's queries in perm order
+    if (lane == 0) sRow[ql] = row;
     const float* oa = p.offaw + (long)row * p.ld_oa;
     const float* offp = oa + m * LP * 2;
     const float* awp = oa + 8 * LP * 2 + m * LP;
@@ -270,14 +275,14 @@ __global__ __launch_bounds__(256, 3) void msda_raw_kernel(const MsdaRawParams p)
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc2[t] = mr_mfma<T>(acc2[t], wa[t][pn], gb[pn]);
     const float s = sS[r * 8 + h];
-    const int row = row0 + r;
+    const int row = sRow[r];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int ch = h * 32 + t * 16 + q4 * 4;
       const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bc + ch);
       const f32x4 part = *reinterpret_cast<const f32x4*>(sP + r * MR_PP + ch * 4);
       const f32x4 v = acc2[t] + bias * s + part;
-      if (row < p.nrows) *reinterpret_cast<u32x2*>(out + (int64_t)row * p.ldo + ch) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+      if (row0 + r < p.nrows) *reinterpret_cast<u32x2*>(out + (int64_t)row * p.ldo + ch) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
     }
   }
 }
@@ -320,6 +325,7 @@ __global__ __launch_bounds__(64 * MRM_NW, 2) void msda_raw_mfma_kernel(const Msd
   __shared__ __attribute__((aligned(16))) uint32_t sT[MRM_NW * MRM_ENT * 8];     // per wave: [entry][T(w) x 4 | remainder x 4], each 16-bit value in both halves
   __shared__ uint32_t sB[MRM_NW * MRM_ENT];                                       // per wave: byte offset of the entry's window
   __shared__ float sS[MR_QB * 8];
+  __shared__ int sRow[MR_QB];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nblk = (int)gridDim.x, chunk = (nblk + 7) >> 3;
@@ -342,8 +348,10 @@ __global__ __launch_bounds__(64 * MRM_NW, 2) void msda_raw_mfma_kernel(const Msd
 
   for (int j = 0; j < 2; ++j) {
     const int ql = wave * 2 + j;
-    const int row = min(row0 + ql, p.nrows - 1);
-    const int b = __builtin_amdgcn_readfirstlane(row / p.Lq);
+    const int pos = min(row0 + ql, p.nrows - 1);
+    const int b = __builtin_amdgcn_readfirstlane(pos / p.Lq);
+    const int row = p.perm ? b * p.Lq + __builtin_amdgcn_readfirstlane(p.perm[pos]) : pos;      // the walk visits the frame's queries in perm order
+    if (lane == 0) sRow[ql] = row;
     const float* oa = p.offaw + (long)row * p.ld_oa;
     const float* offp = oa + m * 24;
     const float* awp = oa + 192 + m * 12;
@@ -498,14 +506,241 @@ __global__ __launch_bounds__(64 * MRM_NW, 2) void msda_raw_mfma_kernel(const Msd
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc2[t] = mr_mfma<T>(acc2[t], wa[t][pn], gb[pn]);
     const float s = sS[r * 8 + h];
-    const int row = row0 + r;
+    const int row = sRow[r];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int ch = h * 32 + t * 16 + q4 * 4;
       const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bc + ch);
       const f32x4 part = *reinterpret_cast<const f32x4*>(sP + r * MR_PP + ch * 4);
       const f32x4 v = acc2[t] + bias * s + part;
-      if (row < p.nrows) *reinterpret_cast<u32x2*>(out + (int64_t)row * p.ldo + ch) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+      if (row0 + r < p.nrows) *reinterpret_cast<u32x2*>(out + (int64_t)row * p.ldo + ch) = u32x2{DT<T>::pack2(v.x, v.y), DT<T>::pack2(v.z, v.w)};
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same operator for the fp32 engines (round 6: MOY_F32, and MOY_F32X3 whose tensors are fp32 too): level 0 gathered raw from the
+// fp32 P3 tensor (a lane owns two channels of a corner: one 8-byte load, 512 contiguous bytes per wave instruction), levels 1.. from
+// fp32 head planes, every sum in fp32, and the per-head projection on the EXACT fp32 matrix instruction (v_mfma_f32_16x16x4_f32) --
+// at 2 x 256 x 128 flops per query the projection is 1 % of the engine's arithmetic, so the split-fp16 engine takes the exact form too.
+// A block is 8 queries (4 waves x 2): the gathered vectors of a block are 8 x 8 heads x 128 fp32 = 32 KB of LDS; the projection's
+// B operand has 16 columns, the upper eight repeat the lower ones and are not stored.
+constexpr int MRF_QB = 8;
+constexpr int MRF_GP = 8 * 128 * 4 + 16;     // bytes per query row of g (fp32; +16: fragment rows start 4 banks apart)
+
+__global__ __launch_bounds__(256, 2) void msda_raw_f32_kernel(const MsdaRawParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char sG[MRF_QB * MRF_GP];
+  __shared__ __attribute__((aligned(16))) unsigned char sP[MRF_QB * MR_PP];
+  __shared__ float sS[MRF_QB * 8];
+  __shared__ int sRow[MRF_QB];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nblk = (int)gridDim.x, chunk = (nblk + 7) >> 3;
+  const int lblk = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);          // XCD-aware walk, as above
+  if (lblk >= p.ngroups) return;
+  const int row0 = lblk * MRF_QB;
+  const int m = lane >> 3, sub = lane & 7, cx = sub >> 2, oct = sub & 3;
+  const int L = p.L, LP = L * 4;
+  const float* planes = static_cast<const float*>(p.planes);
+  const float* x0 = static_cast<const float*>(p.x0);
+  constexpr uint32_t OOB = 0x80000000u;
+  const int H0 = p.lv.H[0], W0 = p.lv.W[0];
+  const uint32_t pix_pitch = (uint32_t)(p.ld0 * 4), row_pitch = (uint32_t)(W0 * p.ld0 * 4);
+
+  for (int j = 0; j < 2; ++j) {
+    const int ql = wave * 2 + j;
+    const int pos = min(row0 + ql, p.nrows - 1);                   // positions past the end recompute the last one (never stored)
+    const int b = __builtin_amdgcn_readfirstlane(pos / p.Lq);
+    const int row = p.perm ? b * p.Lq + __builtin_amdgcn_readfirstlane(p.perm[pos]) : pos;
+    if (lane == 0) sRow[ql] = row;
+    const float* oa = p.offaw + (long)row * p.ld_oa;
+    const float* offp = oa + m * LP * 2;
+    const float* awp = oa + 8 * LP * 2 + m * LP;
+    float logit[16], offx[16], offy[16];
+#pragma unroll
+    for (int i = 0; i < 16; i += 4)
+      if (i < LP) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(awp + i);
+        logit[i] = a.x; logit[i + 1] = a.y; logit[i + 2] = a.z; logit[i + 3] = a.w;
+        const f32x4 o0 = *reinterpret_cast<const f32x4*>(offp + 2 * i), o1 = *reinterpret_cast<const f32x4*>(offp + 2 * i + 4);
+        offx[i] = o0.x; offy[i] = o0.y; offx[i + 1] = o0.z; offy[i + 1] = o0.w;
+        offx[i + 2] = o1.x; offy[i + 2] = o1.y; offx[i + 3] = o1.z; offy[i + 3] = o1.w;
+      }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < LP) mx = fmaxf(mx, logit[i]);
+    float den = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < LP) { logit[i] = expf(logit[i] - mx); den += logit[i]; }       // (accurate exponential: this is the exact class)
+    const float inv_den = 1.0f / den;
+    const f32x4 rb = *reinterpret_cast<const f32x4*>(p.ref + (long)row * 4);
+
+    // ---- level 0, raw: per point the clamped 2x2 window and the four slot weights (as the 16-bit form)
+    uint32_t base0[4];
+    float w00[4], w01[4], w10[4], w11[4];
+    float sw = 0.f;
+#pragma unroll
+    for (int pnt = 0; pnt < 4; ++pnt) {
+      const float lx = rb.x + offx[pnt] / 4.0f * rb.z * 0.5f;      // loc = ref_xy + off / n_points * ref_wh * 0.5   (transformer.py:280-282)
+      const float ly = rb.y + offy[pnt] / 4.0f * rb.w * 0.5f;
+      const float x = lx * W0 - 0.5f, y = ly * H0 - 0.5f;
+      const float aw = logit[pnt] * inv_den;
+      const float xf = floorf(x), yf = floorf(y);
+      const float fx = x - xf, fy = y - yf;
+      const int xi = (int)fminf(fmaxf(xf, -2.0f), (float)W0 + 1.0f), yi = (int)fminf(fmaxf(yf, -2.0f), (float)H0 + 1.0f);
+      const float ax0 = (unsigned)xi < (unsigned)W0 ? 1.f - fx : 0.f, ax1 = (unsigned)(xi + 1) < (unsigned)W0 ? fx : 0.f;
+      const float ay0 = (unsigned)yi < (unsigned)H0 ? 1.f - fy : 0.f, ay1 = (unsigned)(yi + 1) < (unsigned)H0 ? fy : 0.f;
+      const int xb = min(max(xi, 0), W0 - 2), yb = min(max(yi, 0), H0 - 2);
+      const float sx0 = xi == xb ? ax0 : (xi + 1 == xb ? ax1 : 0.f), sx1 = xi == xb ? ax1 : (xi == xb + 1 ? ax0 : 0.f);
+      const float sy0 = yi == yb ? ay0 : (yi + 1 == yb ? ay1 : 0.f), sy1 = yi == yb ? ay1 : (yi == yb + 1 ? ay0 : 0.f);
+      base0[pnt] = (uint32_t)(yb * W0 + xb) * pix_pitch;
+      w00[pnt] = aw * sx0 * sy0; w01[pnt] = aw * sx1 * sy0; w10[pnt] = aw * sx0 * sy1; w11[pnt] = aw * sx1 * sy1;
+      sw += aw * (ax0 + ax1) * (ay0 + ay1);
+    }
+    if (sub == 0) sS[ql * 8 + m] = sw;
+
+    // ---- levels 1..: fp32 head planes; lane (m, cx, oct) reads the 8 channels oct*8.. of its x-corner: two 16-byte loads per tap row
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    {
+      const int64_t ext = (7 * p.head_stride + (int64_t)(p.B - b) * p.S1 * 32) * 4;       // bytes addressable from this frame's first token
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(planes + (int64_t)b * p.S1 * 32), 0,
+                                                        (uint32_t)(ext < 0x7fffffffLL ? ext : 0x7fffffffLL), 0x00020000);
+      const uint32_t lane_off = (uint32_t)((m * p.head_stride + oct * 8) * 4);
+#pragma unroll
+      for (int l = 1; l < 4; ++l)
+        if (l < L) {
+          const int H = p.lv.H[l], W = p.lv.W[l];
+          // two points (8 sixteen-byte loads per lane) in flight at a time: all four would cost 64 registers and spill
+#pragma unroll
+          for (int ph = 0; ph < 4; ph += 2) {
+            f32x4 tap[2][2][2];
+            float wgt[2][2];
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+              const int i = l * 4 + ph + pp;
+              const float lx = rb.x + offx[i] / 4.0f * rb.z * 0.5f;
+              const float ly = rb.y + offy[i] / 4.0f * rb.w * 0.5f;
+              const float x = lx * W - 0.5f, y = ly * H - 0.5f;
+              const float aw = logit[i] * inv_den;
+              const float xf = floorf(x), yf = floorf(y);
+              const float fx = x - xf, fy = y - yf;
+              const int xi = (int)fminf(fmaxf(xf, -2.0f), (float)W + 1.0f) + cx, y0 = (int)fminf(fmaxf(yf, -2.0f), (float)H + 1.0f);
+              const float wx = (cx ? fx : 1.f - fx) * aw;
+              const bool xin = (unsigned)xi < (unsigned)W;
+#pragma unroll
+              for (int t = 0; t < 2; ++t) {
+                const int yi = y0 + t;
+                const bool ok = xin && (unsigned)yi < (unsigned)H;
+                const uint32_t off = lane_off + (uint32_t)((p.lv.start[l] + yi * W + xi) * 128);
+                tap[pp][t][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0));
+                tap[pp][t][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : OOB, 0, 0));
+                wgt[pp][t] = wx * (t ? fy : 1.f - fy);
+              }
+            }
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+              for (int t = 0; t < 2; ++t) {
+                const float g = wgt[pp][t];
+                const f32x4 u = tap[pp][t][0], v = tap[pp][t][1];
+                acc[0] = __builtin_fmaf(u.x, g, acc[0]); acc[1] = __builtin_fmaf(u.y, g, acc[1]); acc[2] = __builtin_fmaf(u.z, g, acc[2]); acc[3] = __builtin_fmaf(u.w, g, acc[3]);
+                acc[4] = __builtin_fmaf(v.x, g, acc[4]); acc[5] = __builtin_fmaf(v.y, g, acc[5]); acc[6] = __builtin_fmaf(v.z, g, acc[6]); acc[7] = __builtin_fmaf(v.w, g, acc[7]);
+              }
+          }
+        }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], 4);
+      if (cx == 0) {
+        float* dst = reinterpret_cast<float*>(sP + ql * MR_PP) + m * 32 + oct * 8;
+        *reinterpret_cast<f32x4*>(dst) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+      }
+    }
+
+    // ---- level 0 gather: head by head, four corners x four points = 16 eight-byte loads per head, scalar offsets and weights
+    {
+      // (plain global loads, scalar frame base + 32-bit offset: the clamped window never leaves the level, so no range check is
+      //  needed -- and hipcc 7.2 lowers __builtin_amdgcn_raw_buffer_load_b64 to a ONE-dword load whose value it then uses for both
+      //  halves: tools/probes/raw_f32_debug.py showed every odd channel equal to its even neighbour)
+      const int64_t frame = (int64_t)H0 * W0 * p.ld0;
+      const unsigned char* fb = reinterpret_cast<const unsigned char*>(x0 + (int64_t)b * frame);
+      const uint32_t voff = (uint32_t)lane * 8u;
+      float* gdst = reinterpret_cast<float*>(sG + ql * MRF_GP) + lane * 2;
+      float2 tp[2][4][4];
+      auto issue = [&](auto hc, float2 (&t)[4][4]) {
+        constexpr int h = decltype(hc)::value;
+#pragma unroll
+        for (int pnt = 0; pnt < 4; ++pnt) {
+          const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)base0[pnt], h * 8);
+          const unsigned char* wb = fb + sb;                            // wave-uniform: the window's first pixel
+          t[pnt][0] = *reinterpret_cast<const float2*>(wb + voff);
+          t[pnt][1] = *reinterpret_cast<const float2*>(wb + pix_pitch + voff);
+          t[pnt][2] = *reinterpret_cast<const float2*>(wb + row_pitch + voff);
+          t[pnt][3] = *reinterpret_cast<const float2*>(wb + row_pitch + pix_pitch + voff);
+        }
+      };
+      auto consume = [&](auto hc, const float2 (&t)[4][4]) {
+        constexpr int h = decltype(hc)::value;
+        float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+        for (int pnt = 0; pnt < 4; ++pnt) {
+          const float ws[4] = {__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w00[pnt]), h * 8)),
+                               __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w01[pnt]), h * 8)),
+                               __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w10[pnt]), h * 8)),
+                               __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w11[pnt]), h * 8))};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            g0 = __builtin_fmaf(t[pnt][c].x, ws[c], g0);
+            g1 = __builtin_fmaf(t[pnt][c].y, ws[c], g1);
+          }
+        }
+        *reinterpret_cast<float2*>(gdst + h * 128) = float2{g0, g1};          // channels 2*lane, 2*lane + 1 of head h's gathered vector
+      };
+      issue(std::integral_constant<int, 0>{}, tp[0]);
+      [&]<int... Hs>(std::integer_sequence<int, Hs...>) {
+        (([&] {
+           if constexpr (Hs + 1 < 8) issue(std::integral_constant<int, Hs + 1>{}, tp[(Hs + 1) & 1]);
+           __builtin_amdgcn_sched_barrier(0);                       // keep the next head's requests ahead of this head's sums
+           consume(std::integral_constant<int, Hs>{}, tp[Hs & 1]);
+         }()), ...);
+      }(std::make_integer_sequence<int, 8>{});
+    }
+  }
+  __syncthreads();
+
+  // ---- projection on the exact fp32 matrix instruction: wave w owns heads 2w, 2w+1.  A = W_h rows (out channel t*16 + r), B = g of the
+  // queries (column r = query r & 7).  A lane holds k = pn*16 + q4*4 .. +3 of its row for BOTH operands; step e of a panel consumes
+  // k = q4*4 + e of every lane quad, so the four steps cover the panel's 16 k exactly once (gemm.hip: mma_panel<float>).
+  const int r = lane & 15, q4 = lane >> 4;
+  const float* wc = static_cast<const float*>(p.wc);
+  float* out = static_cast<float*>(p.out);
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int h = wave * 2 + hh;
+    f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int pn = 0; pn < 8; ++pn) {
+      const f32x4 gb = *reinterpret_cast<const f32x4*>(sG + (r & 7) * MRF_GP + h * 512 + (pn * 16 + q4 * 4) * 4);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(wc + (h * 32 + t * 16 + r) * 128 + pn * 16 + q4 * 4);
+        acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, gb.x, acc2[t], 0, 0, 0);
+        acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, gb.y, acc2[t], 0, 0, 0);
+        acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, gb.z, acc2[t], 0, 0, 0);
+        acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, gb.w, acc2[t], 0, 0, 0);
+      }
+    }
+    const float s = sS[(r & 7) * 8 + h];
+    const int row = sRow[r & 7];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ch = h * 32 + t * 16 + q4 * 4;
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bc + ch);
+      const f32x4 part = *reinterpret_cast<const f32x4*>(sP + (r & 7) * MR_PP + ch * 4);
+      const f32x4 v = acc2[t] + bias * s + part;
+      if (r < MRF_QB && row0 + r < p.nrows) *reinterpret_cast<f32x4*>(out + (int64_t)row * p.ldo + ch) = v;
     }
   }
 }
@@ -516,7 +751,9 @@ using namespace moy;
 
 extern "C" int moy_msda_raw0(const moy_msda_raw_args* a, void* stream) {
   if (!a || !a->x0 || !a->wc || !a->bc || !a->offaw || !a->ref || !a->out || !a->shapes_hw) return MOY_EINVAL;
-  if (a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_ENOSYS;          // 16-bit engines only (the fp32 engine keeps the classic plan)
+  const bool is32 = a->dtype == MOY_F32 || a->dtype == MOY_F32X3;              // fp32 tensors (round 6; MOY_F32X3: the same kernel, exact fp32 arithmetic)
+  if (a->dtype != MOY_BF16 && a->dtype != MOY_F16 && !is32) return MOY_EINVAL;
+  const int esz = is32 ? 4 : 2;
   if (a->B <= 0 || a->Lq <= 0 || a->L < 1 || a->L > 4) return MOY_EINVAL;
   if (a->L > 1 && (!a->planes || a->S1 <= 0)) return MOY_EINVAL;
   MsdaRawParams p{};
@@ -528,15 +765,25 @@ extern "C" int moy_msda_raw0(const moy_msda_raw_args* a, void* stream) {
   }
   if (a->L > 1 && s != a->S1) return MOY_EINVAL;
   if (p.lv.H[0] < 2 || p.lv.W[0] < 2) return MOY_ENOSYS;                        // the clamped 2x2 window needs two rows and two columns
-  if (a->ld0 < 128 || (a->ld0 % 2) || (reinterpret_cast<uintptr_t>(a->x0) % 4)) return MOY_EINVAL;
-  if ((int64_t)p.lv.H[0] * p.lv.W[0] * a->ld0 * 2 > 0x7fffffffLL) return MOY_ENOSYS;      // one frame of level 0 per buffer descriptor
-  if (a->L > 1 && (a->head_stride < 32 || (a->head_stride % 8) || a->head_stride * 8 * 2 > 0x7fffffffLL || !aligned16(a->planes))) return MOY_EINVAL;
+  if (a->ld0 < 128 || (a->ld0 % 2) || (reinterpret_cast<uintptr_t>(a->x0) % (is32 ? 8 : 4))) return MOY_EINVAL;
+  if ((int64_t)p.lv.H[0] * p.lv.W[0] * a->ld0 * esz > 0x7fffffffLL) return MOY_ENOSYS;      // one frame of level 0 per buffer descriptor
+  // head planes: 8 planes of head_stride elements, each holding B * S1 tokens of 32 channels (a stride shorter than that
+  // would let a frame's taps read another head's or frame's tokens without any error)
+  if (a->L > 1 && (a->head_stride < (int64_t)a->B * a->S1 * 32 || (a->head_stride % 8) || a->head_stride * 8 * esz > 0x7fffffffLL || !aligned16(a->planes)))
+    return MOY_EINVAL;
   if (a->ld_oa < 8 * a->L * 4 * 3 || (a->ld_oa % 4) || a->ldo < 256 || (a->ldo % 4) || !aligned16(a->ref) || !aligned16(a->offaw)) return MOY_EINVAL;
-  if (!aligned16(a->wc) || !aligned16(a->bc) || (reinterpret_cast<uintptr_t>(a->out) % 8)) return MOY_EINVAL;
+  if (!aligned16(a->wc) || !aligned16(a->bc) || (reinterpret_cast<uintptr_t>(a->out) % (is32 ? 16 : 8))) return MOY_EINVAL;
+  if (is32 && a->wc_packed) return MOY_EINVAL;                                   // the fp32 form reads wc row-major
   p.wc_packed = a->wc_packed;
   p.x0 = a->x0; p.ld0 = a->ld0; p.wc = a->wc; p.bc = a->bc; p.planes = a->planes; p.head_stride = a->head_stride; p.S1 = a->S1;
   p.L = a->L; p.offaw = a->offaw; p.ld_oa = a->ld_oa; p.ref = a->ref; p.Lq = a->Lq; p.nrows = a->B * a->Lq; p.out = a->out; p.ldo = a->ldo;
+  p.B = a->B; p.perm = a->perm;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (is32) {
+    p.ngroups = (p.nrows + MRF_QB - 1) / MRF_QB;
+    hipLaunchKernelGGL(msda_raw_f32_kernel, dim3((p.ngroups + 7) / 8 * 8), dim3(256), 0, st, p);
+    return launch_status();
+  }
   p.ngroups = (p.nrows + MR_QB - 1) / MR_QB;
   const int nblk = (p.ngroups + 7) / 8 * 8;          // a multiple of the 8 XCDs: XCD x walks the x-th eighth of the groups
   // the tap sums on the matrix cores: three levels, every one with a 2 x 2 window inside it (MOY_MR_MFMA=0: the vector-ALU form)

@@ -1581,6 +1581,47 @@ __global__ __launch_bounds__(256) void sigmoid_kernel(const float* __restrict__ 
   if (t < n) out[t] = sigmoidf_(in[t]);
 }
 
+// Round 6: processing ORDER of a frame's decoder queries for the deformable gather.  The queries of a frame arrive in top-k SCORE order,
+// i.e. spatially random, so the 2 x 2 windows of the queries one block gathers for share nothing.  perm[b][i] = the query to process
+// i-th: the frame's queries sorted by the Morton code of the P3 cell of their reference point (ties: query index).  Only the order in
+// which the gather kernels WALK the queries changes -- every output row stays where it is and holds the same bits.
+// One block per frame; bitonic sort of (code << 10 | index) keys in LDS (Lq <= 1024).
+__device__ __forceinline__ uint32_t morton_spread8(uint32_t v) {     // 8 bits -> the even bits of 16
+  v = (v | (v << 4)) & 0x0f0fu;
+  v = (v | (v << 2)) & 0x3333u;
+  v = (v | (v << 1)) & 0x5555u;
+  return v;
+}
+__global__ __launch_bounds__(512) void query_order_kernel(const float* __restrict__ ref, int Lq, int H0, int W0, int P2,
+                                                          int32_t* __restrict__ perm) {
+  __shared__ uint32_t key[1024];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < P2; i += 512) {
+    uint32_t k = 0xffffffffu;
+    if (i < Lq) {
+      const float cx = ref[((long)b * Lq + i) * 4 + 0], cy = ref[((long)b * Lq + i) * 4 + 1];
+      // (a NaN / out-of-range centre lands in cell 0 or the last cell: any order is a valid order)
+      const int xi = min(max((int)(cx * (float)W0), 0), min(W0, 256) - 1), yi = min(max((int)(cy * (float)H0), 0), min(H0, 256) - 1);
+      k = ((morton_spread8((uint32_t)xi) | (morton_spread8((uint32_t)yi) << 1)) << 10) | (uint32_t)i;
+    }
+    key[i] = k;
+  }
+  __syncthreads();
+  for (int k2 = 2; k2 <= P2; k2 <<= 1)
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P2; i += 512) {
+        const int l = i ^ j;
+        if (l > i) {
+          const uint32_t a = key[i], c = key[l];
+          const bool up = (i & k2) == 0;
+          if ((a > c) == up) { key[i] = c; key[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < Lq; i += 512) perm[(long)b * Lq + i] = (int32_t)(key[i] & 1023u);
+}
+
 inline unsigned nblk(long total, int per = 256) { return (unsigned)((total + per - 1) / per); }
 
 }  // namespace moy
@@ -2131,14 +2172,25 @@ extern "C" int moy_level_select(const float* G, int64_t level_stride, int64_t ld
                                 void* stream) {
   if (!G || !level || !shift || !dst || M <= 0 || N != 256 || (ldg % 4) || (ldd % 4) || !aligned16(G) || !aligned16(shift)) return MOY_EINVAL;
   if (valid && !tok_local) return MOY_EINVAL;
-  if (dtype != MOY_BF16 && dtype != MOY_F16) return MOY_ENOSYS;
+  if (dtype != MOY_BF16 && dtype != MOY_F16 && dtype != MOY_F32 && dtype != MOY_F32X3) return MOY_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dtype == MOY_BF16)
+  if (dtype == MOY_F32 || dtype == MOY_F32X3)            // (round 6: the fp32 engines' folded head)
+    hipLaunchKernelGGL((level_select_kernel<float>), dim3(nblk((long)M * (N / 4))), dim3(256), 0, st, G, level_stride, ldg, level, shift,
+                       tok_local, valid, M, N / 4, static_cast<float*>(dst), ldd);
+  else if (dtype == MOY_BF16)
     hipLaunchKernelGGL((level_select_kernel<bf16_t>), dim3(nblk((long)M * (N / 4))), dim3(256), 0, st, G, level_stride, ldg, level, shift,
                        tok_local, valid, M, N / 4, static_cast<bf16_t*>(dst), ldd);
   else
     hipLaunchKernelGGL((level_select_kernel<f16_t>), dim3(nblk((long)M * (N / 4))), dim3(256), 0, st, G, level_stride, ldg, level, shift,
                        tok_local, valid, M, N / 4, static_cast<f16_t*>(dst), ldd);
+  return launch_status();
+}
+
+extern "C" int moy_query_order(const float* ref, int B, int Lq, int H0, int W0, int32_t* perm, void* stream) {
+  if (!ref || !perm || B <= 0 || Lq <= 0 || Lq > 1024 || H0 <= 0 || W0 <= 0) return MOY_EINVAL;
+  int P2 = 1;
+  while (P2 < Lq) P2 <<= 1;
+  hipLaunchKernelGGL(query_order_kernel, dim3(B), dim3(512), 0, static_cast<hipStream_t>(stream), ref, Lq, H0, W0, P2, perm);
   return launch_status();
 }
 

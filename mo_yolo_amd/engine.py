@@ -552,7 +552,7 @@ class TrackEngine:
         self.p3raw = None
         self.value_tokens = S                  # tokens per frame in the value planes
         if (fold is not None and vmode == "2" and os.environ.get("MOY_P3_RAW", "1") != "0" and nl >= 2 and arch.head_ch[0] == 128
-                and min(self.shapes[0]) >= 2 and self.shapes[0][0] * self.shapes[0][1] * head_src[0][0].ld * 2 <= 0x7fffffff):
+                and min(self.shapes[0]) >= 2 and self.shapes[0][0] * self.shapes[0][1] * head_src[0][0].ld * self._esz <= 0x7fffffff):
             self.value_tokens = S - self.shapes[0][0] * self.shapes[0][1]
         if vmode == "2":
             # [layer][head][token][32]: a head's map is a dense [B*S, 32] matrix, so the two x-taps of a bilinear sample are
@@ -572,6 +572,10 @@ class TrackEngine:
                     bc = (Wv.double() @ fold["t"][li] + bv.double()).float()
                     if li == 0 and Sv != S:
                         # level 0 is sampled raw: its composed weights [ndl * 256, 128] / biases go to the gather, layer by layer
+                        if self.dtype == torch.float32:
+                            # fp32 engines (round 6): the gather projects on the exact fp32 matrix instruction from fp32 row-major weights
+                            self.p3raw = dict(view=src_view, wc=self._dev(Wc.contiguous()), bc=self._dev(bc))
+                            continue
                         self.p3raw = dict(view=src_view, wc=self._weight(Wc), bc=self._dev(bc))
                         assert self.p3raw["wc"].shape == (ndl * hd, 128)
                         from .ops import pack_mfma_a
@@ -725,6 +729,14 @@ class TrackEngine:
                       embed[0].ptr, embed[0].ld, qpos.ptr, qpos.ld, self.refer_all.data_ptr(), refs[0].data_ptr(), code,
                       meta=dict(name=f"temporal_assemble B{B} L{nq + n_max}", bytes=Md * (4 * hd * self._esz + 32), flops=0))
         self.query_pos = qpos
+        # Round 6: the deformable gather walks a frame's queries in the Morton order of their reference points' P3 cells (one sort per
+        # frame, of the decoder's initial boxes: the six refinements move them little, transformer.py:676-728), so that the queries one
+        # block gathers for are neighbours; rows and bits of every output are unchanged (MOY_Q_ORDER=0: top-k order, as rounds 1-5)
+        self.qperm = None
+        if self.p3raw is not None and os.environ.get("MOY_Q_ORDER", "1") != "0" and Lq <= 1024:
+            self.qperm = torch.zeros(B, Lq, device=self.dev, dtype=torch.int32)
+            self._add(lib.moy_query_order, refs[0].data_ptr(), B, Lq, self.shapes[0][0], self.shapes[0][1], self.qperm.data_ptr(),
+                      meta=dict(name=f"query_order B{B} L{Lq}", bytes=Md * 20, flops=0))
 
         M = Md                           # from here on: decoder rows
         qkv = View(self._buf(M, 3 * hd))
@@ -820,12 +832,14 @@ class TrackEngine:
                 t = L.MsdaRawArgs()
                 pv = self.p3raw["view"]
                 t.x0, t.ld0 = pv.ptr, pv.ld
-                t.wc = self.p3raw["wc_packed" if packed_w else "wc"].data_ptr() + i * hd * 128 * self._esz
-                t.wc_packed = int(packed_w)
+                pk = packed_w and "wc_packed" in self.p3raw
+                t.wc = self.p3raw["wc_packed" if pk else "wc"].data_ptr() + i * hd * 128 * self._esz
+                t.wc_packed = int(pk)
                 t.bc = self.p3raw["bc"].data_ptr() + i * hd * 4
                 t.planes, t.head_stride, t.S1 = vslice.ptr, vhs, self.value_tokens
                 t.B, t.Lq, t.L, t.shapes_hw = B, Lq, nl, C.cast(shapes_c, C.c_void_p)
-                t.offaw, t.ld_oa, t.ref, t.out, t.ldo, t.dtype = offaw.data_ptr(), offaw.shape[1], refs[cur].data_ptr(), samp.ptr, samp.ld, code
+                t.offaw, t.ld_oa, t.ref, t.out, t.ldo, t.dtype = offaw.data_ptr(), offaw.shape[1], refs[cur].data_ptr(), samp.ptr, samp.ld, self.code_gemm
+                t.perm = self.qperm.data_ptr() if self.qperm is not None else None
                 self._keep.append(t)
                 self._add(lib.moy_msda_raw0, C.byref(t),
                           meta=dict(name=f"msda_raw0 M{M}", bytes=touched + hd * 128 * self._esz + M * (offaw.shape[1] * 4 + 16 + hd * self._esz),
@@ -1117,11 +1131,19 @@ class TrackEngine:
         tiled kernel has neither the row runs nor the second row numbering), head-plane value layout, <= 4 classes (the fused narrow
         head), level widths of 128 / 256 channels, a valid mask that is one rectangle per level."""
         arch, B, sd = self.arch, self.B, self.sd
-        if self.dtype == torch.float32 or os.environ.get("MOY_FOLD_PROJ", "1") == "0" or os.environ.get("MOY_VALUE_PLANES", "2") != "2":
+        is32 = self.dtype == torch.float32
+        if os.environ.get("MOY_FOLD_PROJ", "1") == "0" or os.environ.get("MOY_VALUE_PLANES", "2") != "2":
             return None
-        if os.environ.get("MOY_SCORE_RUNS", "1") == "0" or os.environ.get("MOY_GEMM_WREG", "1") == "0" or arch.nc > 4 or arch.hd != 256:
+        if os.environ.get("MOY_SCORE_RUNS", "1") == "0" or arch.nc > 4 or arch.hd != 256:
             return None
-        if any(c not in (128, 256) for c in arch.head_ch) or any(B * h_ * w_ < 65536 for h_, w_ in self.shapes):
+        if any(c not in (128, 256) for c in arch.head_ch):
+            return None
+        # 16-bit engines: every per-level launch must take the weight-stationary kernel (row runs, output row remap into head planes);
+        # round 6, fp32 engines (exact and split-fp16): the TILED kernel has the row runs and the remap for fp32 tensors at any launch
+        # size, so the fold holds at every batch -- what is asked below is only that a level's tensor fits one buffer descriptor
+        if not is32 and (os.environ.get("MOY_GEMM_WREG", "1") == "0" or any(B * h_ * w_ < 65536 for h_, w_ in self.shapes)):
+            return None
+        if is32 and any(B * h_ * w_ * v.ld * 4 > 0x7fffffff for (v, _), (h_, w_) in zip(head_src, self.shapes)):
             return None
         if any((v.ld % 8) or (v.ptr % 16) for v, _ in head_src):
             return None
@@ -1143,6 +1165,8 @@ class TrackEngine:
         al = self._dev(torch.zeros(64, dtype=torch.float32)).data_ptr()       # any 16-byte aligned device address: the query dereferences nothing
         off = 0
         for li, ((v, _), (h_, w_)) in enumerate(zip(head_src, self.shapes)):
+            if is32:
+                break
             y0, y1, x0, x1 = rect[li]
             a = L.GemmArgs()
             a.A, a.lda, a.W, a.M, a.N, a.K, a.ksize, a.stride = v.ptr, v.ld, al, B * h_ * w_, arch.ndl * hd, arch.head_ch[li], 1, 1

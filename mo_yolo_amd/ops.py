@@ -335,7 +335,17 @@ def msda_fused(value, B, S, shapes, offaw, ref, Lq, head_planes=False):
     return out
 
 
-def msda_raw0(x0, wc, bc, planes, B, shapes, offaw, ref, Lq, packed=False):
+def query_order(ref, B, Lq, H0, W0):
+    """moy_query_order: perm int32 [B, Lq] = every frame's queries sorted by the Morton code of the (H0 x W0)-grid cell of their
+    reference box centre (ref fp32 [B*Lq, 4])."""
+    _need_gpu(ref)
+    assert ref.dtype == torch.float32 and ref.is_contiguous() and ref.numel() == B * Lq * 4
+    perm = torch.empty(B, Lq, device=ref.device, dtype=torch.int32)
+    L.check(L.lib().moy_query_order(ref.data_ptr(), B, Lq, H0, W0, perm.data_ptr(), _st()), "moy_query_order")
+    return perm
+
+
+def msda_raw0(x0, wc, bc, planes, B, shapes, offaw, ref, Lq, packed=False, head_stride=None, perm=None):
     """moy_msda_raw0: level 0 gathered raw from x0 [B*H0*W0, >= 128] (channel-slice view) and projected with wc [256, 128] / bc [256]
     after the bilinear sum; levels 1.. from head planes [8, B*S1, 32] (None when there is one level)."""
     _need_gpu(x0, wc, bc, offaw, ref)
@@ -347,10 +357,13 @@ def msda_raw0(x0, wc, bc, planes, B, shapes, offaw, ref, Lq, packed=False):
     a.x0, a.ld0, a.wc, a.bc = x0.data_ptr(), _ld(x0), wc.data_ptr(), bc.data_ptr()
     if planes is not None:
         assert planes.is_contiguous() and tuple(planes.shape) == (8, B * S1, 32) and planes.dtype == x0.dtype
-        a.planes, a.head_stride = planes.data_ptr(), B * S1 * 32
+        a.planes, a.head_stride = planes.data_ptr(), (B * S1 * 32 if head_stride is None else head_stride)
     a.S1, a.B, a.Lq, a.L, a.shapes_hw = S1, B, Lq, nl, C.cast(sh, C.c_void_p)
     a.offaw, a.ld_oa, a.ref, a.out, a.ldo, a.dtype = offaw.data_ptr(), _ld(offaw), ref.data_ptr(), out.data_ptr(), 256, _code(x0)
     a.wc_packed = int(packed)          # wc through pack_mfma_a
+    if perm is not None:               # the order in which the kernel walks a frame's queries (moy_query_order); outputs unchanged
+        assert perm.dtype == torch.int32 and perm.is_contiguous() and tuple(perm.shape) == (B, Lq)
+        a.perm = perm.data_ptr()
     assert wc.is_contiguous() and tuple(wc.shape) == (256, 128) and wc.dtype == x0.dtype and bc.dtype == torch.float32
     L.check(L.lib().moy_msda_raw0(C.byref(a), _st()), "moy_msda_raw0")
     return out

@@ -993,9 +993,40 @@ def test_msda_raw_level0_gather_then_project_vs_oracle(dt, B, Lq, shapes, ld0):
     want = O.msda_core(value.view(B, -1, 8, 32), shapes, loc, aw).view(B * Lq, 256)
     # one rounding of the gathered vector to T before its product (|g| <= 1, 128 terms of |w| ~ 0.09) + the output rounding
     assert torch.allclose(y.float().cpu(), want, atol=tol(dt, 2e-5, 1.5e-2), rtol=tol(dt, 1e-5, 1e-2)), float((y.float().cpu() - want).abs().max())
-    with pytest.raises(L.MoyoloError):          # fp32: refused (the exact engine keeps the projected planes)
-        ops.msda_raw0(xbuf[:, :128].float().contiguous(), wc.to(DEV).contiguous(), bc.to(DEV), planes.float() if planes is not None else None,
-                      B, shapes, offaw.to(DEV), ref_box.to(DEV), Lq)
+    # round 6: the walk order of a frame's queries (moy_query_order: Morton order of the reference points' level-0 cells) changes no
+    # output bit; the order itself is a permutation of every frame, sorted by cell code with ties in query order
+    perm = ops.query_order(ref_box.to(DEV), B, Lq, H0, W0)
+    yq = ops.msda_raw0(xbuf[:, :128], wc.to(DEV, dt).contiguous(), bc.to(DEV), planes, B, shapes, offaw.to(DEV), ref_box.to(DEV), Lq, perm=perm)
+    gq = torch.Generator().manual_seed(11)
+    rperm = torch.stack([torch.randperm(Lq, generator=gq) for _ in range(B)]).to(DEV, torch.int32)
+    yr = ops.msda_raw0(xbuf[:, :128], wc.to(DEV, dt).contiguous(), bc.to(DEV), planes, B, shapes, offaw.to(DEV), ref_box.to(DEV), Lq, perm=rperm)
+    torch.cuda.synchronize()
+    assert torch.equal(yq, y) and torch.equal(yr, y)
+    pc = perm.cpu().long()
+    assert all(torch.equal(pc[b].sort().values, torch.arange(Lq)) for b in range(B))
+    def _code(v):
+        v = (v | (v << 4)) & 0x0f0f; v = (v | (v << 2)) & 0x3333; v = (v | (v << 1)) & 0x5555
+        return v
+    rbx = ref_box.view(B, Lq, 4)
+    xi = (rbx[..., 0] * W0).int().clamp(0, min(W0, 256) - 1).long(); yi = (rbx[..., 1] * H0).int().clamp(0, min(H0, 256) - 1).long()
+    keys = ((_code(xi) | (_code(yi) << 1)) << 10) | torch.arange(Lq)[None]
+    assert torch.equal(pc, keys.argsort(1))
+    # round 6: the fp32 form (the fp32 engines' folded head): fp32 tensors, fp32 sums, exact fp32 matrix instruction -- against the
+    # same oracle on the same (16-bit representable) operands: 2e-5; a packed weight matrix or a short head stride is refused
+    xf = torch.zeros(B * H0 * W0, ld0, device=DEV, dtype=torch.float32)
+    xf[:, :128] = x.to(DEV)
+    pf = planes.float().contiguous() if planes is not None else None
+    yf = ops.msda_raw0(xf[:, :128], wc.to(DEV).contiguous(), bc.to(DEV), pf, B, shapes, offaw.to(DEV), ref_box.to(DEV), Lq)
+    yfq = ops.msda_raw0(xf[:, :128], wc.to(DEV).contiguous(), bc.to(DEV), pf, B, shapes, offaw.to(DEV), ref_box.to(DEV), Lq, perm=rperm)
+    torch.cuda.synchronize()
+    assert yf.dtype == torch.float32 and torch.equal(yfq, yf)
+    assert torch.allclose(yf.cpu(), want, atol=2e-5, rtol=1e-5), float((yf.cpu() - want).abs().max())
+    with pytest.raises(L.MoyoloError):
+        ops.msda_raw0(xf[:, :128], wc.to(DEV).contiguous(), bc.to(DEV), pf, B, shapes, offaw.to(DEV), ref_box.to(DEV), Lq, packed=True)
+    if planes is not None and B > 1:
+        with pytest.raises(L.MoyoloError):      # head planes shorter than B * S1 tokens
+            ops.msda_raw0(xbuf[:, :128], wc.to(DEV, dt).contiguous(), bc.to(DEV), planes, B, shapes, offaw.to(DEV), ref_box.to(DEV), Lq,
+                          head_stride=(B - 1) * S1 * 32)
 
 
 @pytest.mark.parametrize("dt", DT)
