@@ -81,6 +81,11 @@ def parse(argv=None):
     ap.add_argument("--fail-rank", type=int, default=None, help=argparse.SUPPRESS)       # test hook: that rank exits 7 before the rendezvous
     ap.add_argument("--host-frames", action="store_true",
                     help="draw the synthetic frames with the numpy generator on the host (the definition) instead of its bit-identical torch form on the device")
+    ap.add_argument("--plan", default=None, metavar="KEY=VALUE,...",
+                    help="plan options of the engines (mo_yolo_amd.engine.PlanOptions), e.g. query_order=0,p3_raw=0: A/B runs; the default is the shipped plan")
+    ap.add_argument("--lab", action="store_true",
+                    help="LAB run: load libmoyolo_diag.so (the build that reads the MOY_* A/B knobs and holds the timing-only kernels) and take the plan "
+                         "options from the MOY_* environment (PlanOptions.from_env) -- what tools/ab_env.sh and tools/ablation_table.sh pass")
     ap.add_argument("--latency", action="store_true",
                     help="small-batch leg (C5 as BASELINE.json words it: one hipGraph replay = ONE frame of each of --batch live sequences): every step is "
                          "synchronised, the line carries the per-step latency distribution; MOTR/benchmark.py:37-68 times exactly this shape")
@@ -363,6 +368,8 @@ def main(argv=None):
     visible = pin_device(0 if a.rehearse_one_gpu else local, a.rehearse_one_gpu)
     cpus = pin_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))      # before anything touches HIP / starts threads
 
+    if a.lab and not a.dry_run:                          # before anything imports mo_yolo_amd._lib
+        os.environ.setdefault("MOYOLO_LIB", os.path.join(ROOT, "mo_yolo_amd", "libmoyolo_diag.so"))
     import torch
     from mo_yolo_amd import shard
     dist = None
@@ -440,6 +447,12 @@ def main(argv=None):
         cfg, arch, sd = fixture(cfg_name)
         dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32x3": torch.float32}[dtype_name]
         ekw = dict(split_f16=True) if dtype_name == "f32x3" else {}
+        if a.plan or a.lab:
+            from mo_yolo_amd.engine import PlanOptions
+            ekw["options"] = PlanOptions.parse(a.plan) if a.plan else PlanOptions.from_env()
+            line_extra["plan_options"] = a.plan or ("from the MOY_* environment: " + ",".join(f"{k}={os.environ[v]}" for k, v in PlanOptions._ENV.items() if v in os.environ))
+        if a.lab:
+            line_extra["library"] = os.environ.get("MOYOLO_LIB")
         seqs = [SyntheticSequence(sid, cfg["H"], cfg["W"], cfg["style"]) for sid in my_seqs]
         n_slots = 3
 

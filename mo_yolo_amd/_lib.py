@@ -9,7 +9,17 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MOYOLO_LIB") or os.path.join(HERE, "libmoyolo.so")   # override: A/B runs of two builds on one device
+# MOYOLO_LIB names another build of the same C ABI: the LAB library (libmoyolo_diag.so: the sources with -DMOY_DIAG=1 -- the `MOY_*`
+# A/B knobs and the timing-only kernel instances live there and only there), or an older build for a same-device A/B
+LIB_PATH = os.environ.get("MOYOLO_LIB") or os.path.join(HERE, "libmoyolo.so")
+LAB_LIB_PATH = os.path.join(HERE, "libmoyolo_diag.so")
+
+
+def lab_library() -> str:
+    """Path of the lab build (`python -m mo_yolo_amd.build --diag`) for a child process's MOYOLO_LIB; raises if it has not been built."""
+    if not os.path.exists(LAB_LIB_PATH):
+        raise MoyoloError(f"{LAB_LIB_PATH} is missing: build it with `python -m mo_yolo_amd.build --diag`")
+    return LAB_LIB_PATH
 
 F32, BF16, F16 = 0, 1, 2
 F32X3 = 3        # moy_gemm only: fp32 tensors, split-fp16 matrix arithmetic (include/moyolo.h: MOY_F32X3)

@@ -381,13 +381,16 @@ static int c2f_num_cus() {
 
 template <typename T>
 static int launch_c2f(C2fParams& p, hipStream_t st) {
-  static int diag = -1;
-  if (diag < 0) diag = garbage_mode_env("MOY_C2F_DIAG");
+#if MOY_DIAG
+  static const int diag = garbage_mode_env("MOY_C2F_DIAG");
   auto kern = diag ? c2f_fused_kernel<T, 1> : c2f_fused_kernel<T, 0>;
+#else
+  auto kern = c2f_fused_kernel<T, 0>;
+#endif
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(c2f_fused_kernel<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, C2F_LDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(c2f_fused_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, C2F_LDS) != hipSuccess)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C2F_LDS) != hipSuccess)
       return MOY_ELAUNCH;
     attr_set = true;
   }

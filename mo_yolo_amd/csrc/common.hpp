@@ -234,28 +234,41 @@ int gemm_dma_try(const moy_gemm_args* a, hipStream_t st);
 // conv_ws.hip: persistent weight-stationary direct 3x3 convolution (MOY_ENOSYS when the shape is not its own)
 int conv_ws_try(const moy_gemm_args* a, hipStream_t st);
 
-// Timing-only / diagnostic modes (MOY_*_ABL, MOY_*_DIAG) produce GARBAGE results by design: they exist for tools/bench_gemm.py
-// and tools/probes/.  A variable left set in a production environment would corrupt outputs with rc = 0, so the first use says so
-// loudly on stderr.
-inline int garbage_mode_env(const char* name) {
+// ---- Build kinds (round 6).  The PRODUCT library (libmoyolo.so, MOY_DIAG == 0) reads no environment variable and holds no timing-only
+// kernel: `knob()` is a compile-time constant there, every A/B dispatch folds to the shipped choice and the lab-only template instances
+// sit behind `#if MOY_DIAG`.  The LAB library (libmoyolo_diag.so: `python -m mo_yolo_amd.build --diag`, selected by MOYOLO_LIB) is the
+// same sources with -DMOY_DIAG=1: `knob("MOY_X", d)` reads the variable ONCE at the call site's first use (callers keep it in a
+// function-local static), the timing-only / stamped instantiations exist.  A host sees no hidden state through include/moyolo.h: the
+// one real option of the library is moy_set_cu_limit().
+#ifndef MOY_DIAG
+#define MOY_DIAG 0
+#endif
+#if MOY_DIAG
+inline int knob(const char* name, int dflt) {
   const char* e = getenv(name);
-  const int v = e ? atoi(e) : 0;
+  return e ? atoi(e) : dflt;
+}
+// Timing-only / diagnostic modes (MOY_*_ABL, MOY_*_DIAG) produce GARBAGE results by design: they exist for tools/bench_gemm.py
+// and tools/probes/.  A variable left set would corrupt outputs with rc = 0, so the first use says so loudly on stderr.
+inline int garbage_mode_env(const char* name) {
+  const int v = knob(name, 0);
   if (v)
-    fprintf(stderr, "\n*** libmoyolo: %s=%d selects a TIMING-ONLY / DIAGNOSTIC kernel build: its RESULTS ARE GARBAGE by design. "
+    fprintf(stderr, "\n*** libmoyolo_diag: %s=%d selects a TIMING-ONLY / DIAGNOSTIC kernel build: its RESULTS ARE GARBAGE by design. "
                     "Unset it for any run whose outputs matter. ***\n\n", name, v);
   return v;
 }
+#else
+constexpr int knob(const char*, int dflt) { return dflt; }
+constexpr int garbage_mode_env(const char*) { return 0; }
+#endif
 
-// moy_set_cu_limit(n) (per host thread) or MOY_CU_LIMIT=<n> (read at every launch; probes): the persistent kernels (gemm_wreg,
+// moy_set_cu_limit(n) (per host thread; the lab library also reads MOY_CU_LIMIT=<n> at every launch): the persistent kernels (gemm_wreg,
 // conv_ws) size their grids for n compute units instead of the device's.  Results do not depend on it (the row-tile walk is the
 // same); used by the engine's forked value projection and by the CU-partition measurements of tools/probes/cu_share.py.
 int& cu_limit_slot();
 inline int cu_limit(int n) {
   int v = cu_limit_slot();
-  if (v <= 0) {
-    const char* e = getenv("MOY_CU_LIMIT");
-    v = e ? atoi(e) : 0;
-  }
+  if (v <= 0) v = knob("MOY_CU_LIMIT", 0);
   v = v / 8 * 8;
   if (v >= 8 && v < n) n = v;
   return n;

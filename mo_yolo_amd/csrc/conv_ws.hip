@@ -702,8 +702,7 @@ static int launch_conv_ws_pipe(ConvWsParams& p, int B, hipStream_t st) {
   constexpr int PATCH_PIECES = ((TH + 2) * 18 * (C / 8) + 63) / 64;
   constexpr int LDS = 2 * (PATCH_PIECES * 1024 + TH * 16 * N * 2) + 1024;
   if constexpr (STAG == 0 && OCC == 1) {
-    static int stag = -1;                  // MOY_CWS_STAG: A/B knob, delay of waves 4-7 after every barrier in units of 64 cycles
-    if (stag < 0) { const char* e = getenv("MOY_CWS_STAG"); stag = e ? atoi(e) : 0; }
+    static const int stag = knob("MOY_CWS_STAG", 0);                  // MOY_CWS_STAG: A/B knob, delay of waves 4-7 after every barrier in units of 64 cycles
     if (stag == 2) return launch_conv_ws_pipe<T, C, N, TH, WN, RES, OCC, 2>(p, B, st);
     if (stag == 4) return launch_conv_ws_pipe<T, C, N, TH, WN, RES, OCC, 4>(p, B, st);
     if (stag == 8) return launch_conv_ws_pipe<T, C, N, TH, WN, RES, OCC, 8>(p, B, st);
@@ -1057,19 +1056,19 @@ static int launch_conv_ws_pp(ConvWsParams& p, int B, hipStream_t st) {
   if (plan_only(MOY_KERNEL_CONV_WS)) return MOY_OK;          // moy_gemm_query: the dispatch without the launch (and without touching the attribute statics)
   constexpr int PATCH_PIECES = ((TH + 2) * 18 * (C / 8) + 63) / 64;
   constexpr int LDS = 2 * (PATCH_PIECES * 1024 + TH * 16 * N * 2) + 1024;
+#if MOY_DIAG
   if constexpr (ABL == 0 && std::is_same<T, bf16_t>::value && !RES) {
-    static int abl = -1;                   // MOY_CWS_ABL=1..4: timing-only builds (no SiLU / no DMA / one MFMA group / no stores)
-    if (abl < 0) abl = garbage_mode_env("MOY_CWS_ABL");
+    static const int abl = garbage_mode_env("MOY_CWS_ABL");                   // MOY_CWS_ABL=1..4: timing-only builds (no SiLU / no DMA / one MFMA group / no stores)
     if (abl == 1) return launch_conv_ws_pp<T, C, N, TH, WN, RES, 1>(p, B, st);
     if (abl == 2) return launch_conv_ws_pp<T, C, N, TH, WN, RES, 2>(p, B, st);
     if (abl == 3) return launch_conv_ws_pp<T, C, N, TH, WN, RES, 3>(p, B, st);
     if (abl == 4) return launch_conv_ws_pp<T, C, N, TH, WN, RES, 4>(p, B, st);
     if (abl == 5) return launch_conv_ws_pp<T, C, N, TH, WN, RES, 5>(p, B, st);
   }
+#endif
   auto kern = conv_ws_pp_kernel<T, C, N, TH, WN, RES, ABL>;
   {
-    static int prio = -1;
-    if (prio < 0) { const char* e = getenv("MOY_CWS_PRIO"); prio = e ? atoi(e) : 1; }
+    static const int prio = knob("MOY_CWS_PRIO", 1);
     p.prio = prio;
   }
   static bool attr_set = false;
@@ -1362,8 +1361,7 @@ static int launch_conv_s2(ConvS2Params& p, int B, hipStream_t st) {
 // Images per virtual row (GRP forms): the smallest group that saves at least 4 % of the tile columns, 1 = plain tiling.  The group's
 // descriptors must stay inside 31 bits.
 static int cws_group(int W, int64_t img_bytes_max) {
-  static int on = -1;                      // MOY_CWS_GROUP=0: plain tiling (A/B runs, bit-identity test)
-  if (on < 0) { const char* e = getenv("MOY_CWS_GROUP"); on = e ? atoi(e) : 1; }
+  static const int on = knob("MOY_CWS_GROUP", 1);                      // MOY_CWS_GROUP=0: plain tiling (A/B runs, bit-identity test)
   if (!on) return 1;
   const double base = (double)((W + 15) / 16);
   int best = 1;
@@ -1392,19 +1390,19 @@ static int launch_conv_ws(ConvWsParams& p, int B, hipStream_t st) {
       return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 0, true>(p, B, st);
     }
   }
+#if MOY_DIAG
   if constexpr (ABL == 0 && !GRP && std::is_same<T, bf16_t>::value && !RES) {
-    static int abl = -1;                   // MOY_CWS_ABL=1..4: timing-only builds (no SiLU / no DMA / one MFMA group / no stores)
-    if (abl < 0) abl = garbage_mode_env("MOY_CWS_ABL");
+    static const int abl = garbage_mode_env("MOY_CWS_ABL");                   // MOY_CWS_ABL=1..4: timing-only builds (no SiLU / no DMA / one MFMA group / no stores)
     if (abl == 1) return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 1>(p, B, st);
     if (abl == 2) return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 2>(p, B, st);
     if (abl == 3) return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 3>(p, B, st);
     if (abl == 4) return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 4>(p, B, st);
     if (abl == 5) return launch_conv_ws<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, 5>(p, B, st);
   }
+#endif
   auto kern = conv_ws_kernel<T, C, N, TH, WN, NBUF, RES, OCC, SPREAD, ABL, GRP>;
   {
-    static int prio = -1;
-    if (prio < 0) { const char* e = getenv("MOY_CWS_PRIO"); prio = e ? atoi(e) : 1; }
+    static const int prio = knob("MOY_CWS_PRIO", 1);
     p.prio = prio;
   }
   static bool attr_set = false;
@@ -1427,14 +1425,16 @@ static int launch_conv_ws(ConvWsParams& p, int B, hipStream_t st) {
   return launch_status();
 }
 
+#if MOY_DIAG
 static int cws_variant() {                 // MOY_CWS_VARIANT: A/B knob (bit 0: spread the DMA pieces, bit 1: C = 32 with two blocks per CU)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MOY_CWS_VARIANT"); v = e ? atoi(e) : 0; }
+  static const int v = knob("MOY_CWS_VARIANT", 0);
   return v;
 }
+#endif
 
 template <typename T>
 static int conv_ws_dispatch(ConvWsParams& p, int B, int C, bool res, hipStream_t st) {
+#if MOY_DIAG
   const int v = cws_variant();
   const bool sp = v & 1, occ2 = v & 2;
   if (v & 8) {                             // ping-pong form (round 3)
@@ -1450,19 +1450,26 @@ static int conv_ws_dispatch(ConvWsParams& p, int B, int C, bool res, hipStream_t
     if (C == 64) return res ? launch_conv_ws_pipe<T, 64, 64, 16, 4, true>(p, B, st) : launch_conv_ws_pipe<T, 64, 64, 16, 4, false>(p, B, st);
     if (C == 128) return res ? launch_conv_ws_pipe<T, 128, 128, 8, 8, true>(p, B, st) : launch_conv_ws_pipe<T, 128, 128, 8, 8, false>(p, B, st);
   }
+#endif
   if (C == 32) {
+#if MOY_DIAG
     if (occ2) return res ? launch_conv_ws<T, 32, 32, 16, 2, 2, true, 2>(p, B, st) : launch_conv_ws<T, 32, 32, 16, 2, 2, false, 2>(p, B, st);
     if (sp) return res ? launch_conv_ws<T, 32, 32, 16, 2, 3, true, 1, true>(p, B, st) : launch_conv_ws<T, 32, 32, 16, 2, 3, false, 1, true>(p, B, st);
+#endif
     return res ? launch_conv_ws<T, 32, 32, 16, 2, 3, true>(p, B, st) : launch_conv_ws<T, 32, 32, 16, 2, 3, false>(p, B, st);
   }
   if (C == 64) {
     // (round 5: the two-column-group form MOY_CWS_WN64=2 -- measured slower, DESIGN.md round 4 item 4 -- spilled 15-90 registers: scratch
     //  traffic is vector-memory traffic the counted waits of the patch ring do not know about; it left the tree)
+#if MOY_DIAG
     if (sp) return res ? launch_conv_ws<T, 64, 64, 16, 4, 2, true, 1, true>(p, B, st) : launch_conv_ws<T, 64, 64, 16, 4, 3, false, 1, true>(p, B, st);
+#endif
     return res ? launch_conv_ws<T, 64, 64, 16, 4, 2, true>(p, B, st) : launch_conv_ws<T, 64, 64, 16, 4, 3, false>(p, B, st);
   }
   if (C == 128) {
+#if MOY_DIAG
     if (sp) return res ? launch_conv_ws<T, 128, 128, 8, 8, 2, true, 1, true>(p, B, st) : launch_conv_ws<T, 128, 128, 8, 8, 2, false, 1, true>(p, B, st);
+#endif
     return res ? launch_conv_ws<T, 128, 128, 8, 8, 2, true>(p, B, st) : launch_conv_ws<T, 128, 128, 8, 8, 2, false>(p, B, st);
   }
   return MOY_ENOSYS;
@@ -1470,14 +1477,12 @@ static int conv_ws_dispatch(ConvWsParams& p, int B, int C, bool res, hipStream_t
 
 // Eligibility + dispatch; MOY_ENOSYS = not this kernel's shape (moy_gemm falls through to the other convolution paths).
 int conv_ws_try(const moy_gemm_args* a, hipStream_t st) {
-  static int mode = -1;                    // MOY_CONV_WS: 0 = off, 1 = on for launches with enough tiles (default), 2 = whenever the shape fits
-  if (mode < 0) { const char* e = getenv("MOY_CONV_WS"); mode = e ? atoi(e) : 1; }
+  static const int mode = knob("MOY_CONV_WS", 1);                    // MOY_CONV_WS: 0 = off, 1 = on for launches with enough tiles (default), 2 = whenever the shape fits
   if (!mode) return MOY_ENOSYS;
   if (a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_ENOSYS;
   if (a->ksize != 3 || a->act != MOY_ACT_SILU) return MOY_ENOSYS;
   if (a->stride == 2) {
-    static int s2 = -1;                    // MOY_CONV_S2=0 switches the stride-2 kernel off (A/B runs)
-    if (s2 < 0) { const char* e = getenv("MOY_CONV_S2"); s2 = e ? atoi(e) : 1; }
+    static const int s2 = knob("MOY_CONV_S2", 1);                    // MOY_CONV_S2=0 switches the stride-2 kernel off (A/B runs)
     const int C = a->Cin, N = a->N;
     const bool l1 = C == 32 && N == 64, l3 = C == 64 && N == 128;
     if (!s2 || !(l1 || l3) || a->K != 9 * C || a->R) return MOY_ENOSYS;

@@ -507,8 +507,8 @@ extern "C" int moy_decoder_tail(const moy_decoder_tail_args* a, void* stream) {
     attr_set = true;
   }
   const int blocks = (a->M + TAIL_BM - 1) / TAIL_BM;
-  static int abl = -1;
-  if (abl < 0) abl = garbage_mode_env("MOY_TAIL_ABL");
+#if MOY_DIAG
+  static const int abl = garbage_mode_env("MOY_TAIL_ABL");
   if (abl == 3 && a->dtype == MOY_BF16) {          // stamps + no weight traffic after the first product
     auto k3 = decoder_tail_kernel<bf16_t, 3>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) != hipSuccess) return MOY_ELAUNCH;
@@ -527,6 +527,7 @@ extern "C" int moy_decoder_tail(const moy_decoder_tail_args* a, void* stream) {
     hipLaunchKernelGGL(k1, dim3(blocks), dim3(64 * TAIL_NW), TAIL_LDS, st, *a);
     return launch_status();
   }
+#endif
   if (a->dtype == MOY_BF16)
     hipLaunchKernelGGL((decoder_tail_kernel<bf16_t>), dim3(blocks), dim3(64 * TAIL_NW), TAIL_LDS, st, *a);
   else

@@ -1005,8 +1005,7 @@ static int try_conv_direct(GemmParams& p, int B, bool ln, hipStream_t st) {
   if constexpr (sizeof(T) != 2) {
     return MOY_ENOSYS;
   } else {
-    static int mode = -1;                   // MOY_CONV_DIRECT=0 switches the path off (A/B runs)
-    if (mode < 0) { const char* e = getenv("MOY_CONV_DIRECT"); mode = e ? atoi(e) : 1; }
+    static const int mode = knob("MOY_CONV_DIRECT", 1);                   // MOY_CONV_DIRECT=0 switches the path off (A/B runs)
     if (!mode || ln || p.ksize != 3 || p.stride != 1 || !p.wide_store || p.c_rpb || p.out_f32) return MOY_ENOSYS;
     if (p.Cin != p.K / 9 || (p.lda % 8) || (p.N % 32)) return MOY_ENOSYS;
     if ((int64_t)p.Hin * p.Win * p.lda * 2 > 0x7fffffffLL) return MOY_ENOSYS;
@@ -1020,13 +1019,13 @@ static int try_conv_direct(GemmParams& p, int B, bool ln, hipStream_t st) {
     // every wave covers all BN channels of its pixel rows (NT = BN/16) and 4 (TH 16) or 2 (TH 8) rows of 16 pixels: the
     // larger register tile halves the LDS fragment reads per MFMA, which bound the first version (1 ds_read_b128 per MFMA)
     if (p.Cin == 32 && p.N == 32) return big ? launch_conv_direct<T, 32, 32, 16, 4, 1>(p, B, st) : launch_conv_direct<T, 32, 32, 8, 4, 1>(p, B, st);
-    static int th64 = -1;
-    if (th64 < 0) { const char* e = getenv("MOY_TH64"); th64 = e ? atoi(e) : 16; }
+    static const int th64 = knob("MOY_TH64", 16);
     if (p.Cin == 64 && p.N % 64 == 0) return (big && th64 == 16) ? launch_conv_direct<T, 64, 64, 16, 4, 1>(p, B, st) : launch_conv_direct<T, 64, 64, 8, 4, 1>(p, B, st);
-    static int bn128 = -1;
-    if (bn128 < 0) { const char* e = getenv("MOY_BN128"); bn128 = e ? atoi(e) : 0; }
+#if MOY_DIAG
+    static const int bn128 = knob("MOY_BN128", 0);
     if (bn128 && p.Cin == 128 && p.N % 128 == 0 && big) return launch_conv_direct<T, 128, 128, 16, 4, 2>(p, B, st);
     if (bn128 == 2 && p.Cin == 128 && p.N % 128 == 0) return launch_conv_direct<T, 128, 128, 8, 4, 2>(p, B, st);
+#endif
     if (p.Cin == 128 && p.N % 64 == 0) return big ? launch_conv_direct<T, 128, 64, 16, 4, 1>(p, B, st) : launch_conv_direct<T, 128, 64, 8, 4, 1>(p, B, st);
     return MOY_ENOSYS;
   }
@@ -1035,12 +1034,13 @@ static int try_conv_direct(GemmParams& p, int B, bool ln, hipStream_t st) {
 template <typename T, int KS>
 static int dispatch_tile(GemmParams& p, bool ln, hipStream_t st) {
   if (ln) return launch_cfg<T, 64, 256, 2, 4, true, KS>(p, st);
-  static int force = -1;   // MOY_TILE: tuning knob (tools/bench_gemm.py); 0 = the measured heuristic below
-  if (force < 0) { const char* e = getenv("MOY_TILE"); force = e ? atoi(e) : 0; }
+#if MOY_DIAG
+  static const int force = knob("MOY_TILE", 0);   // MOY_TILE: tuning knob (tools/bench_gemm.py); 0 = the measured heuristic below
   if (force == 1) return launch_cfg<T, 128, 128, 2, 4, false, KS>(p, st);
   if (force == 2) return launch_cfg<T, 64, 128, 2, 2, false, KS>(p, st);
   if (force == 3) return launch_cfg<T, 128, 64, 4, 2, false, KS>(p, st);
   if (force == 4) return launch_cfg<T, 64, 64, 2, 2, false, KS>(p, st);
+#endif
   // Tile choice (measured, tools/bench_gemm.py): 8-wave blocks for the large tiles; fill >= ~2 blocks
   // per CU when the problem allows it, keep tiles large otherwise.
   const long big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);

@@ -489,16 +489,16 @@ template <typename T, int WR, int NJ, int KS, int DIAG = 0, int MF = 16>
 static int gd_launch(GdParams& p, hipStream_t st) {
   using G = GdGeom<WR, NJ>;
   if (plan_only(MOY_KERNEL_DMA)) return MOY_OK;          // moy_gemm_query: the dispatch without the launch (and without touching the attribute statics)
+#if MOY_DIAG
   if constexpr (DIAG == 0 && MF == 16 && WR == 2 && NJ == 2) {
-    static int mf32 = -1;                  // MOY_GD_MFMA32=1: v_mfma_f32_32x32x16 (A/B knob; results equal up to fp32 rounding, not bit for bit)
-    if (mf32 < 0) { const char* e = getenv("MOY_GD_MFMA32"); mf32 = e ? atoi(e) : 0; }
+    static const int mf32 = knob("MOY_GD_MFMA32", 0);                  // MOY_GD_MFMA32=1: v_mfma_f32_32x32x16 (A/B knob; results equal up to fp32 rounding, not bit for bit)
     if (mf32 == 1) return gd_launch<T, WR, NJ, KS, 0, 32>(p, st);
   }
   if constexpr (DIAG == 0 && MF == 16 && std::is_same<T, bf16_t>::value && NJ == 2 && KS == 3) {
-    static int diag = -1;
-    if (diag < 0) diag = garbage_mode_env("MOY_GD_DIAG");
+    static const int diag = garbage_mode_env("MOY_GD_DIAG");
     if (diag == 1) return gd_launch<T, WR, NJ, KS, 1>(p, st);
   }
+#endif
   auto kern = gemm_dma_kernel<T, WR, NJ, KS, DIAG, MF>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -515,15 +515,16 @@ static int gd_launch(GdParams& p, hipStream_t st) {
 
 template <typename T, int KS>
 static int gd_pick(GdParams& p, int form, hipStream_t st) {
-  if (form == 0) return gd_launch<T, 2, 2, KS>(p, st);    // 256 x 256
+#if MOY_DIAG      // (the forms measured slower than the kernels they would replace: A/B knobs of the lab library)
   if (form == 1) return gd_launch<T, 4, 2, KS>(p, st);    // 512 x 128
-  return gd_launch<T, 2, 1, KS>(p, st);                   // 256 x 128
+  if (form == 2) return gd_launch<T, 2, 1, KS>(p, st);    // 256 x 128
+#endif
+  return form == 0 ? gd_launch<T, 2, 2, KS>(p, st) : MOY_ENOSYS;    // 256 x 256
 }
 
 // Eligibility + dispatch; MOY_ENOSYS = not this kernel's shape (moy_gemm falls through to the tiled kernel).
 int gemm_dma_try(const moy_gemm_args* a, hipStream_t st) {
-  static int mode = -1;                    // MOY_GEMM_DMA: 0 = off, 1 = by the heuristic below (default), 2 = whenever the shape fits
-  if (mode < 0) { const char* e = getenv("MOY_GEMM_DMA"); mode = e ? atoi(e) : 1; }
+  static const int mode = knob("MOY_GEMM_DMA", 1);                    // MOY_GEMM_DMA: 0 = off, 1 = by the heuristic below (default), 2 = whenever the shape fits
   if (!mode) return MOY_ENOSYS;
   if (a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_ENOSYS;
   if (a->A2 || a->a_rows || a->a_mask || a->ln_g || a->out_f32 || a->c_rows_per_batch || a->pre || a->plane_cols || a->dot_n || !a->C || a->run_levels)
@@ -535,8 +536,7 @@ int gemm_dma_try(const moy_gemm_args* a, hipStream_t st) {
   if ((a->scale && !aligned16(a->scale)) || (a->shift && !aligned16(a->shift))) return MOY_ENOSYS;
   if (a->ksize == 3 && (a->Cin % 64)) return MOY_ENOSYS;
   // form 0: 256 x 256 tiles (N % 256 == 0); form 1: 512 x 128 (N % 128 == 0); form 2: 256 x 128 (MOY_GEMM_DMA_FORM=2 only)
-  static int force = -1;
-  if (force < 0) { const char* e = getenv("MOY_GEMM_DMA_FORM"); force = e ? atoi(e) : -2; }
+  static const int force = knob("MOY_GEMM_DMA_FORM", -2);
   // measured (288 frames, same device): 256 x 256 beats the tiled kernel by 19-30 % (128 -> 256 stride 2: 564 -> 467 us, 256 -> 256:
   // 280 -> 206 us); 512 x 128 LOSES to the weight-stationary kernel (128 -> 128 stride 1: 274 vs 234 us) and to the tiled one
   // (stride 2: 330 vs 310 us): its A operand is 4/5 of every k-tile's 80 KB and crosses L2 -> LDS nine times; 256 x 128: 352 vs 301 us.
@@ -552,8 +552,7 @@ int gemm_dma_try(const moy_gemm_args* a, hipStream_t st) {
   }
   GdParams p{};
   {
-    static int variant = -1;
-    if (variant < 0) { const char* e = getenv("MOY_GD_VARIANT"); variant = e ? atoi(e) : 0; }
+    static const int variant = knob("MOY_GD_VARIANT", 0);
     p.variant = variant;
   }
   p.A = a->A; p.lda = a->lda; p.W = a->W; p.Kpad = (a->K + 63) / 64 * 64;

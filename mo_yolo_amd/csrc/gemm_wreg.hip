@@ -629,27 +629,27 @@ static int launch_wreg(WregParams& p, hipStream_t st) {
 
 // Row-tile height of the 32-columns-per-wave forms: MOY_WREG_BM=32|64|128 overrides the per-shape choice (A/B runs; a height whose
 // activation ring does not fit falls back to the next smaller one).
+#if MOY_DIAG
 static int wreg_bm_env() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MOY_WREG_BM"); v = e ? atoi(e) : 0; }
+  static const int v = knob("MOY_WREG_BM", 0);
   return v;
 }
+#endif
 
 // 8 waves x 32 columns = 256 columns per block, any K in {128, 256, 384, 512}: the 1x1 convs / input_proj with 256 outputs
 template <typename T>
 static int launch_wreg_k(WregParams& p, int K, hipStream_t st) {
+#if MOY_DIAG
   const int bm = wreg_bm_env();
+  if (K == 128 && bm == 128) return launch_wreg<T, 128, 3, 1, false, 8, 32, 128>(p, st);
+  if (K == 128 && bm == 64) return launch_wreg<T, 64, 3, 1, false, 8, 32, 128>(p, st);
+  if (K == 256 && bm >= 64) return launch_wreg<T, 64, 3, 1, false, 8, 32, 256>(p, st);
+  if (K == 384 && bm >= 64) return launch_wreg<T, 64, 3, 1, false, 8, 32, 384>(p, st);
+#endif
   switch (K) {
-    case 128:
-      if (bm == 128) return launch_wreg<T, 128, 3, 1, false, 8, 32, 128>(p, st);
-      if (bm == 64) return launch_wreg<T, 64, 3, 1, false, 8, 32, 128>(p, st);
-      return launch_wreg<T, 32, 3, 1, false, 8, 32, 128>(p, st);
-    case 256:
-      if (bm >= 64) return launch_wreg<T, 64, 3, 1, false, 8, 32, 256>(p, st);
-      return launch_wreg<T, 32, 3, 1, false, 8, 32, 256>(p, st);
-    case 384:
-      if (bm >= 64) return launch_wreg<T, 64, 3, 1, false, 8, 32, 384>(p, st);
-      return launch_wreg<T, 32, 3, 1, false, 8, 32, 384>(p, st);
+    case 128: return launch_wreg<T, 32, 3, 1, false, 8, 32, 128>(p, st);
+    case 256: return launch_wreg<T, 32, 3, 1, false, 8, 32, 256>(p, st);
+    case 384: return launch_wreg<T, 32, 3, 1, false, 8, 32, 384>(p, st);
     case 512: return launch_wreg<T, 32, 3, 1, false, 8, 32, 512>(p, st);
     default: return MOY_ENOSYS;
   }
@@ -658,29 +658,26 @@ static int launch_wreg_k(WregParams& p, int K, hipStream_t st) {
 // 4 waves x 32 columns = 128 columns per block, two blocks per CU: the 1x1 convs with 128 outputs (C2f cv1 / cv2 at the P3 level)
 template <typename T>
 static int launch_wreg_n128(WregParams& p, int K, hipStream_t st) {
+#if MOY_DIAG
   const int bm = wreg_bm_env();
+  if (K == 128 && bm >= 64) return launch_wreg<T, 64, 3, 2, false, 4, 32, 128>(p, st);
+  if (K == 192 && bm >= 64) return launch_wreg<T, 64, 3, 2, false, 4, 32, 192>(p, st);
+  if (K == 256 && bm >= 64) return launch_wreg<T, 64, 2, 2, false, 4, 32, 256>(p, st);
+#endif
   switch (K) {
-    case 128:
-      if (bm >= 64) return launch_wreg<T, 64, 3, 2, false, 4, 32, 128>(p, st);
-      return launch_wreg<T, 32, 3, 2, false, 4, 32, 128>(p, st);
-    case 192:
-      if (bm >= 64) return launch_wreg<T, 64, 3, 2, false, 4, 32, 192>(p, st);
-      return launch_wreg<T, 32, 3, 2, false, 4, 32, 192>(p, st);
-    case 256:
-      if (bm >= 64) return launch_wreg<T, 64, 2, 2, false, 4, 32, 256>(p, st);
-      return launch_wreg<T, 32, 3, 2, false, 4, 32, 256>(p, st);
+    case 128: return launch_wreg<T, 32, 3, 2, false, 4, 32, 128>(p, st);
+    case 192: return launch_wreg<T, 32, 3, 2, false, 4, 32, 192>(p, st);
+    case 256: return launch_wreg<T, 32, 3, 2, false, 4, 32, 256>(p, st);
     default: return MOY_ENOSYS;
   }
 }
 
 // Eligibility + dispatch; MOY_ENOSYS = not this kernel's shape (moy_gemm falls through to the tiled kernel).
 int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
-  static int mode = -1;                    // MOY_GEMM_WREG=0 switches the kernel off (A/B runs, bit-identity test)
-  if (mode < 0) { const char* e = getenv("MOY_GEMM_WREG"); mode = e ? atoi(e) : 1; }
+  static const int mode = knob("MOY_GEMM_WREG", 1);                    // MOY_GEMM_WREG=0 switches the kernel off (A/B runs, bit-identity test)
   if (!mode) return MOY_ENOSYS;
   if (a->dtype != MOY_BF16 && a->dtype != MOY_F16) return MOY_ENOSYS;
-  static int n128 = -1;                    // MOY_WREG_N128=0: N = 128 stays on the tiled kernel (A/B runs)
-  if (n128 < 0) { const char* e = getenv("MOY_WREG_N128"); n128 = e ? atoi(e) : 1; }
+  static const int n128 = knob("MOY_WREG_N128", 1);                    // MOY_WREG_N128=0: N = 128 stays on the tiled kernel (A/B runs)
   const bool is128 = a->N == 128 && n128 && (a->K == 128 || a->K == 192 || a->K == 256);
   if (a->ksize != 1 || (!is128 && (a->N % 256 || a->N / 256 > 16))) return MOY_ENOSYS;
   if (a->K != 128 && a->K != 256 && a->K != 384 && a->K != 512 && !(is128 && a->K == 192)) return MOY_ENOSYS;
@@ -702,16 +699,14 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
   } else if (a->ln_g || a->a_mask || a->dot_n || !a->C || a->run_levels) {
     return MOY_ENOSYS;
   }
-  static int preok = -1;                   // MOY_WREG_PRE=0: seeded launches stay on the tiled kernel (A/B runs)
-  if (preok < 0) { const char* e = getenv("MOY_WREG_PRE"); preok = e ? atoi(e) : 1; }
+  static const int preok = knob("MOY_WREG_PRE", 1);                   // MOY_WREG_PRE=0: seeded launches stay on the tiled kernel (A/B runs)
   const bool seeded = a->pre != nullptr;   // (shape and alignment of the seed were validated by moy_gemm)
   if (seeded) {
     const bool form = (is128 && a->K == 128) || (!is128 && a->K == 256);
     const int64_t seed_bytes = (int64_t)(a->M / (a->pre_h * a->pre_w)) * (a->pre_h / 2) * (a->pre_w / 2) * a->ld_pre * 4;
     if (!preok || score || !form || a->plane_cols || a->c_rows_per_batch || seed_bytes > 0x7fffffffLL) return MOY_ENOSYS;
   }
-  static int kgen = -1;                    // MOY_WREG_KGEN=0: only the K = 256 forms (A/B runs)
-  if (kgen < 0) { const char* e = getenv("MOY_WREG_KGEN"); kgen = e ? atoi(e) : 1; }
+  static const int kgen = knob("MOY_WREG_KGEN", 1);                    // MOY_WREG_KGEN=0: only the K = 256 forms (A/B runs)
   // the value-projection form (8 waves x 64 columns, head planes of 32) also exists for K = 128 and with the output row remap
   // (round 4: one launch per pyramid level, straight from that level's tensor)
   const bool valueform = a->plane_cols == 32 && (a->K == 256 || a->K == 128) && (a->N % 512) == 0 && !is128 && !seeded && !score;
@@ -762,16 +757,15 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
     if (a->K == 128) return a->dtype == MOY_BF16 ? launch_wreg<bf16_t, 32, 3, 2, true, 4, 64, 128>(p, st) : launch_wreg<f16_t, 32, 3, 2, true, 4, 64, 128>(p, st);
     return a->dtype == MOY_BF16 ? launch_wreg<bf16_t, 32, 3, 2, true>(p, st) : launch_wreg<f16_t, 32, 3, 2, true>(p, st);
   }
-  static int variant = -1;
-  if (variant < 0) { const char* e = getenv("MOY_WREG_VARIANT"); variant = e ? atoi(e) : 0; }
+  static const int variant = knob("MOY_WREG_VARIANT", 0);
   // measured on the value projection (M = 1.3 M, N = 1536, bf16; tiled kernel 1951 us): 4 waves x 256 columns, BM 32 / 3 buffers /
   // 2 blocks per CU 1168 us; BM 64 / 3 buffers / 1 block per CU 1254 us; BM 64 / 2 buffers 1274 us; BM 32 / 4 buffers 1458 us (one
   // block per CU fits); 8 waves x 512 columns, BM 32 / 3 buffers, one block per CU: 6 % faster than the first (same device) -- half as
   // many blocks re-fetch an activation tile that has left the L2.  (Those variants left the tree in round 3; MOY_WREG_VARIANT=2
   // keeps the 4-wave form selectable for A/B runs.)
+#if MOY_DIAG
   if (a->K == 128 && a->dtype == MOY_BF16) {      // A/B forms of the K = 128 value launch (MOY_WREG_V128; bf16 only)
-    static int v128 = -1;
-    if (v128 < 0) { const char* e = getenv("MOY_WREG_V128"); v128 = e ? atoi(e) : 0; }
+    static const int v128 = knob("MOY_WREG_V128", 0);
     switch (v128) {
       case 3: return launch_wreg<bf16_t, 32, 5, 1, false, 8, 64, 128>(p, st);     // one block, ring of 5
       case 4: return launch_wreg<bf16_t, 64, 3, 1, false, 8, 64, 128>(p, st);     // 64-row tiles
@@ -784,8 +778,7 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
     }
   }
   if (a->K == 256 && a->dtype == MOY_BF16) {      // A/B forms of the K = 256 value launches (MOY_WREG_V256; bf16 only)
-    static int v256 = -1;
-    if (v256 < 0) { const char* e = getenv("MOY_WREG_V256"); v256 = e ? atoi(e) : 0; }
+    static const int v256 = knob("MOY_WREG_V256", 0);
     switch (v256) {
       case 1: return launch_wreg<bf16_t, 64, 3, 1, false, 8, 32, 256>(p, st);     // 32 columns per wave (one plane), 64-row tiles
       case 2: return launch_wreg<bf16_t, 32, 3, 1, false, 8, 32, 256>(p, st);     // 32 columns per wave, 32-row tiles
@@ -794,6 +787,7 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
       default: break;
     }
   }
+#endif
   // round 4, measured (tools/probes/cu_share.py --value-only, 288 frames of the P3 level, 9.9 GB): 32-row tiles 2.53 ms, two blocks
   // per CU (spills) 5.4, ring of 5 2.53, 64-ROW TILES 1.93 ms = 5.1 TB/s -- a plane's run per tile is 4 KB instead of 2 KB and
   // the barrier / DMA-issue cadence per byte halves
@@ -801,6 +795,7 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
     return a->dtype == MOY_BF16 ? launch_wreg<bf16_t, 64, 3, 1, false, 8, 64, 128>(p, st) : launch_wreg<f16_t, 64, 3, 1, false, 8, 64, 128>(p, st);
   if (a->dtype == MOY_BF16) {
     if (variant == 2 || a->N % 512) return launch_wreg<bf16_t, 32, 3, 2>(p, st);
+#if MOY_DIAG
     // timing-only builds of the value-projection form (tools/probes/wreg_ablate.py): see the kernel's ABL comment
     static const int abl = garbage_mode_env("MOY_WREG_ABL");
     switch (abl) {
@@ -814,6 +809,7 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
       case 22: return launch_wreg<bf16_t, 32, 3, 1, false, 8, 64, 256, 22>(p, st);
       default: break;
     }
+#endif
     return launch_wreg<bf16_t, 32, 3, 1, false, 8>(p, st);
   }
   if (a->N % 512) return launch_wreg<f16_t, 32, 3, 2>(p, st);

@@ -787,8 +787,7 @@ extern "C" int moy_msda_raw0(const moy_msda_raw_args* a, void* stream) {
   p.ngroups = (p.nrows + MR_QB - 1) / MR_QB;
   const int nblk = (p.ngroups + 7) / 8 * 8;          // a multiple of the 8 XCDs: XCD x walks the x-th eighth of the groups
   // the tap sums on the matrix cores: three levels, every one with a 2 x 2 window inside it (MOY_MR_MFMA=0: the vector-ALU form)
-  static int mfma = -1;
-  if (mfma < 0) { const char* e = getenv("MOY_MR_MFMA"); mfma = e ? atoi(e) : 1; }
+  static const int mfma = knob("MOY_MR_MFMA", 1);
   bool small = false;
   for (int l = 0; l < a->L; ++l) small |= p.lv.H[l] < 2 || p.lv.W[l] < 2;
   if (mfma && a->L == 3 && !small) {

@@ -1755,8 +1755,7 @@ extern "C" int moy_sppf_pool(const void* x, int64_t ldx, int B, int H, int W, in
   MOY_DISPATCH_T(dtype, {
     const int cpr = C / DT<T>::KPB;                      // 16-byte chunks per pixel
     int G = (cpr % 4 == 0) ? 4 : ((cpr % 2 == 0) ? 2 : 1);
-    static int gmax = -1;                                // MOY_SPPF_G: cap of the group size (A/B runs)
-    if (gmax < 0) { const char* e = getenv("MOY_SPPF_G"); gmax = e ? atoi(e) : 4; }
+    static const int gmax = knob("MOY_SPPF_G", 4);                                // MOY_SPPF_G: cap of the group size (A/B runs)
     while (G > 1 && (G > gmax || (size_t)H * W * 32 * G > 160 * 1024)) G >>= 1;
     const size_t lds = (size_t)H * W * 32 * G;
     if (lds > 160 * 1024) return MOY_ENOSYS;   // the planes of one chunk must fit in LDS (P5 level: 19x34 .. 34x60)
@@ -1879,8 +1878,7 @@ template <typename T>
 static int try_msda_planes(const void* value, int64_t ldv, int64_t head_stride, int S, const LevelInfo& lv, int L, const float* offaw, int64_t ld_oa,
                            const float* ref, int Lq, int nrows, void* out, int64_t ldo, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
-    static int planes = -1;                  // MOY_MSDA_PLANES=0: the one-corner-per-load kernel on every layout (A/B runs)
-    if (planes < 0) { const char* e = getenv("MOY_MSDA_PLANES"); planes = e ? atoi(e) : 1; }
+    static const int planes = knob("MOY_MSDA_PLANES", 1);                  // MOY_MSDA_PLANES=0: the one-corner-per-load kernel on every layout (A/B runs)
     if (planes && ldv == 32 && head_stride * 8 * 2 <= 0x7fffffffLL && (int64_t)S * 64 <= 0x0fffffffLL && aligned16(value) && aligned16(out) &&
         (ldo % 8) == 0 && (head_stride % 8) == 0) {
       if (planes == 3)

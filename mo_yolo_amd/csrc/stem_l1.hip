@@ -309,9 +309,12 @@ static int launch_stem_l1(StemL1Params& p, hipStream_t st) {
   constexpr int TH = SL1_TH;
   constexpr int WIN_B = (((4 * TH + 3) * 52 * 4 + 15) / 16) * 16, PATCH_B = (((2 * TH + 1) * 33 * 64 + 1023) / 1024) * 1024, STG_B = TH * 16 * 128;
   constexpr int LDS = WIN_B + PATCH_B + STG_B + 128;
-  static int diag = -1;
-  if (diag < 0) diag = garbage_mode_env("MOY_SL1_DIAG");
+#if MOY_DIAG
+  static const int diag = garbage_mode_env("MOY_SL1_DIAG");
   auto kern = diag == 4 ? stem_l1_kernel<T, 4> : diag == 3 ? stem_l1_kernel<T, 3> : diag == 2 ? stem_l1_kernel<T, 2> : diag ? stem_l1_kernel<T, 1> : stem_l1_kernel<T, 0>;
+#else
+  auto kern = stem_l1_kernel<T, 0>;
+#endif
   static bool attr_set = false;
   if (!attr_set) {
     if (LDS > 65536 && (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_l1_kernel<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||

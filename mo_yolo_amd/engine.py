@@ -12,6 +12,7 @@ PyTorch is used for device memory and streams only.
 """
 from __future__ import annotations
 
+import dataclasses
 import os
 
 import ctypes as C
@@ -23,6 +24,55 @@ from . import _lib as L
 from .config import TrackArch, level_shapes
 
 BN_EPS = 1e-3   # ultralytics/utils/torch_utils.py:262
+
+
+@dataclasses.dataclass(frozen=True)
+class PlanOptions:
+    """How a TrackEngine lays its launch plan out -- every A/B switch of the plan as an explicit constructor argument (round 6: rounds
+    1-5 read 18 `MOY_*` environment variables here; process-wide state a host could not see).  The defaults ARE the shipped plan; the
+    product path never reads the environment.  `PlanOptions.from_env()` maps the old variable names onto the fields for the lab
+    scripts under tools/ (A/B runs), `bench.py --plan key=value,...` builds one from its argument."""
+    fuse_stem: bool = True        # preprocess + layer 0 + layer 1 as one launch (16-bit, uint8 frames)
+    fuse_upsample: bool = True    # Upsample + Concat folded into the consuming C2f's cv1
+    fuse_c2f: bool = True         # the first C2f block as one launch
+    value_planes: int = 2         # 2: head planes [layer][head][token][32]; 1: one [B*S, 256] matrix per layer; 0: one [B*S, 6*256] matrix
+    fold_proj: bool = True        # input_proj folded into value projection / score pass (where the library has the launches)
+    score_runs: bool = True       # score pass over the valid tokens only
+    p3_raw: bool = True           # level 0 of the deformable attention gathered raw and projected after the bilinear sum
+    query_order: bool = True      # the gather walks a frame's queries in Morton order of their reference points
+    mlp_head: bool = True         # the three-layer box heads as one launch
+    dec_mid: bool = True          # out_proj + norm1 + offsets | weights linear as one launch
+    dec_tail: bool = True         # output_proj + norm2 + FFN + norm3 + box refinement as one launch
+    qkv_split: int = 1            # q | k and v as two plain products over the tail's x + query_pos: 0 never, 1 at bench scale, 2 always
+    qkv_fuse: bool = False        # the tail projects the next layer's q | k | v (measured neutral)
+    w_packed: bool = True         # weights of the row-wise decoder kernels in MFMA-fragment order
+    post_1x1: bool = True         # the cv1 of the second C2f inside the down-sampling conv that feeds it
+    fork_value: int = 0           # compute units of a forked P3 value launch (measured: no gain; 0 = off)
+    assume_wreg: bool = True      # the library's weight-stationary kernel may be planned for (False with a lab library run under MOY_GEMM_WREG=0)
+
+    _ENV = dict(fuse_stem="MOY_FUSE_STEM", fuse_upsample="MOY_FUSE_UPSAMPLE", fuse_c2f="MOY_FUSE_C2F", value_planes="MOY_VALUE_PLANES",
+                fold_proj="MOY_FOLD_PROJ", score_runs="MOY_SCORE_RUNS", p3_raw="MOY_P3_RAW", query_order="MOY_Q_ORDER", mlp_head="MOY_MLP_HEAD",
+                dec_mid="MOY_DEC_MID", dec_tail="MOY_DEC_TAIL", qkv_split="MOY_QKV_SPLIT", qkv_fuse="MOY_QKV_FUSE", w_packed="MOY_W_PACKED",
+                post_1x1="MOY_POST_1X1", fork_value="MOY_FORK_VALUE", assume_wreg="MOY_GEMM_WREG")
+
+    @classmethod
+    def parse(cls, text: str) -> "PlanOptions":
+        """'p3_raw=0,qkv_fuse=1' -> PlanOptions (unknown keys raise)."""
+        kw = {}
+        fields = {f.name: f for f in dataclasses.fields(cls)}
+        for item in filter(None, (t.strip() for t in (text or "").split(","))):
+            k, _, v = item.partition("=")
+            if k not in fields:
+                raise ValueError(f"unknown plan option {k!r}; known: {sorted(fields)}")
+            kw[k] = (v.strip() not in ("0", "", "false", "False")) if fields[k].type in (bool, "bool") else int(v)
+        return cls(**kw)
+
+    @classmethod
+    def from_env(cls, env=None) -> "PlanOptions":
+        """LAB ONLY: the rounds 1-5 variable names (MOY_FOLD_PROJ=0, ...) onto the fields."""
+        env = os.environ if env is None else env
+        items = [f"{k}={env[v]}" for k, v in cls._ENV.items() if v in env]
+        return cls.parse(",".join(items))
 
 
 class View:
@@ -63,10 +113,11 @@ class TrackEngine:
                  score_thresh: float = 0.4, scale_boxes: bool = True, head_only: bool = False,
                  level_shapes_override=None, side_state: bool = False, iou: float = 0.7, max_det: int = 300, orig_hw=None,
                  temporal: int = 0, filter_score_thresh: float = 0.5, miss_tolerance: int = 5, n_inputs: int = 1,
-                 split_f16: bool = False, track_content: str = "decoder_output"):
+                 split_f16: bool = False, track_content: str = "decoder_output", options: PlanOptions | None = None):
         if not torch.cuda.is_available():
             raise L.MoyoloError("TrackEngine needs a HIP device (no CPU path)")
         self.lib = L.lib()
+        self.opt = options if options is not None else PlanOptions()
         self.arch, self.H, self.W, self.B = arch, H, W, batch
         self.dtype, self.code, self.dev = dtype, _code(dtype), torch.device(device)
         # split_f16 (fp32 engines, round 5): every product of `moy_gemm` on the 16-bit matrix cores in split precision (MOY_F32X3:
@@ -288,7 +339,7 @@ class TrackEngine:
     def _fuse_stem_l1(self, consumers):
         """Layers 0 and 1 as one launch: uint8 frames, 16-bit engine, Conv(3->32, s2) feeding ONLY Conv(32->64, 3x3, s2)."""
         a = self.arch.layers
-        if os.environ.get("MOY_FUSE_STEM", "1") == "0" or self.dtype == torch.float32 or self.input_format != "u8" or len(a) < 2:
+        if not self.opt.fuse_stem or self.dtype == torch.float32 or self.input_format != "u8" or len(a) < 2:
             return False
         return (a[0].kind == "Conv" and a[0].k == 3 and a[0].s == 2 and a[0].c1 == 3 and a[0].c2 == 32 and a[1].kind == "Conv"
                 and a[1].k == 3 and a[1].s == 2 and a[1].c1 == 32 and a[1].c2 == 64 and list(a[1].src) in ([-1], [0])
@@ -362,7 +413,7 @@ class TrackEngine:
                 up = arch.layers[cat.src[0]]
                 cons = [arch.layers[c] for c in consumers.get(cat.i, [])]
                 return (up.kind == "Upsample" and consumers.get(up.i, []) == [cat.i] and len(cons) == 1 and cons[0].kind == "C2f"
-                        and os.environ.get("MOY_FUSE_UPSAMPLE", "1") != "0")
+                        and self.opt.fuse_upsample)
             self._layer_first_step: Dict[int, int] = {}
             pending_post: Dict[int, tuple] = {}
             self.post_fused_layers = set()
@@ -420,7 +471,7 @@ class TrackEngine:
                     self._conv(p, x, hin, Ls.c1, Ls.c2, Ls.k, Ls.s, o)
                     outv[Ls.i] = o
                 elif (Ls.kind == "C2f" and Ls.c1 == 64 and Ls.c2 == 64 and Ls.n == 1 and Ls.shortcut and Ls.src[0] not in virt_cat
-                      and self.dtype != torch.float32 and os.environ.get("MOY_FUSE_C2F", "1") != "0"
+                      and self.dtype != torch.float32 and self.opt.fuse_c2f
                       and hin[0] * hin[1] * 64 * 2 <= 0x3fffffff):
                     # the whole block in one launch (csrc/c2f_fused.hip): y0 | y1, z and y2 never reach HBM
                     c, (h_, w_) = 32, hin
@@ -544,14 +595,14 @@ class TrackEngine:
         Wv = torch.cat([sd[f"{d}.decoder.layers.{i}.cross_attn.value_proj.weight"] for i in range(ndl)], 0)
         bv = torch.cat([sd[f"{d}.decoder.layers.{i}.cross_attn.value_proj.bias"] for i in range(ndl)], 0)
         # ... written as ndl contiguous [B*S, hd] planes: a layer's slice is dense in HBM for its deformable gather
-        vmode = os.environ.get("MOY_VALUE_PLANES", "2")
+        vmode = str(self.opt.value_planes)
         dh = hd // arch.nh
         # Round 5: level 0 (P3) of the deformable attention gathered RAW and projected after the bilinear sum (csrc/msda_raw.hip): its
         # value planes -- the longest launch of the plan, 54 % of whose output no sample touches -- are never formed.  Folded head only
         # (the composed weights are the fold's); MOY_P3_RAW=0 keeps the planes of all levels.
         self.p3raw = None
         self.value_tokens = S                  # tokens per frame in the value planes
-        if (fold is not None and vmode == "2" and os.environ.get("MOY_P3_RAW", "1") != "0" and nl >= 2 and arch.head_ch[0] == 128
+        if (fold is not None and vmode == "2" and self.opt.p3_raw and nl >= 2 and arch.head_ch[0] == 128
                 and min(self.shapes[0]) >= 2 and self.shapes[0][0] * self.shapes[0][1] * head_src[0][0].ld * self._esz <= 0x7fffffff):
             self.value_tokens = S - self.shapes[0][0] * self.shapes[0][1]
         if vmode == "2":
@@ -655,7 +706,7 @@ class TrackEngine:
             W0, b0 = self._linear_w(prefix + ".layers.0")
             W1, b1 = self._linear_w(prefix + ".layers.1")
             w2, b2 = self._dev(sd[prefix + ".layers.2.weight"]), self._dev(sd[prefix + ".layers.2.bias"])
-            if self.dtype != torch.float32 and os.environ.get("MOY_MLP_HEAD", "1") != "0":
+            if self.dtype != torch.float32 and self.opt.mlp_head:
                 # the whole head in one launch (csrc/mlp_head.hip): hidden activations stay in LDS
                 self._add(lib.moy_mlp_head, x.ptr, x.ld, a_rows.data_ptr() if a_rows is not None else None, M, W0.data_ptr(),
                           b0.data_ptr(), W1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), mode, aux.data_ptr(),
@@ -733,7 +784,7 @@ class TrackEngine:
         # frame, of the decoder's initial boxes: the six refinements move them little, transformer.py:676-728), so that the queries one
         # block gathers for are neighbours; rows and bits of every output are unchanged (MOY_Q_ORDER=0: top-k order, as rounds 1-5)
         self.qperm = None
-        if self.p3raw is not None and os.environ.get("MOY_Q_ORDER", "1") != "0" and Lq <= 1024:
+        if self.p3raw is not None and self.opt.query_order and Lq <= 1024:
             self.qperm = torch.zeros(B, Lq, device=self.dev, dtype=torch.int32)
             self._add(lib.moy_query_order, refs[0].data_ptr(), B, Lq, self.shapes[0][0], self.shapes[0][1], self.qperm.data_ptr(),
                       meta=dict(name=f"query_order B{B} L{Lq}", bytes=Md * 20, flops=0))
@@ -755,17 +806,17 @@ class TrackEngine:
         # weight-stationary kernel (MOY_QKV_SPLIT=0 switches it off, 2 forces it at any size).  Round 3 measured -0.2 ms on the sum of a
         # pass's kernels and +-0 on the two-stream step and left it off; round 5 (two interleaved pairs on one device): 33.45 / 33.33 ->
         # 33.24 / 33.28 ms per step, on by default
-        use_xp = (self.dtype != torch.float32 and arch.d_ffn % 256 == 0 and os.environ.get("MOY_DEC_TAIL", "1") != "0"
-                  and os.environ.get("MOY_QKV_SPLIT", "1") != "0" and (M >= 65536 or os.environ.get("MOY_QKV_SPLIT") == "2"))
+        use_xp = (self.dtype != torch.float32 and arch.d_ffn % 256 == 0 and self.opt.dec_tail
+                  and self.opt.qkv_split != 0 and (M >= 65536 or self.opt.qkv_split == 2))
         # round 5, OFF by default (MOY_QKV_FUSE=1): the fused tail of layer i can also PROJECT q | k | v of layer i + 1 while its rows are on
         # chip, instead of the two plain products over `xp`.  Bit-identical (tests), 10 launches fewer per pass -- and measured neutral: the three
         # extra products cost the tail what the two launches cost (sum of a pass's kernels 17.795 against 17.771 ms, step 64.40 / 64.51 against
         # 64.25 / 64.76 ms, two interleaved pairs): 1.4 MB of weights per 128-row tile is the tail's price per product, the plain products pay it once
-        fuse_qkv = use_xp and os.environ.get("MOY_QKV_FUSE", "0") == "1"
+        fuse_qkv = use_xp and self.opt.qkv_fuse
         qkv_ready = False
         xp = View(self._buf(M, hd)) if use_xp and not fuse_qkv else None
         from .ops import pack_mfma_a
-        packed_w = os.environ.get("MOY_W_PACKED", "1") != "0"       # the row-wise decoder kernels' weights in MFMA-fragment order
+        packed_w = self.opt.w_packed       # the row-wise decoder kernels' weights in MFMA-fragment order
         xp_ready = False
         for i in range(ndl):
             q = f"{d}.decoder.layers.{i}"
@@ -794,7 +845,7 @@ class TrackEngine:
             Woa = torch.cat([sd[q + ".cross_attn.sampling_offsets.weight"], sd[q + ".cross_attn.attention_weights.weight"]], 0)
             boa = torch.cat([sd[q + ".cross_attn.sampling_offsets.bias"], sd[q + ".cross_attn.attention_weights.bias"]], 0)
             n_oa = Woa.shape[0]
-            if self.dtype != torch.float32 and n_oa % 32 == 0 and n_oa <= 512 and os.environ.get("MOY_DEC_MID", "1") != "0":
+            if self.dtype != torch.float32 and n_oa % 32 == 0 and n_oa <= 512 and self.opt.dec_mid:
                 # out_proj + norm1 and the offsets | weights linear of (e1 + query_pos) as ONE launch (csrc/dec_mid.hip)
                 Wpad = torch.zeros(max(256, n_oa), hd)
                 Wpad[:n_oa] = Woa
@@ -855,7 +906,7 @@ class TrackEngine:
             Wp, bp = self._linear_w(q + ".cross_attn.output_proj")
             W1, b1 = self._linear_w(q + ".linear1")
             W2, b2 = self._linear_w(q + ".linear2")
-            if self.dtype != torch.float32 and arch.d_ffn % 256 == 0 and os.environ.get("MOY_DEC_TAIL", "1") != "0":
+            if self.dtype != torch.float32 and arch.d_ffn % 256 == 0 and self.opt.dec_tail:
                 # output_proj + norm2, FFN + norm3 and the box refinement as one launch (csrc/dec_tail.hip)
                 ln2, ln3 = self._ln(q + ".norm2"), self._ln(q + ".norm3")
                 hp = f"{d}.dec_bbox_head.{i}"
@@ -1089,7 +1140,7 @@ class TrackEngine:
         """Round 4: a down-sampling Conv (64 -> 128, 3x3, stride 2: yolo_track.yaml:19) whose ONLY consumer is the generic C2f that
         follows (i.e. its cv1, block.py:225-235) and whose output lives in no concat buffer: planned as one launch with that cv1
         (`moy_gemm_args.post_*`); MOY_POST_1X1=0 keeps the two launches."""
-        if self.dtype == torch.float32 or os.environ.get("MOY_POST_1X1", "1") == "0":
+        if self.dtype == torch.float32 or not self.opt.post_1x1:
             return False
         if not (Ls.k == 3 and Ls.s == 2 and Ls.c1 == 64 and Ls.c2 == 128) or Ls.i in home:
             return False
@@ -1111,7 +1162,7 @@ class TrackEngine:
         hipGraphs of bench.py (112 and 144 units: 37.94, 38.49).  The fork stays as a switch with its bit-identity test; the two
         free-running engines of StreamedEngines remain the overlap mechanism."""
         self._fork = None
-        L_ = int(os.environ.get("MOY_FORK_VALUE", "0"))
+        L_ = int(self.opt.fork_value)
         step = getattr(self, "_value_p3_step", None)
         first = getattr(self, "_layer_first_step", {})
         if L_ <= 0 or step is None or not getattr(self, "fold_proj", False) or 16 not in first:
@@ -1132,16 +1183,16 @@ class TrackEngine:
         head), level widths of 128 / 256 channels, a valid mask that is one rectangle per level."""
         arch, B, sd = self.arch, self.B, self.sd
         is32 = self.dtype == torch.float32
-        if os.environ.get("MOY_FOLD_PROJ", "1") == "0" or os.environ.get("MOY_VALUE_PLANES", "2") != "2":
+        if not self.opt.fold_proj or self.opt.value_planes != 2:
             return None
-        if os.environ.get("MOY_SCORE_RUNS", "1") == "0" or arch.nc > 4 or arch.hd != 256:
+        if not self.opt.score_runs or arch.nc > 4 or arch.hd != 256:
             return None
         if any(c not in (128, 256) for c in arch.head_ch):
             return None
         # 16-bit engines: every per-level launch must take the weight-stationary kernel (row runs, output row remap into head planes);
         # round 6, fp32 engines (exact and split-fp16): the TILED kernel has the row runs and the remap for fp32 tensors at any launch
         # size, so the fold holds at every batch -- what is asked below is only that a level's tensor fits one buffer descriptor
-        if not is32 and (os.environ.get("MOY_GEMM_WREG", "1") == "0" or any(B * h_ * w_ < 65536 for h_, w_ in self.shapes)):
+        if not is32 and (not self.opt.assume_wreg or any(B * h_ * w_ < 65536 for h_, w_ in self.shapes)):
             return None
         if is32 and any(B * h_ * w_ * v.ld * 4 > 0x7fffffff for (v, _), (h_, w_) in zip(head_src, self.shapes)):
             return None
@@ -1190,7 +1241,7 @@ class TrackEngine:
         rows zeroed) runs ONCE here and leaves that constant in the static `scores_all` buffer; the step then replaces it by the same
         launch restricted to the valid tokens, which `_generate_anchors` (head.py:1007) makes one rectangle per pyramid level --
         verified on the mask itself, any other pattern keeps the masked pass.  46 % fewer rows at 1088x608."""
-        if self.dtype == torch.float32 or os.environ.get("MOY_SCORE_RUNS", "1") == "0":
+        if self.dtype == torch.float32 or not self.opt.score_runs:
             return
         v = valid_host.bool()
         rects = valid_rectangles(v, self.shapes)

@@ -238,7 +238,7 @@ def value_planes_vs_tiled(eng, n_frames: int | None = None):
     """The value planes of the first `n_frames` frames as the plan left them, against the SAME value-projection launches restricted
     to those frames (fewer than 65536 rows -> `moy_gemm` takes the tiled kernel): bit for bit.  Call after a pass + synchronize."""
     launches = getattr(eng, "_value_launches", None)
-    if not launches or getattr(eng, "value_planes", None) is None or os.environ.get("MOY_VALUE_PLANES", "2") != "2":
+    if not launches or getattr(eng, "value_planes", None) is None or eng.opt.value_planes != 2:
         return dict(equal=True, skipped="no head-plane value launches in this plan")
     arch, B, S = eng.arch, eng.B, getattr(eng, "value_tokens", eng.S)      # (tokens per frame IN THE PLANES: without level 0 when it is sampled raw)
     P, dh = arch.ndl * arch.nh, arch.hd // arch.nh

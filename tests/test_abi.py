@@ -146,3 +146,58 @@ def test_gemm_query_answers_the_dispatch_on_the_host():
     small = dict(geom, B=1, M=76 * 136)
     assert q(**small)[0] == 0 and q(**small)[1] != _lib.KERNEL_CONV_S2
     assert q(**dict(small, post_W=al, post_scale=al, post_shift=al, post_n=128, post_act=_lib.ACT_SILU))[0] == _lib.ENOSYS   # never computed without its consumer
+
+
+def test_product_library_reads_no_environment_and_the_lab_lives_in_its_own_build():
+    """Round 6 (SURVEY section 8(b) 'no global state'): the kernels' sources call getenv nowhere (`knob()` of common.hpp is a
+    compile-time constant in the product build and an environment read only under -DMOY_DIAG=1); the shipped libmoyolo.so holds none of
+    the `MOY_*` switch names and none of the timing-only / stamped template instances; the lab build (libmoyolo_diag.so) has both and the
+    same C ABI; the host code reads no `MOY_*` variable outside `PlanOptions.from_env` (lab) and the bench's own launcher settings."""
+    import glob
+    import subprocess
+    csrc = os.path.join(ROOT, "mo_yolo_amd", "csrc")
+    for f in glob.glob(os.path.join(csrc, "*.hip")):
+        assert "getenv" not in open(f).read(), f
+    hpp = open(os.path.join(csrc, "common.hpp")).read()
+    assert hpp.count("getenv") == 1 and hpp.index("#if MOY_DIAG") < hpp.index("getenv") < hpp.index("#else")
+    prod, lab = build.build(verbose=False), build.build(verbose=False, diag=True)
+    bp, bl = open(prod, "rb").read(), open(lab, "rb").read()
+    for name in (b"MOY_GEMM_WREG", b"MOY_WREG_ABL", b"MOY_CWS_VARIANT", b"MOY_TILE", b"MOY_CU_LIMIT", b"MOY_SL1_DIAG", b"MOY_TAIL_ABL", b"MOY_MR_MFMA"):
+        assert name not in bp, name
+        assert name in bl, name
+    assert len(bp) < 0.75 * len(bl), (len(bp), len(bl))            # the lab's extra instances are most of a third of it
+    nm = lambda p: {ln.split()[-1] for ln in subprocess.run(["nm", "-D", "--defined-only", p], capture_output=True, text=True, check=True).stdout.splitlines()
+                    if " T " in ln and ln.split()[-1].startswith("moy_")}
+    assert nm(prod) == nm(lab) == set(header_symbols())
+    # timing-only / stamped kernel instances: only the lab has them (device code is embedded in the .so: search the mangled names)
+    for frag in (b"decoder_tail_kernelINS_6bf16_tELi2E", b"stem_l1_kernelINS_6bf16_tELi2E", b"conv_ws_pp_kernel"):
+        assert frag not in bp and frag in bl, frag
+    # host side: MOY_* variables are read by PlanOptions.from_env (lab) and by nothing else in the package
+    pkg = os.path.join(ROOT, "mo_yolo_amd")
+    for f in glob.glob(os.path.join(pkg, "*.py")):
+        txt = open(f).read()
+        if os.path.basename(f) == "engine.py":
+            body = txt[:txt.index("    def from_env(")] + txt[txt.index("class View"):]
+            assert "os.environ" not in body, "engine.py reads the environment outside PlanOptions.from_env"
+        elif os.path.basename(f) not in ("_lib.py", "build.py"):
+            assert "os.environ" not in txt, f
+
+
+def test_kernel_resource_check_fails_a_ring_kernel_with_scratch():
+    """build.py parses hipcc's kernel-resource-usage remarks; scratch in an LDS-DMA ring kernel (hand-counted vmcnt waits) is a
+    build error, scratch elsewhere is listed."""
+    rem = """x.hip:1:1: remark: Function Name: _ZN3moy16gemm_wreg_kernelINS_6bf16_tELi32EEEvNS_10WregParamsE [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     VGPRs: 256 [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     ScratchSize [bytes/lane]: 24 [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark: Function Name: _ZN3moy19decoder_tail_kernelINS_6bf16_tELi0EEEv21moy_decoder_tail_args [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     VGPRs: 256 [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     ScratchSize [bytes/lane]: 88 [-Rpass-analysis=kernel-resource-usage]
+"""
+    table, errors = build.check_resources("x.hip", rem)
+    assert len(table) == 2 and len(errors) == 1 and "gemm_wreg_kernel" in errors[0] and "24 bytes/lane" in errors[0]
+    res = os.path.join(ROOT, "mo_yolo_amd", "csrc", "obj", "resources.txt")
+    build.build(verbose=False)
+    if os.path.exists(res):       # (absent on a box that received the prebuilt library without the object directory)
+        rows = open(res).read().splitlines()
+        assert len(rows) > 200
+        assert not [r for r in rows if any(k in r for k in build.RING_KERNELS) and " scratch    0 " not in r]

@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from mo_yolo_amd.engine import TrackEngine
+from mo_yolo_amd.engine import TrackEngine, PlanOptions
 from oracle import track_oracle as O
 from tests._util import fixture, frames_u8, golden, net_input
 
@@ -229,9 +229,7 @@ def test_engine_folded_input_proj_plan_vs_classic_plan(dt, monkeypatch):
     cfg, arch, sd = fixture("c2")
     B = 104
     fr = torch.from_numpy(frames_u8(cfg, 0, B)).to(DEV)
-    monkeypatch.setenv("MOY_FOLD_PROJ", "0")
-    classic = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt)
-    monkeypatch.setenv("MOY_FOLD_PROJ", "1")
+    classic = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt, options=PlanOptions(fold_proj=False))
     folded = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt)
     assert folded.fold_proj and not classic.fold_proj and folded.feats is None
     assert sum("valid-runs" in m["name"] for m in folded.meta) == 3 and not any("level_" in m["name"] for m in classic.meta)
@@ -285,16 +283,14 @@ def test_engine_folded_input_proj_plan_vs_classic_plan(dt, monkeypatch):
 @pytest.mark.parametrize("name,B,dt", [("c2", 104, torch.bfloat16), ("c2", 104, torch.float16), ("c4", 34, torch.bfloat16)])
 def test_engine_level0_sampled_raw_vs_projected_planes(name, B, dt, monkeypatch):
     """Round 5: level 0 of the deformable attention gathered raw and projected after the bilinear sum (`moy_msda_raw0`; the P3 value
-    planes are never formed) against the same folded plan WITH those planes (MOY_P3_RAW=0).  Same function, the level-0 contribution
+    planes are never formed) against the same folded plan WITH those planes (`PlanOptions(p3_raw=False)`).  Same function, the level-0 contribution
     rounded once (the gathered vector) instead of once per projected value: the two plans must agree like two noise realisations of
     the type, and the raw plan must sit as close to the fp32 engine as the other does; everything in front of the decoder is the
     same launches -- bit-identical scores of all tokens, same query selection, same planes of the other levels."""
     from mo_yolo_amd.parity import engine_pair_stats
     cfg, arch, sd = fixture(name)
     fr = torch.from_numpy(frames_u8(cfg, 0, B)).to(DEV)
-    monkeypatch.setenv("MOY_P3_RAW", "0")
-    proj = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt)
-    monkeypatch.setenv("MOY_P3_RAW", "1")
+    proj = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt, options=PlanOptions(p3_raw=False))
     raw = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt)
     assert proj.fold_proj and raw.fold_proj and proj.p3raw is None and raw.p3raw is not None
     hw0 = raw.shapes[0][0] * raw.shapes[0][1]
@@ -332,11 +328,9 @@ def test_engine_forked_value_projection_bit_identical_eager_and_graph(monkeypatc
     cfg, arch, sd = fixture("c2")
     B = 104
     fr = torch.from_numpy(frames_u8(cfg, 0, B)).to(DEV)
-    monkeypatch.setenv("MOY_P3_RAW", "0")             # (the fork is a property of the plan that still projects level 0)
-    monkeypatch.setenv("MOY_FORK_VALUE", "0")
-    plain = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=torch.bfloat16)
-    monkeypatch.setenv("MOY_FORK_VALUE", "128")
-    forked = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=torch.bfloat16)
+    # (the fork is a property of the plan that still projects level 0)
+    plain = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=torch.bfloat16, options=PlanOptions(p3_raw=False))
+    forked = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=torch.bfloat16, options=PlanOptions(p3_raw=False, fork_value=128))
     assert plain._fork is None and forked._fork is not None and forked.fold_proj
     fk = forked._fork
     assert forked.meta[fk["side"]]["name"].startswith("gemm1x1") and "N1536" in forked.meta[fk["side"]]["name"]
@@ -449,33 +443,29 @@ def test_engine_16bit_within_the_budget_of_the_arithmetic_type(name, dt):
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_decoder_plan_variants_are_bit_identical(dt, monkeypatch):
     """Round-3 plan changes that must not change a bit of the outputs.  (i) q | k and v as two plain products over the
-    `x + query_pos` the previous layer's tail wrote (`MOY_QKV_SPLIT`; at bench scale they take the weight-stationary kernel) instead
+    `x + query_pos` the previous layer's tail wrote (`PlanOptions.qkv_split`; at bench scale they take the weight-stationary kernel) instead
     of one product with a second A operand, on the tiny fixture (forced: 2).  (ii) the score pass over the valid tokens only
-    (`MOY_SCORE_RUNS`) at the C2 shape with enough rows for the weight-stationary score kernel (B x S >= 65 536)."""
-    def run(name, B, env):
+    (`PlanOptions.score_runs`) at the C2 shape with enough rows for the weight-stationary score kernel (B x S >= 65 536)."""
+    def run(name, B, opt):
         cfg, arch, sd = fixture(name)
         fr = torch.from_numpy(frames_u8(cfg, 0, B)).to(DEV)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt)
+        eng = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt, options=PlanOptions(**opt))
         out = {k: v.clone() for k, v in eng.forward(fr).items()}
         torch.cuda.synchronize()
         return out, [m["name"] for m in eng.meta], arch
     keys = ("topk_ind", "logits", "boxes", "hs", "obj_idxes", "y", "rows")
-    a, na, arch = run("tiny", 3, {"MOY_QKV_SPLIT": "0"})
-    b, nb, _ = run("tiny", 3, {"MOY_QKV_SPLIT": "2"})
+    a, na, arch = run("tiny", 3, dict(qkv_split=0))
+    b, nb, _ = run("tiny", 3, dict(qkv_split=2))
     assert len(nb) == len(na) + (arch.ndl - 1), (len(na), len(nb))                  # one more launch per layer after the first
     for k in keys:
         assert torch.equal(a[k], b[k]), ("qkv split", k)
-    # (iii, round 5) the next layer's q | k | v projected by the fused tail itself (`MOY_QKV_FUSE=1`): one launch fewer per layer after the first
-    f, nf, _ = run("tiny", 3, {"MOY_QKV_SPLIT": "2", "MOY_QKV_FUSE": "1"})
+    # (iii, round 5) the next layer's q | k | v projected by the fused tail itself (`PlanOptions.qkv_fuse`): one launch fewer per layer after the first
+    f, nf, _ = run("tiny", 3, dict(qkv_split=2, qkv_fuse=True))
     assert len(nf) == len(na) - (arch.ndl - 1) and sum("decoder_tail+qkv" in n for n in nf) == arch.ndl - 1, nf
     for k in keys:
         assert torch.equal(a[k], f[k]), ("qkv fused into the tail", k)
-    monkeypatch.setenv("MOY_QKV_FUSE", "0")
-    monkeypatch.setenv("MOY_QKV_SPLIT", "0")
-    c, nc_, _ = run("c2", 5, {"MOY_SCORE_RUNS": "0"})
-    d, nd, _ = run("c2", 5, {"MOY_SCORE_RUNS": "1"})
+    c, nc_, _ = run("c2", 5, dict(qkv_split=0, score_runs=False))
+    d, nd, _ = run("c2", 5, dict(qkv_split=0, score_runs=True))
     assert not any("valid-runs" in n for n in nc_) and sum("valid-runs 7317/13566" in n for n in nd) == 1, nd
     for k in keys:
         assert torch.equal(c[k], d[k]), ("score runs", k)

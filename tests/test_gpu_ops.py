@@ -560,7 +560,7 @@ def test_gemm_dma_other_forms_in_a_child_process(form):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MOY_GEMM_DMA_FORM=str(form))
+    env = dict(os.environ, MOY_GEMM_DMA_FORM=str(form), MOYOLO_LIB=L.lab_library())     # an A/B knob of the LAB library (the product reads no environment)
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "gemm_dma_check.py"), "n128"], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -585,7 +585,7 @@ def test_conv3x3_grouped_virtual_row_tiling_bit_identical_to_plain_tiling(dtn, t
     grouped = P.run(dt)
     out = str(tmp_path / "plain.pt")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "conv_group_check.py"), out, dtn],
-                       env=dict(os.environ, MOY_CWS_GROUP="0"), capture_output=True, text=True, timeout=600)
+                       env=dict(os.environ, MOY_CWS_GROUP="0", MOYOLO_LIB=L.lab_library()), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     plain = torch.load(out)
     assert len(plain) == len(grouped) == len(P.SHAPES)

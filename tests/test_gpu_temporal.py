@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 from mo_yolo_amd import _lib as L
 from mo_yolo_amd import ops
-from mo_yolo_amd.engine import TrackEngine
+from mo_yolo_amd.engine import TrackEngine, PlanOptions
 from mo_yolo_amd.synth import SyntheticSequence, to_network_input
 from oracle import track_oracle as O
 from oracle.temporal_oracle import TemporalOracle
@@ -262,13 +262,11 @@ def test_temporal_mode_at_bench_scale_with_level0_sampled_raw(monkeypatch):
     """Round 5: the carried-query mode on the folded plan with level 0 sampled raw (`moy_msda_raw0`; decoder rows per sequence =
     [track slots | detect queries], so the gather's rows-per-frame is n_max + nq, not nq): 104 sequences in lockstep (the smallest batch
     at which the folded head applies at the C2 shape), 3 frames from a reset, bf16, against the same engine WITH the projected P3 planes
-    (MOY_P3_RAW=0): same ids / live-track counts wherever the scores keep their margins, boxes and memory within the 16-bit budget."""
+    (`PlanOptions(p3_raw=False)`): same ids / live-track counts wherever the scores keep their margins, boxes and memory within the 16-bit budget."""
     cfg, arch, sd = fixture("c2")
     B, n_max, T = 104, 40, 3
     seqs = [SyntheticSequence(s, cfg["H"], cfg["W"], cfg["style"]) for s in range(B)]
-    monkeypatch.setenv("MOY_P3_RAW", "0")
-    proj = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=torch.bfloat16, temporal=n_max)
-    monkeypatch.setenv("MOY_P3_RAW", "1")
+    proj = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=torch.bfloat16, temporal=n_max, options=PlanOptions(p3_raw=False))
     raw = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=torch.bfloat16, temporal=n_max)
     assert proj.fold_proj and raw.fold_proj and proj.p3raw is None and raw.p3raw is not None
     same_ids = frames = 0

@@ -7,7 +7,7 @@ mkdir -p $(dirname $out)
 run() {   # label, env assignment (or "")
   local label=$1 kv=$2
   local line
-  line=$(env $kv python3 bench.py --no-cpu-baseline --no-launch-table 2>/dev/null | tail -1) || return 1
+  line=$(env $kv python3 bench.py --lab --no-cpu-baseline --no-launch-table 2>/dev/null | tail -1) || return 1
   python3 - "$label" "$kv" "$line" >> $out <<'PY'
 import json, sys
 label, kv, line = sys.argv[1:4]
