@@ -44,7 +44,7 @@ __device__ __forceinline__ float tail_inv_sigmoid(float x) {   // nn/modules/uti
 #ifndef MOY_TAIL_PD
 #define MOY_TAIL_PD 1       // steps of activation fragments requested ahead of the MFMAs that use them
 #endif
-constexpr int TAIL_BM = 128, TAIL_NW = MOY_TAIL_NW;
+constexpr int TAIL_BM = 128, TAIL_NW = MOY_TAIL_NW;     // TAIL_BM: rows of a block at bench scale; round 6: 64 / 32-row blocks for small M
 #ifndef MOY_TAIL_RS
 #define MOY_TAIL_RS 8       // row parts of a product's step walk: 8 = one 16-row fragment per step.  With 4 (two fragments in flight per buffer) the
 #endif                      // kernel needed 38 registers more than it has, and one of the spilled values was reloaded INSIDE the FFN loop: a scratch
@@ -53,12 +53,17 @@ constexpr int TAIL_BM = 128, TAIL_NW = MOY_TAIL_NW;
 // fp32 vectors of the chain staged in LDS once per block (round 5): [bp | ln2_g | ln2_b | b2 | ln3_g | ln3_b | c0 | b1[0 .. 2048)]
 constexpr int TAIL_V_BP = 0, TAIL_V_LN2G = 256, TAIL_V_LN2B = 512, TAIL_V_B2 = 768, TAIL_V_LN3G = 1024, TAIL_V_LN3B = 1280, TAIL_V_C0 = 1536,
               TAIL_V_B1 = 1792, TAIL_MAX_FFN = 2048, TAIL_V_N = 1792 + TAIL_MAX_FFN;
-constexpr int TAIL_LDS = 2 * TAIL_BM * 512 + TAIL_BM * TAIL_NW * 16 + TAIL_V_N * 4;
+constexpr int tail_lds(int bm) { return 2 * bm * 512 + bm * TAIL_NW * 16 + TAIL_V_N * 4; }
+constexpr int TAIL_LDS = tail_lds(TAIL_BM);
 
-template <typename T, int ABL = 0>       // ABL 1: timing-only build that keeps the FIRST weight chunk for every product (MOY_TAIL_ABL=1; results garbage)
+// BM_ (round 6): rows of a block.  128 at bench scale; at small M (a few frames per step: the small-batch leg) the chain of a block --
+// eleven dependent products, each behind 128 KB of weights -- is the kernel's whole duration, and 10 blocks of 128 rows leave 246
+// compute units idle: 32-row blocks quarter the matrix work of a block's chain (every row's arithmetic is independent of the block height:
+// the same bits).
+template <typename T, int ABL = 0, int BM_ = TAIL_BM>       // ABL 1: timing-only build that keeps the FIRST weight chunk for every product (MOY_TAIL_ABL=1; results garbage)
                                          // ABL 2: s_memtime stamps of wave 0 per phase, written over the head of `out` (MOY_TAIL_ABL=2; tools/probes/tail_diag.py)
 __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_decoder_tail_args p) {
-  constexpr int BM = TAIL_BM, NW = TAIL_NW, NTHR = 64 * NW, MT = BM / 16, NT = 16 / NW, WC = 256 / NW;
+  constexpr int BM = BM_, NW = TAIL_NW, NTHR = 64 * NW, MT = BM / 16, NT = 16 / NW, WC = 256 / NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* XA = smem;
   unsigned char* XB = smem + BM * 512;
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
   const int lbase = r * 512 + ((q ^ r) << 4);      // fragment of row i*16 + r, chunk (pn*4 + q) ^ r
   // rows in two halves of 64: 16 fragment registers live instead of 32
   auto gemm_acc = [&](const unsigned char* As, f32x4 (&acc)[MT][NT], const WSrc& next) {
-    constexpr int RS = MOY_TAIL_RS, HM = MT / RS, NSTEP = 8 * RS;   // step s = (panel s / RS, row part s % RS), panel outermost
+    constexpr int RS = MOY_TAIL_RS < MT ? MOY_TAIL_RS : MT, HM = MT / RS, NSTEP = 8 * RS;   // step s = (panel s / RS, row part s % RS), panel outermost
     constexpr int PD = MOY_TAIL_PD;
     u32x4 af[PD + 1][HM];                                 // the fragments of step s+PD are requested before the MFMAs of step s
     auto frag = [&](int s_, u32x4 (&buf)[HM]) {
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
   //      order, so a bias / residual / LayerNorm load issued in an epilogue came back only after BOTH weight halves of the NEXT product,
   //      requested just before it (32 x 16-byte loads per lane): the stamps (MOY_TAIL_ABL=2) showed the epilogues at twice the time of
   //      the products they follow.  The weight requests now overlap the epilogues instead of gating them.
-  constexpr int NREF = BM * 4 / NTHR;              // (row, output) pairs of the box refinement per thread
+  constexpr int NREF = (BM * 4 + NTHR - 1) / NTHR; // (row, output) pairs of the box refinement per thread (blocks of fewer than 128 rows: some threads have none)
   constexpr int NLD = BM * 32 / NTHR;              // 16-byte pieces of a 128 x 256 tile per thread
   if ((int)blockIdx.x >= ntiles) return;
   const int m0 = blockIdx.x * BM;
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
 #pragma unroll
     for (int k = 0; k < NREF; ++k) {
       const int m = m0 + ((tid + k * NTHR) >> 2);
-      ref_in_r[k] = m < p.M ? p.ref_in[(int64_t)m * 4 + (tid & 3)] : 0.f;
+      ref_in_r[k] = (m < p.M && tid + k * NTHR < BM * 4) ? p.ref_in[(int64_t)m * 4 + (tid & 3)] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_de
 #pragma unroll
   for (int k = 0; k < NREF; ++k) {
     const int row = (tid + k * NTHR) >> 2, o = tid & 3, m = m0 + row;
-    if (m < p.M) {
+    if (m < p.M && row < BM) {
       const float* pr = P + row * NW * 4 + o;
       float v = 0.f;
 #pragma unroll
@@ -499,6 +504,30 @@ extern "C" int moy_decoder_tail(const moy_decoder_tail_args* a, void* stream) {
       !aligned16(a->e1))
     return MOY_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // small M: lower blocks, so that the launch is more than a handful of long chains (see BM_ above): 32 rows below 64 x 192 rows, 64 rows
+  // below 128 x 192 rows (at least ~192 blocks before the block grows)
+  if (a->M < 128 * 192) {
+    const bool b32 = a->M < 64 * 192;
+    const int bm = b32 ? 32 : 64, lds = tail_lds(bm);
+    static bool attr_small = false;
+    if (!attr_small) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_tail_kernel<bf16_t, 0, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, tail_lds(32)) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_tail_kernel<f16_t, 0, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, tail_lds(32)) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_tail_kernel<bf16_t, 0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, tail_lds(64)) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_tail_kernel<f16_t, 0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, tail_lds(64)) != hipSuccess)
+        return MOY_ELAUNCH;
+      attr_small = true;
+    }
+    const int nb = (a->M + bm - 1) / bm;
+    if (a->dtype == MOY_BF16) {
+      if (b32) hipLaunchKernelGGL((decoder_tail_kernel<bf16_t, 0, 32>), dim3(nb), dim3(64 * TAIL_NW), lds, st, *a);
+      else hipLaunchKernelGGL((decoder_tail_kernel<bf16_t, 0, 64>), dim3(nb), dim3(64 * TAIL_NW), lds, st, *a);
+    } else {
+      if (b32) hipLaunchKernelGGL((decoder_tail_kernel<f16_t, 0, 32>), dim3(nb), dim3(64 * TAIL_NW), lds, st, *a);
+      else hipLaunchKernelGGL((decoder_tail_kernel<f16_t, 0, 64>), dim3(nb), dim3(64 * TAIL_NW), lds, st, *a);
+    }
+    return launch_status();
+  }
   static bool attr_set = false;          // > 64 KiB of dynamic LDS: opt in once per kernel symbol
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_tail_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS) != hipSuccess ||

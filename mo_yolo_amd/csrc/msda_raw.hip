@@ -317,7 +317,14 @@ __global__ __launch_bounds__(256, 3) void msda_raw_kernel(const MsdaRawParams p)
 constexpr int MRM_NW = 8;                    // waves per block
 constexpr int MRM_ENT = 96;                  // (head, point) entries per query: 8 x 12
 
-template <typename T>
+// X4 (round 6): level 0 by 16-BYTE loads.  The counters of round 6 (profiles/r06_gather_order_*) show the kernel bound by the texture
+// addresser / L1 pipeline -- busy 85 % of the kernel's cycles at ~8 cycles per wave instruction -- not by misses (a Morton walk order
+// raised the L1 hit rate from 72.9 to 76.9 % and changed nothing), so what counts is the NUMBER of vector-memory instructions.  Lane
+// (n, kg) loads channels 8n .. 8n+7 of each of the four corners of point kg: 16 lanes = one whole 256-byte pixel, FOUR instructions per
+// head instead of sixteen.  The B fragment of product m is then dword m of the four corner registers -- (corner) x (even, odd) of channel
+// pair 4n + m, still no instruction between the load and the product -- and D's columns are the channel pairs 4n + m: the lane's four
+// results are four consecutive dwords of g (one 16-byte LDS store).  The same products on the same values: bit-identical.
+template <typename T, bool X4 = true>
 __global__ __launch_bounds__(64 * MRM_NW, 2) void msda_raw_mfma_kernel(const MsdaRawParams p) {
   static_assert(sizeof(T) == 2, "16-bit values");
   __shared__ __attribute__((aligned(16))) unsigned char sG[MR_QB * MR_GP];
@@ -421,7 +428,15 @@ __global__ __launch_bounds__(64 * MRM_NW, 2) void msda_raw_mfma_kernel(const Msd
     uint32_t tp[DEPTH + 1][16];
     auto issue = [&](auto uc, uint32_t (&t)[16]) {
       constexpr int u = decltype(uc)::value;
-      if constexpr (u < 8) {
+      if constexpr (u < 8 && X4) {
+        const uint32_t voff = aB[u * 12] + (uint32_t)n * 16u;
+        const u32x4 c0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, voff, 0, MOY_MRM_AUX));
+        const u32x4 c1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, voff, pix_pitch, MOY_MRM_AUX));
+        const u32x4 c2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, voff, row_pitch, MOY_MRM_AUX));
+        const u32x4 c3 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, voff, row_pitch + pix_pitch, MOY_MRM_AUX));
+        t[0] = c0.x; t[1] = c0.y; t[2] = c0.z; t[3] = c0.w;  t[4] = c1.x; t[5] = c1.y; t[6] = c1.z; t[7] = c1.w;        // t[corner * 4 + m]
+        t[8] = c2.x; t[9] = c2.y; t[10] = c2.z; t[11] = c2.w;  t[12] = c3.x; t[13] = c3.y; t[14] = c3.z; t[15] = c3.w;
+      } else if constexpr (u < 8) {
         const uint32_t voff = aB[u * 12] + nb;
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
@@ -453,7 +468,15 @@ __global__ __launch_bounds__(64 * MRM_NW, 2) void msda_raw_mfma_kernel(const Msd
     auto consume = [&](auto uc, const uint32_t (&t)[16]) {
       constexpr int u = decltype(uc)::value;
       const f32x4 z{0.f, 0.f, 0.f, 0.f};
-      if constexpr (u < 8) {
+      if constexpr (u < 8 && X4) {
+        const u32x4 a = weights(u * 12);
+        f32x4 d[4];
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) d[mm] = mr_mfma<T>(z, a, u32x4{t[mm], t[4 + mm], t[8 + mm], t[12 + mm]});
+        if (lane < 16)        // channel pairs 4 * lane .. 4 * lane + 3 of head u
+          *reinterpret_cast<u32x4*>(gdst + u * 64 + lane * 4) = u32x4{DT<T>::pack2(d[0].x + d[0].z, d[0].y + d[0].w), DT<T>::pack2(d[1].x + d[1].z, d[1].y + d[1].w),
+                                                                      DT<T>::pack2(d[2].x + d[2].z, d[2].y + d[2].w), DT<T>::pack2(d[3].x + d[3].z, d[3].y + d[3].w)};
+      } else if constexpr (u < 8) {
         const u32x4 a = weights(u * 12);
         f32x4 d[4];
 #pragma unroll
@@ -791,8 +814,20 @@ extern "C" int moy_msda_raw0(const moy_msda_raw_args* a, void* stream) {
   bool small = false;
   for (int l = 0; l < a->L; ++l) small |= p.lv.H[l] < 2 || p.lv.W[l] < 2;
   if (mfma && a->L == 3 && !small) {
-    if (a->dtype == MOY_BF16) hipLaunchKernelGGL((msda_raw_mfma_kernel<bf16_t>), dim3(nblk), dim3(64 * MRM_NW), 0, st, p);
-    else hipLaunchKernelGGL((msda_raw_mfma_kernel<f16_t>), dim3(nblk), dim3(64 * MRM_NW), 0, st, p);
+    // level 0 by 16-byte loads needs 16-byte aligned pixels (a channel slice of a wider tensor at an odd 8-channel offset keeps dword loads)
+    const bool x4ok = (a->ld0 % 8) == 0 && aligned16(a->x0);
+#if MOY_DIAG
+    static const int x4 = knob("MOY_MRM_X4", 1);                        // A/B: 0 = level 0 by dword loads (the round-5 form)
+    if (!x4 || !x4ok) {
+#else
+    if (!x4ok) {
+#endif
+      if (a->dtype == MOY_BF16) hipLaunchKernelGGL((msda_raw_mfma_kernel<bf16_t, false>), dim3(nblk), dim3(64 * MRM_NW), 0, st, p);
+      else hipLaunchKernelGGL((msda_raw_mfma_kernel<f16_t, false>), dim3(nblk), dim3(64 * MRM_NW), 0, st, p);
+      return launch_status();
+    }
+    if (a->dtype == MOY_BF16) hipLaunchKernelGGL((msda_raw_mfma_kernel<bf16_t, true>), dim3(nblk), dim3(64 * MRM_NW), 0, st, p);
+    else hipLaunchKernelGGL((msda_raw_mfma_kernel<f16_t, true>), dim3(nblk), dim3(64 * MRM_NW), 0, st, p);
     return launch_status();
   }
   if (a->dtype == MOY_BF16) hipLaunchKernelGGL((msda_raw_kernel<bf16_t>), dim3(nblk), dim3(256), 0, st, p);

@@ -39,7 +39,8 @@ class PlanOptions:
     fold_proj: bool = True        # input_proj folded into value projection / score pass (where the library has the launches)
     score_runs: bool = True       # score pass over the valid tokens only
     p3_raw: bool = True           # level 0 of the deformable attention gathered raw and projected after the bilinear sum
-    query_order: bool = True      # the gather walks a frame's queries in Morton order of their reference points
+    query_order: bool = False     # the gather walks a frame's queries in Morton order of their reference points (round 6: L1 hit rate 72.9 ->
+                                  # 76.9 %, kernel 1-2 % SLOWER -- it is bound by the texture addresser, not by misses: off)
     mlp_head: bool = True         # the three-layer box heads as one launch
     dec_mid: bool = True          # out_proj + norm1 + offsets | weights linear as one launch
     dec_tail: bool = True         # output_proj + norm2 + FFN + norm3 + box refinement as one launch
@@ -48,12 +49,17 @@ class PlanOptions:
     w_packed: bool = True         # weights of the row-wise decoder kernels in MFMA-fragment order
     post_1x1: bool = True         # the cv1 of the second C2f inside the down-sampling conv that feeds it
     fork_value: int = 0           # compute units of a forked P3 value launch (measured: no gain; 0 = off)
+    fork_small_value: int = 0     # round 6: below this many value rows (B x S) the value projection of the classic plan runs on a side stream
+                                  # beside the query selection / first self-attention.  MEASURED at four frames per step: 1.258 ms forked
+                                  # against 1.224 ms in plan order (the value launch fills the chip and only takes turns with the chain): off
+    qkv_fuse_small: bool = True   # round 6: below 65536 decoder rows the tail projects the next layer's q | k | v (a launch less per layer)
     assume_wreg: bool = True      # the library's weight-stationary kernel may be planned for (False with a lab library run under MOY_GEMM_WREG=0)
 
     _ENV = dict(fuse_stem="MOY_FUSE_STEM", fuse_upsample="MOY_FUSE_UPSAMPLE", fuse_c2f="MOY_FUSE_C2F", value_planes="MOY_VALUE_PLANES",
                 fold_proj="MOY_FOLD_PROJ", score_runs="MOY_SCORE_RUNS", p3_raw="MOY_P3_RAW", query_order="MOY_Q_ORDER", mlp_head="MOY_MLP_HEAD",
                 dec_mid="MOY_DEC_MID", dec_tail="MOY_DEC_TAIL", qkv_split="MOY_QKV_SPLIT", qkv_fuse="MOY_QKV_FUSE", w_packed="MOY_W_PACKED",
-                post_1x1="MOY_POST_1X1", fork_value="MOY_FORK_VALUE", assume_wreg="MOY_GEMM_WREG")
+                post_1x1="MOY_POST_1X1", fork_value="MOY_FORK_VALUE", assume_wreg="MOY_GEMM_WREG", fork_small_value="MOY_FORK_SMALL",
+                qkv_fuse_small="MOY_QKV_FUSE_SMALL")
 
     @classmethod
     def parse(cls, text: str) -> "PlanOptions":
@@ -614,6 +620,7 @@ class TrackEngine:
             if fold is None:
                 self._gemm(feats, self._weight(Wv), ndl * hd, hd, value[0][0], B * S, shift=self._dev(bv), planes=(dh, B * S * dh))
                 self._value_launches.append((self._steps[-1][1][0]._obj, S))
+                self._value_step = len(self._steps) - 1
             else:
                 # value = (P . Wp^T * s + t) . Wv^T + bv = P . (Wv diag(s) Wp)^T + (Wv t + bv): one launch per level, rows (b, i) of the
                 # level -> token b*S + off + i of every head plane (output row remap)
@@ -813,6 +820,10 @@ class TrackEngine:
         # extra products cost the tail what the two launches cost (sum of a pass's kernels 17.795 against 17.771 ms, step 64.40 / 64.51 against
         # 64.25 / 64.76 ms, two interleaved pairs): 1.4 MB of weights per 128-row tile is the tail's price per product, the plain products pay it once
         fuse_qkv = use_xp and self.opt.qkv_fuse
+        # round 6: at SMALL M (the small-batch leg: a few frames per step) a launch is its own latency, not its work: the tail projects the
+        # next layer's q | k | v while its rows are on chip -- one launch less per layer; bit-identical (tests)
+        if (not use_xp and self.opt.qkv_fuse_small and M < 65536 and self.dtype != torch.float32 and arch.d_ffn % 256 == 0 and self.opt.dec_tail):
+            fuse_qkv = True
         qkv_ready = False
         xp = View(self._buf(M, hd)) if use_xp and not fuse_qkv else None
         from .ops import pack_mfma_a
@@ -1162,6 +1173,19 @@ class TrackEngine:
         hipGraphs of bench.py (112 and 144 units: 37.94, 38.49).  The fork stays as a switch with its bit-identity test; the two
         free-running engines of StreamedEngines remain the overlap mechanism."""
         self._fork = None
+        # Round 6, small batches: the value projection of the classic plan (one launch over all B x S tokens, the longest of a small-batch
+        # pass) depends on nothing between input_proj and the first deformable sampling, and the launches between them -- score pass, query
+        # selection, box head, first self-attention -- are a chain of small kernels that leave the chip mostly idle: it runs beside them on
+        # a side stream (two parallel branches of the hipGraph), whole chip for both (no CU limit).  Bit-identical by construction.
+        vs = getattr(self, "_value_step", None)
+        if vs is not None and 0 < self.B * self.S < int(self.opt.fork_small_value) and not int(self.opt.fork_value):
+            join = next((i for i, m in enumerate(self.meta) if m["name"].startswith("msda")), None)
+            if join is not None and 0 < vs < self._topk_step - 1 < join:
+                # issued once the SCORE pass is through (itself a chip-filling launch: beside it the value launch only takes turns), so
+                # that it runs beside the chain of small launches behind the score pass
+                self._side_stream = torch.cuda.Stream(device=self.dev)
+                self._fork = dict(side=vs, after=self._topk_step - 1, join=join, side_cus=0, main_cus=0)
+                return
         L_ = int(self.opt.fork_value)
         step = getattr(self, "_value_p3_step", None)
         first = getattr(self, "_layer_first_step", {})

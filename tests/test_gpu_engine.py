@@ -454,13 +454,13 @@ def test_decoder_plan_variants_are_bit_identical(dt, monkeypatch):
         torch.cuda.synchronize()
         return out, [m["name"] for m in eng.meta], arch
     keys = ("topk_ind", "logits", "boxes", "hs", "obj_idxes", "y", "rows")
-    a, na, arch = run("tiny", 3, dict(qkv_split=0))
-    b, nb, _ = run("tiny", 3, dict(qkv_split=2))
+    a, na, arch = run("tiny", 3, dict(qkv_split=0, qkv_fuse_small=False))
+    b, nb, _ = run("tiny", 3, dict(qkv_split=2, qkv_fuse_small=False))
     assert len(nb) == len(na) + (arch.ndl - 1), (len(na), len(nb))                  # one more launch per layer after the first
     for k in keys:
         assert torch.equal(a[k], b[k]), ("qkv split", k)
     # (iii, round 5) the next layer's q | k | v projected by the fused tail itself (`PlanOptions.qkv_fuse`): one launch fewer per layer after the first
-    f, nf, _ = run("tiny", 3, dict(qkv_split=2, qkv_fuse=True))
+    f, nf, _ = run("tiny", 3, dict(qkv_split=2, qkv_fuse=True, qkv_fuse_small=False))
     assert len(nf) == len(na) - (arch.ndl - 1) and sum("decoder_tail+qkv" in n for n in nf) == arch.ndl - 1, nf
     for k in keys:
         assert torch.equal(a[k], f[k]), ("qkv fused into the tail", k)
@@ -469,6 +469,42 @@ def test_decoder_plan_variants_are_bit_identical(dt, monkeypatch):
     assert not any("valid-runs" in n for n in nc_) and sum("valid-runs 7317/13566" in n for n in nd) == 1, nd
     for k in keys:
         assert torch.equal(c[k], d[k]), ("score runs", k)
+
+
+@pytest.mark.parametrize("name,B,dt,temporal", [("tiny", 3, torch.bfloat16, 0), ("c2", 4, torch.float16, 0), ("c2", 4, torch.bfloat16, 40)])
+def test_small_batch_plan_forked_value_and_fused_qkv_bit_identical(name, B, dt, temporal):
+    """Round 6, the small-batch leg (one frame of each of a few live sequences per hipGraph replay): the value projection of the classic
+    plan on a side stream beside the query selection / first self-attention (`PlanOptions.fork_small_value`: measured +33 us at four frames,
+    so off by default -- the chip-filling value launch only takes turns with the chain it was meant to hide behind), the next layer's
+    q | k | v projected by the decoder tail (`qkv_fuse_small`: one launch less per layer) and the tail's 32-row blocks change no bit of the
+    outputs -- eagerly and replayed from the hipGraph (the fork becomes two parallel branches) -- against the plan without the two."""
+    cfg, arch, sd = fixture(name)
+    fr = torch.from_numpy(frames_u8(cfg, 0, B)).to(DEV)
+    kw = dict(temporal=temporal) if temporal else {}
+    plain = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt, options=PlanOptions(fork_small_value=0, qkv_fuse_small=False), **kw)
+    small = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt, options=PlanOptions(fork_small_value=262144), **kw)
+    assert plain._fork is None and small._fork is not None and small._fork["side_cus"] == 0
+    assert small.meta[small._fork["side"]]["name"].startswith("gemm1x1") and small.meta[small._fork["join"]]["name"].startswith("msda")
+    assert small.num_launches == plain.num_launches - (arch.ndl - 1) and sum("decoder_tail+qkv" in m["name"] for m in small.meta) == arch.ndl - 1
+    # (temporal mode: `rows` beyond n_rows keep whatever an earlier step left there -- the capture's warm-up steps in the replayed engine)
+    keys = ("scores", "boxes", "obj_idxes", "topk_ind", "hs", "n_rows", "logits", "y") + (() if temporal else ("rows",))
+    op = {k: v.clone() for k, v in plain.forward(fr).items()}
+    torch.cuda.synchronize()
+    os_ = {k: v.clone() for k, v in small.forward(fr).items()}
+    torch.cuda.synchronize()
+    for k in keys:
+        assert torch.equal(op[k], os_[k]), ("eager", k)
+    assert torch.equal(plain.value_planes, small.value_planes)
+    small.capture()
+    if temporal:
+        small.reset_sequence()
+    for rep in range(3):
+        og = {k: v.clone() for k, v in small.forward(fr).items()}
+        torch.cuda.synchronize()
+        if temporal and rep:
+            break                       # (carried state: only the first replay from a reset equals the eager first step)
+        for k in keys:
+            assert torch.equal(op[k], og[k]), ("graph replay", rep, k)
 
 
 def test_engine_graph_replay_matches_eager():

@@ -850,6 +850,38 @@ def test_decoder_tail_one_launch_equals_separate(dt, M, dffn):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_decoder_tail_block_heights_are_bit_identical(dt):
+    """Round 6: at small M (the small-batch leg) moy_decoder_tail runs 32- or 64-row blocks instead of 128-row ones (a block's chain of
+    eleven dependent products is the launch's duration there).  Every row's arithmetic is independent of the block height: the first rows
+    of a 24 653-row launch (128-row blocks) == the same rows launched alone as 12 300 rows (64-row blocks) and as 1 000 rows (32-row
+    blocks), bit for bit -- outputs, refined boxes and the next layer's q | k | v."""
+    M, dffn = 128 * 192 + 77, 1024
+    g = lambda *s_, seed, scale=1.0: rnd(*s_, seed=seed, scale=scale)
+    samp, e1 = g(M, 256, seed=1).to(DEV, dt), g(M, 256, seed=2).to(DEV, dt)
+    pk = lambda w: ops.pack_mfma_a(ops.pad_weight(w.to(DEV), dt))
+    Wp, W1, W2 = pk(g(256, 256, seed=3, scale=1 / 16)), pk(g(dffn, 256, seed=4, scale=1 / 16)), pk(g(256, dffn, seed=5, scale=1 / 32))
+    B0, B1 = pk(g(256, 256, seed=6, scale=1 / 16)), pk(g(256, 256, seed=7, scale=1 / 16))
+    d = lambda t: t.to(DEV)
+    vec = [d(g(256, seed=8, scale=0.1)), d(g(dffn, seed=9, scale=0.1)), d(g(256, seed=10, scale=0.1)), d(g(256, seed=11, scale=0.1)), d(g(256, seed=12, scale=0.1))]
+    ln2, ln3 = (d(g(256, seed=13) * 0.2 + 1), d(g(256, seed=14, scale=0.1))), (d(g(256, seed=15) * 0.2 + 1), d(g(256, seed=16, scale=0.1)))
+    w2, c2 = d(g(4, 256, seed=17, scale=0.1)), d(g(4, seed=18))
+    ref_in = torch.rand(M, 4, generator=torch.Generator().manual_seed(19)).to(DEV)
+    Wqkv, bqkv, qpos = pk(g(768, 256, seed=21, scale=1 / 16)), d(g(768, seed=22, scale=0.2)), g(M, 256, seed=23).to(DEV, dt)
+
+    def run(n):
+        return ops.decoder_tail(samp[:n].contiguous(), e1[:n].contiguous(), Wp, vec[0], ln2, W1, vec[1], W2, vec[2], ln3, B0, vec[3], B1, vec[4], w2, c2,
+                                ref_in[:n].contiguous(), packed=True, next_qkv=(Wqkv, bqkv, qpos[:n].contiguous()))
+    full = run(M)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(full[0].float()).all())
+    for n in (12300, 1000):
+        part = run(n)
+        torch.cuda.synchronize()
+        for a, b in zip(part, full):
+            assert torch.equal(a, b[:n]), n
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,n_oa", [(300 * 3 + 7, 288), (128, 288), (1000, 384), (513, 192), (200, 96)])
 def test_decoder_mid_one_launch_equals_separate(dt, M, n_oa):
     """moy_decoder_mid (out_proj + norm1, then sampling_offsets | attention_weights of e1 + query_pos, in one launch) vs the two
