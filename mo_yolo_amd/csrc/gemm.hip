@@ -378,7 +378,10 @@ __device__ __forceinline__ void gemm_epilogue_half(const GemmParams& p, const fl
 // stage ahead.  A compile-time choice: with both paths in one kernel hipcc's register allocation and
 // wait placement degrade for both (measured).
 template <typename T, int BM, int BN, int WGM, int WGN, bool LN, int KS, int NSET>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p) {
+// (second launch-bounds argument = waves per SIMD.  Lab build only: the eight-wave split-fp16 forms with one stage in flight ask for four,
+//  i.e. two blocks per CU -- measured slower, launch_cfg)
+__global__ __launch_bounds__(64 * WGM * WGN, (MOY_DIAG && std::is_same<T, f32x3_t>::value && WGM * WGN == 8 && NSET == 1 && !LN && BN == 128) ? 4 : 1)
+void gemm_kernel(const GemmParams p) {
   // X3 (MOY_F32X3): the tensors are fp32 and staged exactly as in the fp32 kernel (32 k per stage: 128 bytes of a row), but a stage's
   // LDS image is TWO fp16 panels of 64 bytes per row -- panel 0 the heads, panel 1 the scaled remainders of the same 32 k -- and a stage
   // is ONE k step of v_mfma_f32_16x16x32_f16, three products per output sub-tile (hi.hi into acc; hi.lo, lo.hi into accx)
@@ -604,33 +607,42 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(const GemmParams p
     const unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
     const unsigned char* Bs = As + A_BYTES;
     if constexpr (X3) {
-      u32x4 ah[MT], al[MT], wh[NT], wl[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int row = wm * TM + i * 16 + r;
-        ah[i] = *reinterpret_cast<const u32x4*>(As + row * 64 + swz(row, q) * 16);
-        al[i] = *reinterpret_cast<const u32x4*>(As + (BM + (row ^ SKEW)) * 64 + swz(row, q) * 16);
-      }
+      // Round 6: the row sub-tiles in GROUPS of two -- the fragments of a group (heads and remainders of two 16-row tiles: 16 registers)
+      // are read just before its twelve products instead of all MT tiles' up front (32 registers at MT = 4); with one stage in flight
+      // the 128 x 128 eight-wave form then fits 128 registers, i.e. two resident blocks per CU (measured slower than one block with two
+      // stages in flight: launch_cfg).  Inside a group the three sweeps keep two products into
+      // ONE accumulator four instructions apart (a dependent v_mfma_f32_16x16x32 chain issues every ~53 cycles instead of 16:
+      // DESIGN.md round 3, item 11).  Same products in the same k order per accumulator: the same bits.
+      constexpr int GI = MT >= 2 ? 2 : 1;
+      u32x4 wh[NT], wl[NT];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int row = wn * TN + j * 16 + r;
         wh[j] = *reinterpret_cast<const u32x4*>(Bs + row * 64 + swz(row, q) * 16);
         wl[j] = *reinterpret_cast<const u32x4*>(Bs + (BN + (row ^ SKEW)) * 64 + swz(row, q) * 16);
       }
-      // three sweeps over the sub-tiles, not three products per sub-tile: two MFMAs in a row into ONE accumulator wait for each other
-      // (a dependent v_mfma_f32_16x16x32 chain issues every ~53 cycles instead of 16: DESIGN.md round 3, item 11)
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int i0 = 0; i0 < MT; i0 += GI) {
+        u32x4 ah[GI], al[GI];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) mma_panel<f16_t>(acc[i][j], wh[j], ah[i]);
+        for (int g = 0; g < GI; ++g) {
+          const int row = wm * TM + (i0 + g) * 16 + r;
+          ah[g] = *reinterpret_cast<const u32x4*>(As + row * 64 + swz(row, q) * 16);
+          al[g] = *reinterpret_cast<const u32x4*>(As + (BM + (row ^ SKEW)) * 64 + swz(row, q) * 16);
+        }
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+        for (int g = 0; g < GI; ++g)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) mma_panel<f16_t>(accx[i][j], wh[j], al[i]);
+          for (int j = 0; j < NT; ++j) mma_panel<f16_t>(acc[i0 + g][j], wh[j], ah[g]);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+        for (int g = 0; g < GI; ++g)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) mma_panel<f16_t>(accx[i][j], wl[j], ah[i]);
+          for (int j = 0; j < NT; ++j) mma_panel<f16_t>(accx[i0 + g][j], wh[j], al[g]);
+#pragma unroll
+        for (int g = 0; g < GI; ++g)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) mma_panel<f16_t>(accx[i0 + g][j], wl[j], ah[g]);
+      }
       return;
     }
 #pragma unroll
@@ -751,6 +763,15 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
   p.nblocks = tiles_m * p.tiles_n;
   p.fd_tiles_n = make_fastdiv(p.tiles_n);
   constexpr int bk = 4 * DT<T>::KPB * PANELS;
+  // round 6, MEASURED AND LEFT OFF: the eight-wave split-fp16 forms with ONE stage in flight fit 128 registers (the stage loop reads its
+  // fragments group by group) and run two blocks per CU -- 4.69-4.70 k frames/s against 4.90-4.92 k for one block with two stages in
+  // flight (same device, interleaved; four scratch reloads of loop-invariant addresses per stage remain).  Lab knob MOY_X3_NSET=1.
+#if MOY_DIAG
+  if constexpr (std::is_same<T, f32x3_t>::value && WGM * WGN == 8 && !LN) {
+    static const int x3nset = knob("MOY_X3_NSET", 2);
+    if (x3nset == 1) return launch_inst<T, BM, BN, WGM, WGN, LN, KS, 1>(p, st);
+  }
+#endif
   // prefetch distance 2 pays from three k-stages on and for tiles at least 64 columns wide (measured)
   if (BN >= 64 && p.Kpad / bk > 2) return launch_inst<T, BM, BN, WGM, WGN, LN, KS, 2>(p, st);
   return launch_inst<T, BM, BN, WGM, WGN, LN, KS, 1>(p, st);
