@@ -679,6 +679,37 @@ void gemm_kernel(const GemmParams p) {
       if (kt + 1 < nk) store_stage(buf ^ 1, S0{});
       __syncthreads();
     }
+  } else if constexpr (NSET >= 3) {
+    // Round 6 (lab build: measured slower, launch_cfg): NSET stages of global loads in flight (NSET even: LDS buffer of stage s is s & 1,
+    // register set s % NSET).
+    static_assert(NSET % 2 == 0, "stage s lives in LDS buffer s & 1 and in register set s % NSET");
+    auto for_sets = [&](auto&& f) { [&]<int... U>(std::integer_sequence<int, U...>) { (f(std::integral_constant<int, U>{}), ...); }(std::make_integer_sequence<int, NSET>{}); };
+    for_sets([&](auto uc) { constexpr int u = decltype(uc)::value; if (u < nk) load_stage(u, uc); });
+    store_stage(0, S0{});
+    __syncthreads();
+    int kt = 0;
+    // steady state: every prefetch of the body is a real stage (kt + u + NSET < nk for every u), no branch around a load
+    for (; kt + 2 * NSET <= nk; kt += NSET) {
+      for_sets([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        load_stage(kt + u + NSET, uc);                 // set u was stored to LDS as stage kt + u
+        compute_stage(u & 1);
+        store_stage((u + 1) & 1, std::integral_constant<int, (u + 1) % NSET>{});
+        __syncthreads();
+      });
+    }
+    // tail: fewer than 2 NSET stages left, the same body with every step guarded (wave-uniform conditions)
+    for (; kt < nk; kt += NSET) {
+      for_sets([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        if (kt + u < nk) {
+          if (kt + u + NSET < nk) load_stage(kt + u + NSET, uc);
+          compute_stage(u & 1);
+          if (kt + u + 1 < nk) store_stage((u + 1) & 1, std::integral_constant<int, (u + 1) % NSET>{});
+          __syncthreads();
+        }
+      });
+    }
   } else {
     load_stage(0, S0{});
     if (nk > 1) load_stage(1, S1{});
@@ -763,13 +794,17 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
   p.nblocks = tiles_m * p.tiles_n;
   p.fd_tiles_n = make_fastdiv(p.tiles_n);
   constexpr int bk = 4 * DT<T>::KPB * PANELS;
-  // round 6, MEASURED AND LEFT OFF: the eight-wave split-fp16 forms with ONE stage in flight fit 128 registers (the stage loop reads its
-  // fragments group by group) and run two blocks per CU -- 4.69-4.70 k frames/s against 4.90-4.92 k for one block with two stages in
-  // flight (same device, interleaved; four scratch reloads of loop-invariant addresses per stage remain).  Lab knob MOY_X3_NSET=1.
 #if MOY_DIAG
   if constexpr (std::is_same<T, f32x3_t>::value && WGM * WGN == 8 && !LN) {
+    // round 6, both MEASURED SLOWER than two stages in flight on one resident block (same device, interleaved, whole f32x3 bench):
+    //   MOY_X3_NSET=1: one stage in flight, 128 registers, TWO blocks per CU            4.69-4.70 k against 4.90-4.92 k frames/s
+    //   MOY_X3_NSET=4: four stages in flight (198 / 253 registers)                       4.61-4.62 k against 4.92-4.93 k
+    // (per launch: deep-K convolutions 0.92-0.97 x, K = 288 / 576 forms 1.3-1.4 x) -- the split kernel's stage is bound neither by
+    // occupancy nor by the global round trip; what is left is its LDS path (8-byte staging stores of the split halves, 12 fragment
+    // reads and one barrier per 24 products)
     static const int x3nset = knob("MOY_X3_NSET", 2);
     if (x3nset == 1) return launch_inst<T, BM, BN, WGM, WGN, LN, KS, 1>(p, st);
+    if (x3nset == 4 && p.Kpad / bk > 4) return launch_inst<T, BM, BN, WGM, WGN, LN, KS, 4>(p, st);
   }
 #endif
   // prefetch distance 2 pays from three k-stages on and for tiles at least 64 columns wide (measured)
