@@ -59,7 +59,9 @@ constexpr int TAIL_LDS = tail_lds(TAIL_BM);
 // BM_ (round 6): rows of a block.  128 at bench scale; at small M (a few frames per step: the small-batch leg) the chain of a block --
 // eleven dependent products, each behind 128 KB of weights -- is the kernel's whole duration, and 10 blocks of 128 rows leave 246
 // compute units idle: 32-row blocks quarter the matrix work of a block's chain (every row's arithmetic is independent of the block height:
-// the same bits).
+// the same bits).  What a small block's chain then costs is its WEIGHT STREAM: 1.8 MB per block through one CU's 64 B/clk, fourteen
+// dependent products at ~2.6 us each (1 200 rows: 36-39 us).  Measured and dropped (round 6): a second weight set in registers, the next
+// product's slice requested a whole product ahead -- 43 us: the request is as long as two products, one product of distance hides none of it.
 template <typename T, int ABL = 0, int BM_ = TAIL_BM>       // ABL 1: timing-only build that keeps the FIRST weight chunk for every product (MOY_TAIL_ABL=1; results garbage)
                                          // ABL 2: s_memtime stamps of wave 0 per phase, written over the head of `out` (MOY_TAIL_ABL=2; tools/probes/tail_diag.py)
 __global__ __launch_bounds__(64 * TAIL_NW) void decoder_tail_kernel(const moy_decoder_tail_args p) {

@@ -717,7 +717,11 @@ int gemm_wreg_try(const moy_gemm_args* a, hipStream_t st) {
     if (rows * a->ldc * 2 > 0x7fffffffLL) return MOY_ENOSYS;
     if (a->plane_cols && !valueform) return MOY_ENOSYS;
   }
-  if (a->M < 65536) return MOY_ENOSYS;     // persistent row-tile walk: needs many tiles per block
+  // persistent row-tile walk: needs many tiles per block.  The 32-columns-per-wave forms (1x1 convs) from 65536 rows; round 6: the value
+  // form (8 waves x 64 columns, N >= 1024: six or more column groups share every activation tile) and the score form from 8192 rows --
+  // at a few frames per step (the small-batch leg) they are the two longest launches of the plan and the tiled kernel runs them at
+  // half this kernel's rate (value projection of 4 frames: 75 us tiled).  Bit-identical to the tiled kernel either way (tests).
+  if (a->M < (((valueform && a->N >= 1024) || score) ? 8192 : 65536)) return MOY_ENOSYS;
   if ((a->lda % 8) || !aligned16(a->A) || !aligned16(a->W)) return MOY_ENOSYS;
   if (!score && ((a->ldc % 8) || !aligned16(a->C))) return MOY_ENOSYS;
   if (a->plane_cols && a->plane_cols != 32 && (a->plane_cols % 64)) return MOY_ENOSYS;
