@@ -89,6 +89,9 @@ def parse(argv=None):
     ap.add_argument("--latency", action="store_true",
                     help="small-batch leg (C5 as BASELINE.json words it: one hipGraph replay = ONE frame of each of --batch live sequences): every step is "
                          "synchronised, the line carries the per-step latency distribution; MOTR/benchmark.py:37-68 times exactly this shape")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child passes that measure the dominant kernel's HBM traffic in this run (roofline.traffic then "
+                         "comes from the committed measurement under profiles/)")
     ap.add_argument("--no-selfcheck", action="store_true", help="skip the determinism / value-planes self-check after the timed region")
     ap.add_argument("--full-out", default=None, help="side file with the full record (default: gpurun_out/bench_full.json if that directory "
                                                       "exists, else bench_full.json beside bench.py)")
@@ -305,6 +308,50 @@ def cpu_baseline(cfg, arch, sd, n_frames, engine_check=None):
            "sample": f"{n_frames} frames ({t_num + t_state:.1f} s of CPU work; best of a scan over 16-128 threads x 1 | {BATCHED} frames per call: "
                      f"{cores} threads, {bs} per call) of the same stream, fp32 eager torch-CPU oracle incl. the host state machine"}
     return out, parity
+
+
+def live_traffic(kernel_substr, bench_args, out_dir, budget_s=170.0):
+    """HBM bytes per launch of one kernel from PMC counters collected IN THIS RUN (`roofline.traffic` used to be a committed
+    constant): two child runs of this script under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (SEPARATE passes, and
+    --kernel-trace the only trace domain beside them: MI355X_MICROARCH.md, HBM section) on one sub-batch engine, one stream, eager launches;
+    bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- the guide's gfx950 correction (FETCH_SIZE counts 64 bytes per 128-byte request of a wide
+    read; tools/traffic_summary.py).  The children are fresh processes (rocprofv3 -> python3 bench.py: no exec after GPU init).  Returns
+    (bytes or None, source text); any failure or time-out returns None and the caller keeps the committed constant."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    rp = shutil.which("rocprofv3")
+    if rp is None:
+        return None, "rocprofv3 not on PATH"
+    t_end = time.monotonic() + budget_s
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(out_dir, f"live_pmc_{ctr.lower()}")
+        shutil.rmtree(d, ignore_errors=True)
+        left = t_end - time.monotonic()
+        if left < 20:
+            return None, "time budget of the live PMC passes used up"
+        cmd = [rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), *bench_args]
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=left)
+        except subprocess.TimeoutExpired:
+            return None, f"the {ctr} pass timed out"
+        if r.returncode != 0:
+            return None, f"the {ctr} pass failed (rc {r.returncode})"
+        got = []
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if row.get("Counter_Name") == ctr and kernel_substr in row.get("Kernel_Name", ""):
+                    got.append(float(row["Counter_Value"]))
+        shutil.rmtree(d, ignore_errors=True)
+        if not got:
+            return None, f"no {ctr} rows for {kernel_substr}"
+        vals[ctr] = (sum(got) / len(got), len(got))
+    by = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
+    return by, (f"PMC counters of THIS run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate child passes, {kernel_substr}, {vals['FETCH_SIZE'][1]} dispatches, "
+                f"(2*FETCH_SIZE + WRITE_SIZE)*1024, fetch {vals['FETCH_SIZE'][0]:.0f} KB raw, write {vals['WRITE_SIZE'][0]:.0f} KB")
 
 
 def copy_peak_gbs(dev):
@@ -739,6 +786,24 @@ def main(argv=None):
                 roof["runner_up"] = {k: ru[k] for k in ("kernel", "calls_per_pass", "avg_ms", "total_ms_per_pass", "bound", "achieved", "frac", "traffic", "traffic_frac")}
             longest = max(range(nL), key=lambda i: per[i])
             roof["longest_single_launch"] = {"kernel": eng.meta[longest]["name"], "ms": round(per[longest], 4)}
+            # `traffic` of the dominant kernel from counters of THIS run (two child passes, ~1 min; the committed constant stays as the fallback)
+            sym = next((v for k, v in (("msda_raw0", "msda_raw_mfma_kernel"), ("stem+conv1", "stem_l1_kernel"), ("c2f fused", "c2f_fused_kernel"))
+                        if ranked[0].startswith(k)), None)
+            under_profiler = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+            if (sym and world == 1 and not a.no_live_traffic and not under_profiler and not a.temporal and not a.predictor and not a.from_host and not a.resize_from
+                    and not a.latency and dtype_name in ("bf16", "f16") and a.config in ("c2", "c5")):
+                log(f"live PMC passes: HBM traffic of {sym} (two rocprofv3 child runs)")
+                child = ["--batch", str(eng.B), "--streams", "1", "--no-graph", "--no-cpu-baseline", "--no-parity", "--no-launch-table", "--no-selfcheck",
+                         "--no-live-traffic", "--steps", "2", "--warmup", "1", "--dtype", dtype_name, "--full-out", os.path.join(os.path.dirname(full_path(a)), "bench_full_live_pmc_child.json")]
+                if a.plan:
+                    child += ["--plan", a.plan]
+                by_live, src_live = live_traffic(sym, child, os.path.dirname(full_path(a)))
+                if by_live:
+                    roof["traffic"] = by_live
+                    roof["traffic_frac"] = round(by_live / (roof["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    roof["traffic_source"] = src_live
+                else:
+                    roof["traffic_live_error"] = src_live
             if ranked[0].startswith("stem"):
                 roof["note"] = ("fused preprocess + stem + conv1: bound by vector-instruction issue (SiLU at 28 cycles per value, uint8 fragment build), "
                                 "neither the HBM nor the matrix roof is near")
@@ -1043,6 +1108,10 @@ def main(argv=None):
         gc.collect()
         torch.cuda.empty_cache()
         leg_list = (("c4_bf16", ["--config", "c4"], 20), ("c5_f16", ["--config", "c5"], 20),
+                    # C5 as BASELINE.json words it -- a hipGraph-captured PER-FRAME step over 4 live sequences -- and the carried-query mode at
+                    # 4 sequences: one replay = one frame of each sequence, device synchronised after every step
+                    ("c5_f16_b4_latency", ["--config", "c5", "--batch", "4", "--streams", "1", "--latency"], 300),
+                    ("c2_bf16_temporal100_b4_latency", ["--temporal", "100", "--batch", "4", "--latency"], 300),
                     ("c2_bf16_temporal100", ["--temporal", "100", "--batch", "32"], 20),
                     ("c2_f32", ["--dtype", "f32"], 10),                  # the engine that meets "bit-exact ids" (fp32)
                     ("c2_f32x3", ["--dtype", "f32x3"], 10),              # ... and the same engine with split-fp16 matrix products
@@ -1055,19 +1124,20 @@ def main(argv=None):
         for name, flags, nsteps in leg_list:
             log(f"extra leg {name}")
             side = os.path.join(os.path.dirname(full_path(a)), f"bench_full_{name}.json")
-            cmd = [sys.executable, os.path.abspath(__file__), *flags, "--steps", str(nsteps), "--warmup", "2", "--no-cpu-baseline",
+            cmd = [sys.executable, os.path.abspath(__file__), *flags, "--steps", str(nsteps), "--warmup", "2", "--no-cpu-baseline", "--no-live-traffic",
                    "--full-out", side] + ([] if name in ("c2_f32", "c2_f32x3", "full_bf16") else ["--no-launch-table"]) \
-                  + (["--no-parity", "--no-selfcheck"] if "sustained" in name else [])
+                  + (["--no-parity", "--no-selfcheck"] if "sustained" in name else []) + (["--no-selfcheck"] if "latency" in name else [])
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
                 leg = {"leg": name, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "dtype": d["dtype"],
+                       "latency_ms": (d.get("config") or {}).get("latency_ms"), "launches_per_step": (d.get("config") or {}).get("launches_per_step"),
                        "parity_ok": (d.get("parity") or {}).get("ok"), "selfcheck_ok": (d.get("selfcheck") or {}).get("ok"), "rc": r.returncode,
                        "full": d.get("full")}
                 if d.get("roofline"):
                     leg["roofline_frac"] = d["roofline"].get("frac")
                 cname = "c4" if name.startswith("c4") else "c2"
-                if "temporal" not in name and not name.startswith("full"):    # SURVEY §8(d) figure: FPS x algorithmic bytes per frame / HBM peak
+                if "temporal" not in name and not name.startswith("full") and "latency" not in name:    # SURVEY §8(d) figure: FPS x algorithmic bytes per frame / HBM peak
                     leg["roofline_frac_survey_8d"] = round(d["value"] * ALG_BYTES_FRAME[cname] * (2 if d["dtype"] in ("f32", "f32x3") else 1) / (HBM_PEAK_GBS * 1e9), 4)
                 if name in ("c2_bf16_from_host", "c2_bf16_predictor", "c2_bf16_predictor_pinned_source", "c2_bf16_sustained_200_steps"):
                     leg["vs_resident_headline"] = round(d["value"] / fps, 4)

@@ -18,11 +18,14 @@ run_line() {   # name, args...
 }
 if [ "$stage" != "prof" ]; then
 run_line c2_bf16 --dump-launches $out/launches_c2_bf16.json &&
-run_line c2_f16 --dtype f16 --no-cpu-baseline --dump-launches $out/launches_c2_f16.json &&
+run_line c2_f16 --dtype f16 --no-cpu-baseline --no-live-traffic --dump-launches $out/launches_c2_f16.json &&
 run_line c4_bf16 --config c4 --no-cpu-baseline --dump-launches $out/launches_c4_bf16.json &&
-run_line c5_f16 --config c5 --no-cpu-baseline &&
+run_line c5_f16 --config c5 --no-cpu-baseline --no-live-traffic &&
 run_line c2_temporal100 --temporal 100 --batch 32 --no-cpu-baseline &&
-run_line c2_bf16_1stream --batch 288 --streams 1 --no-cpu-baseline &&
+run_line c2_bf16_1stream --batch 288 --streams 1 --no-cpu-baseline --no-live-traffic &&
+run_line c5_f16_b4_latency --config c5 --batch 4 --streams 1 --latency --steps 300 --warmup 30 --no-cpu-baseline --dump-launches $out/launches_c5_f16_b4_latency.json &&
+run_line c2_bf16_temporal100_b4_latency --temporal 100 --batch 4 --latency --steps 300 --warmup 30 --no-cpu-baseline &&
+run_line c2_bf16_b1_latency --config c2 --batch 1 --streams 1 --latency --steps 300 --warmup 30 --no-cpu-baseline --no-parity &&
 run_line c2_f32 --dtype f32 --no-cpu-baseline --dump-launches $out/launches_c2_f32.json &&
 run_line c2_f32x3 --dtype f32x3 --no-cpu-baseline --dump-launches $out/launches_c2_f32x3.json &&
 run_line full_bf16 --config full --no-cpu-baseline --dump-launches $out/launches_full_bf16.json || exit 1
@@ -31,7 +34,7 @@ fi
 echo "[profile_round] rocprofv3 kernel stats (default run, 2 streams)" &&
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_default -- python3 bench.py --no-cpu-baseline --no-parity --no-launch-table --no-selfcheck --steps 10 --warmup 2 > $out/trace_default.log 2>&1 &&
 echo "[profile_round] rocprofv3 kernel stats (288 frames, 1 stream)" &&
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_1stream -- python3 bench.py --batch 288 --streams 1 --no-cpu-baseline --no-parity --no-selfcheck --steps 10 --warmup 2 > $out/trace_1stream.log 2>&1 &&
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_1stream -- python3 bench.py --batch 288 --streams 1 --no-cpu-baseline --no-parity --no-selfcheck --no-live-traffic --steps 10 --warmup 2 > $out/trace_1stream.log 2>&1 &&
 echo "[profile_round] PMC FETCH_SIZE" &&
 timeout -k 10 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --batch 288 --streams 1 --no-graph --no-cpu-baseline --no-parity --no-launch-table --no-selfcheck --steps 2 --warmup 1 > $out/fetch.log 2>&1 &&
 echo "[profile_round] PMC WRITE_SIZE" &&
