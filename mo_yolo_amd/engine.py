@@ -580,6 +580,11 @@ class TrackEngine:
         # Round 4: input_proj (Conv1x1 + BN, NO activation: head.py:838-839) is a linear map between two linear consumers, so at bench
         # scale it is folded into them -- value projection and score pass read each level's own tensor with composed weights, the
         # projected features exist only for the nq selected tokens (`_fold_plan` says when; MOY_FOLD_PROJ=0 keeps the classic plan)
+        # (whether level 0 will be sampled raw is known before the fold is asked for: the value launches the library is asked about are then
+        #  the ones the plan makes -- planes of S - h0*w0 tokens per frame)
+        nl_, vmode_ = arch.nl, str(self.opt.value_planes)
+        self._p3raw_wanted = bool(vmode_ == "2" and self.opt.p3_raw and nl_ >= 2 and arch.head_ch[0] == 128 and min(self.shapes[0]) >= 2
+                                  and self.shapes[0][0] * self.shapes[0][1] * head_src[0][0].ld * self._esz <= 0x7fffffff)
         fold = self._fold_plan(head_src, valid[0, :, 0])
         self.fold_proj = fold is not None
         feats = None
@@ -608,8 +613,7 @@ class TrackEngine:
         # (the composed weights are the fold's); MOY_P3_RAW=0 keeps the planes of all levels.
         self.p3raw = None
         self.value_tokens = S                  # tokens per frame in the value planes
-        if (fold is not None and vmode == "2" and self.opt.p3_raw and nl >= 2 and arch.head_ch[0] == 128
-                and min(self.shapes[0]) >= 2 and self.shapes[0][0] * self.shapes[0][1] * head_src[0][0].ld * self._esz <= 0x7fffffff):
+        if fold is not None and self._p3raw_wanted:
             self.value_tokens = S - self.shapes[0][0] * self.shapes[0][1]
         if vmode == "2":
             # [layer][head][token][32]: a head's map is a dense [B*S, 32] matrix, so the two x-taps of a bilinear sample are
@@ -1246,13 +1250,14 @@ class TrackEngine:
             a = L.GemmArgs()
             a.A, a.lda, a.W, a.M, a.N, a.K, a.ksize, a.stride = v.ptr, v.ld, al, B * h_ * w_, arch.ndl * hd, arch.head_ch[li], 1, 1
             a.shift, a.C, a.ldc, a.dtype = al, al, dh, self.code
-            a.plane_cols, a.plane_stride, a.c_rows_per_batch, a.c_batch_stride = dh, B * S * dh, h_ * w_, S
+            Sv_ = S - self.shapes[0][0] * self.shapes[0][1] if self._p3raw_wanted else S       # tokens per frame in the planes the plan will make
+            a.plane_cols, a.plane_stride, a.c_rows_per_batch, a.c_batch_stride = dh, B * Sv_ * dh, h_ * w_, Sv_
             b = L.GemmArgs()
             b.A, b.lda, b.W, b.M, b.N, b.K, b.ksize, b.stride = v.ptr, v.ld, al, B * S, hd, arch.head_ch[li], 1, 1
             b.shift, b.ln_g, b.ln_b, b.dot_w, b.dot_b, b.dot_out, b.dot_n, b.dtype = al, al, al, al, al, al, arch.nc, self.code
             b.run_levels, b.run_period, b.run_a_period, b.run_a_off = 1, S, h_ * w_, off
             b.run_tok0[0], b.run_pitch[0], b.run_len[0], b.run_rows[0] = off + y0 * w_ + x0, w_, x1 - x0 + 1, y1 - y0 + 1
-            for q_ in (a, b):
+            for q_ in ((b,) if (li == 0 and self._p3raw_wanted) else (a, b)):     # (level 0 sampled raw: its value launch is never made)
                 k = C.c_int(0)
                 if self.lib.moy_gemm_query(C.byref(q_), C.byref(k)) != 0 or k.value != L.KERNEL_WREG:
                     return None
