@@ -807,6 +807,8 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
     if (x3nset == 4 && p.Kpad / bk > 4) return launch_inst<T, BM, BN, WGM, WGN, LN, KS, 4>(p, st);
   }
 #endif
+  // (round 6, measured and dropped: four stages in flight for the SMALL launches of the 16-bit forms -- at most one block per compute unit,
+  //  the small-batch leg -- 3.33-3.34 k against 3.37 k frames/s at four frames per step: their k loop is not paced by the global round trip)
   // prefetch distance 2 pays from three k-stages on and for tiles at least 64 columns wide (measured)
   if (BN >= 64 && p.Kpad / bk > 2) return launch_inst<T, BM, BN, WGM, WGN, LN, KS, 2>(p, st);
   return launch_inst<T, BM, BN, WGM, WGN, LN, KS, 1>(p, st);
