@@ -1518,6 +1518,9 @@ int conv_ws_try(const moy_gemm_args* a, hipStream_t st) {
   const int64_t ldmax = a->lda > a->ldc ? (a->lda > a->ldr ? a->lda : a->ldr) : (a->ldc > a->ldr ? a->ldc : a->ldr);
   if ((int64_t)a->Hin * a->Win * ldmax * 2 > 0x3fffffffLL) return MOY_ENOSYS;   // per-image descriptors, 32-bit lane offsets
   const int TH = C == 128 ? 8 : 16;
+  // (utilisation of the PLAIN tiling on purpose.  Round 6 measured the 34-pixel-wide level -- 0.56 of every tile used, 0.76 with the tile
+  //  columns cut from a virtual row of five images -- on this kernel with the grouped tiling: 0.080 / 0.092 ms (plain / shortcut form)
+  //  against the tiled kernel's 0.080 / 0.079 at 288 frames: no gain, the launch stays with the tiled kernel)
   const long tiles = (long)a->B * ((a->Hin + TH - 1) / TH) * ((a->Win + 15) / 16);
   const double util = (double)a->Hin * a->Win * a->B / (double)(tiles * TH * 16);
   if (mode == 1 && (tiles < 2 * cws_num_cus() || util < 0.7)) return MOY_ENOSYS;
