@@ -419,3 +419,22 @@ def test_valid_token_rectangles_of_the_reference_anchor_mask():
     assert valid_rectangles(holed, shapes) is None
     assert valid_rectangles(torch.zeros(13566, dtype=torch.bool), shapes) == [None, None, None]
 
+
+
+def test_plan_options_are_explicit_and_the_environment_is_a_lab_input_only():
+    """Round 6: the plan's A/B switches are fields of PlanOptions -- defaults = the shipped plan, `parse` for
+    `bench.py --plan`, `from_env` (the rounds 1-5 variable names) for the lab only; unknown keys are refused."""
+    from mo_yolo_amd.engine import PlanOptions
+    d = PlanOptions()
+    assert d.fold_proj and d.p3_raw and d.dec_tail and d.dec_mid and d.qkv_split == 1 and not d.qkv_fuse and d.qkv_fuse_small
+    assert not d.query_order and d.fork_value == 0 and d.fork_small_value == 0 and d.value_planes == 2
+    p = PlanOptions.parse("p3_raw=0, qkv_split=2,query_order=1,fork_value=128")
+    assert (p.p3_raw, p.qkv_split, p.query_order, p.fork_value) == (False, 2, True, 128) and p.fold_proj
+    assert PlanOptions.parse("") == d and PlanOptions.parse(None) == d
+    with pytest.raises(ValueError):
+        PlanOptions.parse("no_such_switch=1")
+    e = PlanOptions.from_env({"MOY_FOLD_PROJ": "0", "MOY_QKV_FUSE": "1", "MOY_Q_ORDER": "1", "UNRELATED": "x"})
+    assert (e.fold_proj, e.qkv_fuse, e.query_order) == (False, True, True) and e.p3_raw
+    assert PlanOptions.from_env({}) == d
+    with pytest.raises(Exception):
+        d.fold_proj = False                      # frozen: an engine's options cannot change under it
