@@ -927,8 +927,11 @@ def main(argv=None):
             #                                       box      hs     score   births / active        (profiles/r04_f_bench_*.json)
             measured = {("c2", "bf16"): (4.08e-3, 0.673, 0.147, 0.0744), ("c2", "f16"): (1.07e-3, 0.115, 0.0256, 0.0153),
                         ("c4", "bf16"): (4.89e-3, 0.638, 0.0650, 0.0293)}.get((cfg_name, dtype_name))
-            if small:
-                measured = None          # (the committed windows are those of the bench-scale plan; a small-batch engine runs the classic plan)
+            if small or NP != 32 or (B // max(1, seq_per_gpu)) < P0 + NP:
+                # the committed windows are frames 8..39 of ONE sequence through the bench-scale plan: a small-batch engine runs the classic
+                # plan, a --batch below 40 sees a shorter window (a birth-flip RATIO over 8 frames is not the one over 32) and a batch of
+                # several sequences (C5, 8 frames of each) a window of other frames
+                measured = None
             if measured is not None:
                 rb = tuple(round(1.5 * v, 5) for v in measured)
                 parity["regression"] = {"kind": "1.5 x this window's committed measurement (profiles/r04_f_bench_*.json)",

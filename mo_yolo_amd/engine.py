@@ -37,6 +37,7 @@ class PlanOptions:
     fuse_c2f: bool = True         # the first C2f block as one launch
     value_planes: int = 2         # 2: head planes [layer][head][token][32]; 1: one [B*S, 256] matrix per layer; 0: one [B*S, 6*256] matrix
     fold_proj: bool = True        # input_proj folded into value projection / score pass (where the library has the launches)
+    fold_min_rows: int = 8192     # 16-bit engines fold from this many rows on the smallest level (= where the library admits the value / score launches; round 6: was 65536)
     score_runs: bool = True       # score pass over the valid tokens only
     p3_raw: bool = True           # level 0 of the deformable attention gathered raw and projected after the bilinear sum
     query_order: bool = False     # the gather walks a frame's queries in Morton order of their reference points (round 6: L1 hit rate 72.9 ->
@@ -56,7 +57,7 @@ class PlanOptions:
     assume_wreg: bool = True      # the library's weight-stationary kernel may be planned for (False with a lab library run under MOY_GEMM_WREG=0)
 
     _ENV = dict(fuse_stem="MOY_FUSE_STEM", fuse_upsample="MOY_FUSE_UPSAMPLE", fuse_c2f="MOY_FUSE_C2F", value_planes="MOY_VALUE_PLANES",
-                fold_proj="MOY_FOLD_PROJ", score_runs="MOY_SCORE_RUNS", p3_raw="MOY_P3_RAW", query_order="MOY_Q_ORDER", mlp_head="MOY_MLP_HEAD",
+                fold_proj="MOY_FOLD_PROJ", fold_min_rows="MOY_FOLD_MIN_ROWS", score_runs="MOY_SCORE_RUNS", p3_raw="MOY_P3_RAW", query_order="MOY_Q_ORDER", mlp_head="MOY_MLP_HEAD",
                 dec_mid="MOY_DEC_MID", dec_tail="MOY_DEC_TAIL", qkv_split="MOY_QKV_SPLIT", qkv_fuse="MOY_QKV_FUSE", w_packed="MOY_W_PACKED",
                 post_1x1="MOY_POST_1X1", fork_value="MOY_FORK_VALUE", assume_wreg="MOY_GEMM_WREG", fork_small_value="MOY_FORK_SMALL",
                 qkv_fuse_small="MOY_QKV_FUSE_SMALL")
@@ -1206,8 +1207,8 @@ class TrackEngine:
 
     def _fold_plan(self, head_src, valid_host):
         """Conditions of the folded head (round 4) and its host-side constants, or None for the classic plan.  Folded when: a 16-bit engine
-        at a batch where every per-level launch takes the weight-stationary kernel (B * h*w >= 65536 on the smallest level: the
-        tiled kernel has neither the row runs nor the second row numbering), head-plane value layout, <= 4 classes (the fused narrow
+        at a batch where every per-level launch takes the weight-stationary kernel (B * h*w >= `fold_min_rows` = 8192 on the smallest
+        level -- 13 frames of 640x1088; the 16-bit tiled kernel has neither the row runs nor the second row numbering), head-plane value layout, <= 4 classes (the fused narrow
         head), level widths of 128 / 256 channels, a valid mask that is one rectangle per level."""
         arch, B, sd = self.arch, self.B, self.sd
         is32 = self.dtype == torch.float32
@@ -1220,7 +1221,9 @@ class TrackEngine:
         # 16-bit engines: every per-level launch must take the weight-stationary kernel (row runs, output row remap into head planes);
         # round 6, fp32 engines (exact and split-fp16): the TILED kernel has the row runs and the remap for fp32 tensors at any launch
         # size, so the fold holds at every batch -- what is asked below is only that a level's tensor fits one buffer descriptor
-        if not is32 and (not self.opt.assume_wreg or any(B * h_ * w_ < 65536 for h_, w_ in self.shapes)):
+        # (round 6: the library takes the value / score forms of the weight-stationary kernel from 8192 rows -- `fold_min_rows`; the query
+        #  below is what decides, this is only the cheap first look)
+        if not is32 and (not self.opt.assume_wreg or any(B * h_ * w_ < int(self.opt.fold_min_rows) for h_, w_ in self.shapes)):
             return None
         if is32 and any(B * h_ * w_ * v.ld * 4 > 0x7fffffff for (v, _), (h_, w_) in zip(head_src, self.shapes)):
             return None

@@ -218,16 +218,17 @@ def test_engine_bench_scale_kernel_paths_vs_small_batch():
             assert sf["box_max_err_matched"] < 2.0 * mb and sf["hs_max_err_matched"] < 2.0 * mh, (dt, sf)
 
 
+@pytest.mark.parametrize("B", [104, 16])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-def test_engine_folded_input_proj_plan_vs_classic_plan(dt, monkeypatch):
-    """Round 4: at bench scale (every pyramid level >= 65536 rows per launch: B >= 102 at the C2 shape) input_proj (Conv1x1 + BN, no
+def test_engine_folded_input_proj_plan_vs_classic_plan(dt, B, monkeypatch):
+    """Round 4: at bench scale (every pyramid level >= 65536 rows per launch: B >= 102 at the C2 shape; round 6: from 8192 rows, B >= 13,
+    `PlanOptions.fold_min_rows` -- 16 frames is the second case) input_proj (Conv1x1 + BN, no
     activation, head.py:838-839) is folded into its two linear consumers -- value projection and score pass read P3/P4/P5 directly
     with composed weights, the projected features exist for the nq selected tokens only.  Same function, one rounding fewer (the
     bf16 feature map is never formed), so the folded engine must sit at least as close to fp32 as the classic plan does, and the two
     16-bit plans must agree with each other as two noise realisations do (previous test's argument)."""
     from mo_yolo_amd.parity import engine_pair_stats
     cfg, arch, sd = fixture("c2")
-    B = 104
     fr = torch.from_numpy(frames_u8(cfg, 0, B)).to(DEV)
     classic = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt, options=PlanOptions(fold_proj=False))
     folded = TrackEngine(arch, sd, cfg["H"], cfg["W"], batch=B, dtype=dt)
