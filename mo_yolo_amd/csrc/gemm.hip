@@ -380,7 +380,8 @@ __device__ __forceinline__ void gemm_epilogue_half(const GemmParams& p, const fl
 template <typename T, int BM, int BN, int WGM, int WGN, bool LN, int KS, int NSET>
 // (second launch-bounds argument = waves per SIMD.  Lab build only: the eight-wave split-fp16 forms with one stage in flight ask for four,
 //  i.e. two blocks per CU -- measured slower, launch_cfg)
-__global__ __launch_bounds__(64 * WGM * WGN, (MOY_DIAG && std::is_same<T, f32x3_t>::value && WGM * WGN == 8 && NSET == 1 && !LN && BN == 128) ? 4 : 1)
+__global__ __launch_bounds__(64 * WGM * WGN, (MOY_DIAG && std::is_same<T, f32x3_t>::value && WGM * WGN == 8 && NSET == 1 && !LN && BN == 128 && BM == 128) ? 4
+                                             : ((std::is_same<T, f32x3_t>::value && WGM * WGN == 4 && (BM / WGM) * (BN / WGN) == 4096) ? 2 : 1))   // (two four-wave blocks of 64 x 64 wave tiles per CU: <= 256 registers)
 void gemm_kernel(const GemmParams p) {
   // X3 (MOY_F32X3): the tensors are fp32 and staged exactly as in the fp32 kernel (32 k per stage: 128 bytes of a row), but a stage's
   // LDS image is TWO fp16 panels of 64 bytes per row -- panel 0 the heads, panel 1 the scaled remainders of the same 32 k -- and a stage
@@ -667,6 +668,10 @@ void gemm_kernel(const GemmParams p) {
 
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, NSET - 1>;
+  // (round 6, measured and dropped: hipcc sinks the stage's global loads below its products and hoists the LDS store of the other register
+  //  set above them, so the loads fly for half a stage on average, not two; pinning the source order with sched_barrier -- loads first,
+  //  optionally the store last -- was SLOWER: f32x3 4.85 -> 4.63 / 4.75 k, exact fp32 3.17 -> 3.15 / 3.08 k frames/s.  The k loop of the
+  //  fp32-tensor forms is paced by the LDS pipe, not by the global round trip: dispatch_tile, the 256-row tiles.)
   const int nk = p.Kpad / BK;
   if constexpr (NSET == 1) {
     load_stage(0, S0{});
@@ -794,6 +799,9 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
   p.nblocks = tiles_m * p.tiles_n;
   p.fd_tiles_n = make_fastdiv(p.tiles_n);
   constexpr int bk = 4 * DT<T>::KPB * PANELS;
+  // (the 256 x 128 split form: 128 accumulator registers -- a second stage in flight does not fit 256: 152-200 bytes of scratch)
+  if constexpr (std::is_same<T, f32x3_t>::value && (BM / WGM) * (BN / WGN) == 4096) return launch_inst<T, BM, BN, WGM, WGN, LN, KS, 1>(p, st);
+  else {
 #if MOY_DIAG
   if constexpr (std::is_same<T, f32x3_t>::value && WGM * WGN == 8 && !LN) {
     // round 6, both MEASURED SLOWER than two stages in flight on one resident block (same device, interleaved, whole f32x3 bench):
@@ -812,6 +820,7 @@ static int launch_cfg(GemmParams& p, hipStream_t st) {
   // prefetch distance 2 pays from three k-stages on and for tiles at least 64 columns wide (measured)
   if (BN >= 64 && p.Kpad / bk > 2) return launch_inst<T, BM, BN, WGM, WGN, LN, KS, 2>(p, st);
   return launch_inst<T, BM, BN, WGM, WGN, LN, KS, 1>(p, st);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1099,6 +1108,25 @@ static int dispatch_tile(GemmParams& p, bool ln, hipStream_t st) {
   if (force == 3) return launch_cfg<T, 128, 64, 4, 2, false, KS>(p, st);
   if (force == 4) return launch_cfg<T, 64, 64, 2, 2, false, KS>(p, st);
 #endif
+  if constexpr (std::is_same<T, f32x3_t>::value) {
+    // Round 6: the split form is paced by its LDS path (counters, profiles/r06_c_x3_gemm_counters.txt: at 128 x 128 on eight waves the
+    // fragment reads + staging stores of a stage are 128 KB = 1000 cycles of the 128 B/clk pipe against 768 cycles of matrix work per
+    // SIMD, at 128 x 64 88 KB against 384; three products per fragment pair do not help while a wave's register tile is 64 x 32 or
+    // 32 x 32).  Wave tiles of 64 x 64 (128 accumulator registers, one stage in flight -- a second register set spills), same device,
+    // interleaved, tools/bench_gemm.py BG_DT=f32x3 at 96 frames, times relative to the round-5 choice:
+    //   N > 64, 1x1 and 3x3 stride 2:  128 x 128 on FOUR waves, two blocks per CU      0.86 / 0.90-0.93
+    //   N > 64, 3x3 stride 1:          256 x 128 on eight waves                         0.95-1.0 (four waves: 1.03)
+    //   N = 64, 1x1 and 3x3 stride 2:  256 x 64 on four waves (each all 64 columns)     0.91 / 0.96-0.98
+    //   N = 64, 3x3 stride 1:          stays 128 x 64 on eight waves (three resident blocks; 256 x 64 on four or eight waves 1.04-1.18,
+    //                                  128 x 64 on four waves 1.0-1.04)
+    static const int x3tile = knob("MOY_X3_TILE", 1);
+    const long rows256 = (p.M + 255) / 256;
+    if (x3tile && p.N > 64 && rows256 * ((p.N + 127) / 128) >= 256) {
+      if (KS == 3 && p.stride == 1) return launch_cfg<T, 256, 128, 4, 2, false, KS>(p, st);
+      return launch_cfg<T, 128, 128, 2, 2, false, KS>(p, st);
+    }
+    if (x3tile && p.N > 32 && p.N <= 64 && rows256 >= 256 && !(KS == 3 && p.stride == 1)) return launch_cfg<T, 256, 64, 4, 1, false, KS>(p, st);
+  }
   // Tile choice (measured, tools/bench_gemm.py): 8-wave blocks for the large tiles; fill >= ~2 blocks
   // per CU when the problem allows it, keep tiles large otherwise.
   const long big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);

@@ -55,7 +55,8 @@ def test_gemm_linear_variants(dt, M, N, K):
     assert torch.allclose(y.cpu(), ref, atol=tol(dt, 2e-5, 2e-2), rtol=1e-5)
 
 
-@pytest.mark.parametrize("M,N,K,scale", [(300, 256, 256, 1.0), (1000, 64, 96, 30.0), (129, 1024, 256, 1e-3), (4097, 32, 384, 1.0), (70000, 256, 128, 1.0)])
+@pytest.mark.parametrize("M,N,K,scale", [(300, 256, 256, 1.0), (1000, 64, 96, 30.0), (129, 1024, 256, 1e-3), (4097, 32, 384, 1.0), (70000, 256, 128, 1.0),
+                                         (66001, 64, 96, 1.0), (65537 + 77, 136, 288, 3.0)])      # (round 6: the 256 x 64 / 256 x 128 tiles, ragged)
 def test_gemm_split_f16_products_carry_fp32_accuracy(M, N, K, scale):
     """MOY_F32X3 (round 5): fp32 tensors, every product on the 16-bit matrix cores as hi.hi + (hi.lo + lo.hi) * 2^-11 with
     hi = fp16(x), lo = fp16((x - hi) * 2^11).  Against a float64 product of the same fp32 operands: the error must be of the order of
@@ -85,7 +86,8 @@ def test_gemm_split_f16_products_carry_fp32_accuracy(M, N, K, scale):
         ops.gemm(xd.to(torch.bfloat16), ops.pad_weight(w.to(DEV), torch.bfloat16), N, K, split_f16=True)      # a mode of fp32 tensors only
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,s", [(2, 13, 21, 16, 32, 1), (1, 38, 68, 64, 64, 2), (3, 8, 12, 32, 24, 1)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,s", [(2, 13, 21, 16, 32, 1), (1, 38, 68, 64, 64, 2), (3, 8, 12, 32, 24, 1),
+                                              (2, 190, 190, 64, 64, 1), (1, 261, 259, 16, 128, 1), (2, 366, 370, 32, 64, 2)])   # (the 256-row tiles)
 def test_gemm_split_f16_conv3x3(B, H, W, Cin, Cout, s):
     """The implicit-GEMM 3x3 convolution in split precision against float64 (conv.py:36-38: conv + BN + SiLU)."""
     x, w = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=1 / math.sqrt(9 * Cin))

@@ -12,7 +12,11 @@ from mo_yolo_amd import _lib as L
 from mo_yolo_amd import ops
 
 B = int(os.environ.get("BG_B", 32))
-dt = torch.bfloat16
+# BG_DT: bf16 (default) | f16 | f32 | f32x3 (fp32 tensors, pre-split fp16 weights: the MOY_F32X3 form of the tiled kernel)
+DT_NAME = os.environ.get("BG_DT", "bf16")
+X3 = DT_NAME == "f32x3"
+dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32x3": torch.float32}[DT_NAME]
+ESZ = 4 if dt == torch.float32 else 2
 dev = "cuda"
 # (name, ksize, stride, Hin, Win, Cin, Cout, ln)
 SHAPES = [
@@ -48,7 +52,8 @@ def make(s):
     name, ks, st, H, W, Cin, Cout, ln = s
     x = (torch.rand(B * H * W, Cin, device=dev) - 0.5).to(dt)
     K = ks * ks * Cin
-    w = ops.pad_weight((torch.rand(Cout, K, device=dev) - 0.5) / K ** 0.5, dt)
+    w0 = (torch.rand(Cout, K, device=dev) - 0.5) / K ** 0.5
+    w = ops.split_weight(w0) if X3 else ops.pad_weight(w0, dt)
     sc = torch.rand(Cout, device=dev) + 0.5
     sh = torch.rand(Cout, device=dev) - 0.5
     if ks == 3:
@@ -63,8 +68,10 @@ def make(s):
               act=(L.ACT_SILU if conv else L.ACT_NONE))
     if ln:
         kw.update(ln=(sc, sh), act=L.ACT_NONE)
-    alg = (x.numel() + w.numel() + out.numel()) * 2
+    alg = (x.numel() + w.numel() + out.numel()) * ESZ
     flops = 2 * M * Cout * K
+    if X3:
+        kw["split_f16"] = True
     f = lambda: ops.gemm(x, w, Cout, K, **kw)
     f.out = out
     return f, alg, flops, M
