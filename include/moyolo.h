@@ -186,6 +186,14 @@ int moy_stem_conv(const void* in, int in_fmt, int B, int H, int W, const float* 
 int moy_stem_conv_mfma(const void* in_u8, int B, int H, int W, const void* wpad, const float* scale, const float* shift,
                        int Cout, void* out, int64_t ldc, void* stream);
 
+/* Round 6: the stem of the split-fp16 engine (MOY_F32X3): uint8 BGR input, fp32 output.  The pixel bytes are exact fp16 values, the weights
+ * arrive split -- wsplit: fp16 [2][Cout][32], plane 0 = fp16(w), plane 1 = fp16((w - plane 0) * 2^11), in moy_stem_l1_fused's k order (below;
+ * mo_yolo_amd.ops.stem_weights_x3) -- two matrix products per output tile; y = SiLU((sum) * scale / 255 + shift) in fp32
+ * (predictor.py:117-134 + conv.py:36-38; the exact fp32 engine keeps moy_stem_conv).  Cout in {16, 32, 64}; out 16-byte aligned, ldc % 4 == 0;
+ * MOY_ENOSYS for W % 4 != 0 or B*H*W*3 >= 4 GiB (the caller keeps moy_stem_conv). */
+int moy_stem_conv_x3(const void* in_u8, int B, int H, int W, const void* wsplit, const float* scale, const float* shift,
+                     int Cout, void* out, int64_t ldc, void* stream);
+
 /* Stem AND the first down-sampling conv in one launch (16-bit engines): uint8 BGR frames -> layer 0 (3x3 s2, 3 -> 32) -> layer 1
  * (3x3 s2, 32 -> 64), each Conv + BN + SiLU (predictor.py:117-134; yolo_track.yaml:17-18; conv.py:36-38).  The 32-channel
  * half-resolution tensor never reaches HBM (csrc/stem_l1.hip).

@@ -98,6 +98,7 @@ SIGNATURES = {
     "moy_gemm_query": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(C.c_int)]),
     "moy_stem_conv": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, i64, C.c_int, vp]),
     "moy_stem_conv_mfma": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, i64, vp]),
+    "moy_stem_conv_x3": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, i64, vp]),
     "moy_stem_l1_fused": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64, C.c_int, vp]),
     "moy_c2f_fused": (C.c_int, [C.POINTER(C2fArgs), vp]),
     "moy_sppf_pool": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, i64, C.c_int, vp]),

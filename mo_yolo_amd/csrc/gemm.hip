@@ -1126,6 +1126,9 @@ static int dispatch_tile(GemmParams& p, bool ln, hipStream_t st) {
       return launch_cfg<T, 128, 128, 2, 2, false, KS>(p, st);
     }
     if (x3tile && p.N > 32 && p.N <= 64 && rows256 >= 256 && !(KS == 3 && p.stride == 1)) return launch_cfg<T, 256, 64, 4, 1, false, KS>(p, st);
+#if MOY_DIAG
+    if (x3tile == 7 && p.N <= 32 && rows256 >= 256) return launch_cfg<T, 256, 32, 4, 1, false, KS>(p, st);     // 64 x 32 per wave
+#endif
   }
   // Tile choice (measured, tools/bench_gemm.py): 8-wave blocks for the large tiles; fill >= ~2 blocks
   // per CU when the problem allows it, keep tiles large otherwise.

@@ -181,6 +181,138 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const uint8_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round 6: the stem of the split-fp16 engine (MOY_F32X3): fp32 output, uint8 input.  A pixel byte IS an fp16 value (0..255, exact), so
+// only the weights need the split -- w = hi + lo * 2^-11, both fp16, [2][COUT][32] -- and a 16 x 16 output sub-tile is TWO products
+// (bytes . hi into acc, bytes . lo into accx); y = SiLU((acc + accx * 2^-11) * (scale / 255) + shift) in fp32, i.e. the fp32 stem's
+// function with the weights carried to 22 bits and the division by 255 applied after the sum instead of per pixel.  Same window /
+// tile / channel assignment as stem_mfma_kernel; 16-byte stores of four consecutive channels.  Replaces the scalar-FMA fp32 stem
+// (0.92 ms at 96 frames, fp32-FMA bound) in the f32x3 plan only -- the exact fp32 engine keeps u8 / 255 in fp32 as the reference has it.
+constexpr int STEM_X3_TPB = 8;      // output tiles a block walks; the input windows of ALL of them are requested up front (4 dwords per thread each)
+
+template <int COUT>
+__global__ __launch_bounds__(256) void stem_x3_kernel(const uint8_t* __restrict__ in, int B, int H, int W,
+                                                      const f16_t* __restrict__ wsplit,  // [2][COUT][32] fp16 in the k order below
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      float* __restrict__ out, int64_t ldc) {
+  constexpr int NTC = COUT / 16;
+  constexpr int IN_ROWS = 2 * STEM_TH + 1;
+  constexpr int ROW_DW = ((2 * STEM_TW + 1) * 3 + 3 + 3) / 4 + 1;
+  constexpr int ROWB = ROW_DW * 4;
+  constexpr int NLD = (IN_ROWS * ROW_DW + 255) / 256;
+  __shared__ uint32_t tile[IN_ROWS][ROW_DW];
+  const int Ho = H >> 1, Wo = W >> 1;
+  const int tiles_x = (Wo + STEM_TW - 1) / STEM_TW, tiles_y = (Ho + STEM_TH - 1) / STEM_TH;
+  const int ntiles = B * tiles_y * tiles_x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const long total = (long)B * H * W * 3;
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(in), 0, (uint32_t)total, 0x00020000);     // (host: W % 4 == 0, total < 4 GiB)
+  // The window of a tile: 17 rows x 51 dwords from the aligned dword at or below its first byte (rows are whole dwords, so every row of
+  // a window has the same byte phase: (2 ox0 - 1) * 3 mod 4).  ALL of a thread's dwords are requested before the first is used
+  // (range-checked buffer loads, no branch between them), and the requests of all eight tiles of a block are issued before the first is computed:
+  // measured at 96 frames (lab build, tools/probes/stem_x3_time.py), one tile per block: 722 us; without the stores 293, without the
+  // loads 388 -- the reads of a block wait behind the write stream, so they must be in flight a tile ahead.  Rows outside the image =
+  // out-of-range offset = 0 = the padding; the bytes of a dword that precede the image row (left padding) are masked.
+  auto coords = [&](int t, int& b, int& oy0, int& ox0) {
+    const int tx = t % tiles_x; t /= tiles_x;
+    oy0 = (t % tiles_y) * STEM_TH; ox0 = tx * STEM_TW; b = t / tiles_y;
+  };
+  uint32_t v[STEM_X3_TPB][NLD];
+  auto request = [&](int t, auto nc) {
+    constexpr int n_ = decltype(nc)::value;
+    int b, oy0, ox0;
+    coords(t, b, oy0, ox0);
+    const long img = (long)b * H * W * 3;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = tid + k * 256;
+      const int rr = i / ROW_DW, dw = i - rr * ROW_DW;
+      const int iy = 2 * oy0 - 1 + rr;
+      const long start = img + (long)iy * W * 3 + (long)(2 * ox0 - 1) * 3;
+      const long addr = (start & ~3L) + dw * 4;
+      const bool ok = t < ntiles && i < IN_ROWS * ROW_DW && (unsigned)iy < (unsigned)H && addr >= 0;
+      v[n_][k] = __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (uint32_t)addr : 0xffffffffu, 0, 0);
+    }
+  };
+  auto deposit = [&](int t, auto nc) {
+    constexpr int n_ = decltype(nc)::value;
+    int b, oy0, ox0;
+    coords(t, b, oy0, ox0);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = tid + k * 256;
+      const int dw = i % ROW_DW;
+      // left edge (ox0 == 0): the window starts 3 bytes before the row, i.e. byte 1 of the dword below it: that dword's bytes 1..3 are the padding
+      const uint32_t m = (ox0 == 0 && dw == 0) ? 0u : 0xffffffffu;
+      if (i < IN_ROWS * ROW_DW) (&tile[0][0])[i] = v[n_][k] & m;
+    }
+  };
+  u32x4 wh[NTC], wl[NTC];
+  f32x4 sc[NTC], sh[NTC];
+#pragma unroll
+  for (int j = 0; j < NTC; ++j) {                       // lane: MFMA row r of tile j (channel j*16 + r), k-slice q
+    wh[j] = *reinterpret_cast<const u32x4*>(wsplit + (j * 16 + r) * 32 + q * 8);
+    wl[j] = *reinterpret_cast<const u32x4*>(wsplit + (COUT + j * 16 + r) * 32 + q * 8);
+    sc[j] = *reinterpret_cast<const f32x4*>(scale + j * 16 + q * 4) * (1.0f / 255.0f);
+    sh[j] = *reinterpret_cast<const f32x4*>(shift + j * 16 + q * 4);
+  }
+  const uint8_t* tb = reinterpret_cast<const uint8_t*>(&tile[0][0]);
+  const uint32_t* tw = &tile[0][0];
+  const int t0 = blockIdx.x * STEM_X3_TPB;
+  auto for_tiles = [&](auto&& f) { [&]<int... U>(std::integer_sequence<int, U...>) { (f(std::integral_constant<int, U>{}), ...); }(std::make_integer_sequence<int, STEM_X3_TPB>{}); };
+  for_tiles([&](auto nc) { request(t0 + decltype(nc)::value, nc); });      // every window of the block in flight at once (beyond the last tile: nothing is read)
+  for_tiles([&](auto nc) {
+    constexpr int n = decltype(nc)::value;
+    const int t = t0 + n;
+    if (t >= ntiles) return;                                               // block-uniform
+    int b, oy0, ox0;
+    coords(t, b, oy0, ox0);
+    deposit(t, nc);
+    __syncthreads();
+    const int mis = (int)(((long)(2 * ox0 - 1) * 3) & 3L);   // byte phase of the window inside its first dword (row pitch and image base: whole dwords)
+    // k order of a lane's slice (= moy_stem_l1_fused's, ops.stem_weights_x3): q < 3: the first EIGHT consecutive bytes of window row
+    // ky = q (kx = e / 3, c_bgr = e % 3); q = 3: the ninth byte (kx 2, red) of the three rows, then zeros -- three dword reads + two
+    // v_alignbyte (or three byte reads) per fragment instead of eight byte gathers
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int orow = wave * 2 + (g >> 1), ocol = (g & 1) * 16 + r;
+      uint32_t lo, hi;
+      if (q < 3) {
+        const int off = (2 * orow + q) * ROWB + mis + 6 * ocol;
+        const uint32_t d0 = tw[off >> 2], d1 = tw[(off >> 2) + 1], d2 = tw[(off >> 2) + 2];
+        lo = __builtin_amdgcn_alignbyte(d1, d0, off & 3);
+        hi = __builtin_amdgcn_alignbyte(d2, d1, off & 3);
+      } else {
+        uint32_t b3[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) b3[e] = tb[(2 * orow + e) * ROWB + mis + 6 * ocol + 8];
+        lo = b3[0] | (b3[1] << 8) | (b3[2] << 16);
+        hi = 0;
+      }
+      // the bytes as fp16: 0x6400 | x is 1024 + x, minus 1024 is exact (one v_perm_b32 + one v_pk_add_f16 per pair)
+      typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+      auto pair = [&](uint32_t w4, uint32_t sel) {
+        const h2_ big = __builtin_bit_cast(h2_, __builtin_amdgcn_perm(0x64646464u, w4, sel));
+        return __builtin_bit_cast(uint32_t, big - h2_{(_Float16)1024.0f, (_Float16)1024.0f});
+      };
+      const u32x4 af = {pair(lo, 0x04010400u), pair(lo, 0x04030402u), pair(hi, 0x04010400u), pair(hi, 0x04030402u)};
+      const int oy = oy0 + orow, ox = ox0 + ocol;
+      float* o = out + (((long)b * Ho + oy) * Wo + ox) * ldc;
+#pragma unroll
+      for (int j = 0; j < NTC; ++j) {                    // D[channel q*4+reg][pixel r]
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accx = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[j]), __builtin_bit_cast(f16x8, af), acc, 0, 0, 0);
+        accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wl[j]), __builtin_bit_cast(f16x8, af), accx, 0, 0, 0);
+        f32x4 y = (acc + accx * (1.0f / 2048.0f)) * sc[j] + sh[j];
+        y.x = siluf_(y.x); y.y = siluf_(y.y); y.z = siluf_(y.z); y.w = siluf_(y.w);
+        if (oy < Ho && ox < Wo) *reinterpret_cast<f32x4*>(o + j * 16 + q * 4) = y;
+      }
+    }
+    __syncthreads();                                      // every wave has read the window before the next one overwrites it
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
 // SPPF: y1 = pool5(x), y2 = pool5(y1), y3 = pool5(y2) (stride 1, pad 2, -inf padding), exactly the
 // cascade of block.py:129-134.  One block = one (frame, 16-byte channel chunk): the H x W plane of
 // that chunk lives in LDS and each 5x5 pool is a separable row pass + column pass (5 + 5 reads per
@@ -1742,6 +1874,30 @@ extern "C" int moy_stem_conv_mfma(const void* in_u8, int B, int H, int W, const 
     case 16: hipLaunchKernelGGL((stem_mfma_kernel<16>), dim3(blocks), dim3(256), 0, st, in, B, H, W, w, scale, shift, o, ldc); break;
     case 32: hipLaunchKernelGGL((stem_mfma_kernel<32>), dim3(blocks), dim3(256), 0, st, in, B, H, W, w, scale, shift, o, ldc); break;
     case 64: hipLaunchKernelGGL((stem_mfma_kernel<64>), dim3(blocks), dim3(256), 0, st, in, B, H, W, w, scale, shift, o, ldc); break;
+    default: return MOY_ENOSYS;
+  }
+  return launch_status();
+}
+
+extern "C" int moy_stem_conv_x3(const void* in_u8, int B, int H, int W, const void* wsplit, const float* scale, const float* shift,
+                                int Cout, void* out, int64_t ldc, void* stream) {
+  if (!in_u8 || !wsplit || !scale || !shift || !out || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return MOY_EINVAL;
+  if (ldc < Cout || (ldc % 4) || !aligned16(wsplit) || !aligned16(scale) || !aligned16(shift) || !aligned16(out) ||
+      reinterpret_cast<uintptr_t>(in_u8) % 4)
+    return MOY_EINVAL;
+  // (the window loads are range-checked dwords at 32-bit offsets: rows of whole dwords, frames below 4 GiB)
+  if ((W % 4) || (long)B * H * W * 3 >= 0xfffffffcL) return MOY_ENOSYS;
+  const int Ho = H / 2, Wo = W / 2;
+  const unsigned tiles = (unsigned)B * ((Ho + STEM_TH - 1) / STEM_TH) * ((Wo + STEM_TW - 1) / STEM_TW);
+  const unsigned blocks = (tiles + STEM_X3_TPB - 1) / STEM_X3_TPB;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const uint8_t* in = static_cast<const uint8_t*>(in_u8);
+  const f16_t* w = static_cast<const f16_t*>(wsplit);
+  float* o = static_cast<float*>(out);
+  switch (Cout) {
+    case 16: hipLaunchKernelGGL((stem_x3_kernel<16>), dim3(blocks), dim3(256), 0, st, in, B, H, W, w, scale, shift, o, ldc); break;
+    case 32: hipLaunchKernelGGL((stem_x3_kernel<32>), dim3(blocks), dim3(256), 0, st, in, B, H, W, w, scale, shift, o, ldc); break;
+    case 64: hipLaunchKernelGGL((stem_x3_kernel<64>), dim3(blocks), dim3(256), 0, st, in, B, H, W, w, scale, shift, o, ldc); break;
     default: return MOY_ENOSYS;
   }
   return launch_status();

@@ -32,6 +32,7 @@ class PlanOptions:
     1-5 read 18 `MOY_*` environment variables here; process-wide state a host could not see).  The defaults ARE the shipped plan; the
     product path never reads the environment.  `PlanOptions.from_env()` maps the old variable names onto the fields for the lab
     scripts under tools/ (A/B runs), `bench.py --plan key=value,...` builds one from its argument."""
+    stem_x3: bool = True          # round 6, f32x3 only: the stem on the matrix cores with split weights (bytes are exact fp16 values)
     fuse_stem: bool = True        # preprocess + layer 0 + layer 1 as one launch (16-bit, uint8 frames)
     fuse_upsample: bool = True    # Upsample + Concat folded into the consuming C2f's cv1
     fuse_c2f: bool = True         # the first C2f block as one launch
@@ -57,7 +58,7 @@ class PlanOptions:
     assume_wreg: bool = True      # the library's weight-stationary kernel may be planned for (False with a lab library run under MOY_GEMM_WREG=0)
 
     _ENV = dict(fuse_stem="MOY_FUSE_STEM", fuse_upsample="MOY_FUSE_UPSAMPLE", fuse_c2f="MOY_FUSE_C2F", value_planes="MOY_VALUE_PLANES",
-                fold_proj="MOY_FOLD_PROJ", fold_min_rows="MOY_FOLD_MIN_ROWS", score_runs="MOY_SCORE_RUNS", p3_raw="MOY_P3_RAW", query_order="MOY_Q_ORDER", mlp_head="MOY_MLP_HEAD",
+                stem_x3="MOY_STEM_X3", fold_proj="MOY_FOLD_PROJ", fold_min_rows="MOY_FOLD_MIN_ROWS", score_runs="MOY_SCORE_RUNS", p3_raw="MOY_P3_RAW", query_order="MOY_Q_ORDER", mlp_head="MOY_MLP_HEAD",
                 dec_mid="MOY_DEC_MID", dec_tail="MOY_DEC_TAIL", qkv_split="MOY_QKV_SPLIT", qkv_fuse="MOY_QKV_FUSE", w_packed="MOY_W_PACKED",
                 post_1x1="MOY_POST_1X1", fork_value="MOY_FORK_VALUE", assume_wreg="MOY_GEMM_WREG", fork_small_value="MOY_FORK_SMALL",
                 qkv_fuse_small="MOY_QKV_FUSE_SMALL")
@@ -458,6 +459,15 @@ class TrackEngine:
                         self._add(lib.moy_stem_conv_mfma, self.input.data_ptr(), B, H, W, wpad.data_ptr(), scale.data_ptr(),
                                   shift.data_ptr(), Ls.c2, o.ptr, o.ld,
                                   meta=dict(name=f"stem_mfma M{B * (H // 2) * (W // 2)} N{Ls.c2}", bytes=B * H * W * 3 + B * (H // 2) * (W // 2) * Ls.c2 * 2,
+                                            flops=2 * B * (H // 2) * (W // 2) * Ls.c2 * 27))
+                    elif (self.split_f16 and self.opt.stem_x3 and self.input_format == "u8" and Ls.c2 in (16, 32, 64) and o.ld % 4 == 0
+                          and W % 4 == 0 and B * H * W * 3 < 2 ** 32 - 4):
+                        # round 6: the pixel bytes are exact fp16 values -> two products per tile with the split weights (moy_stem_conv_x3)
+                        from .ops import stem_weights_x3
+                        wsp = self._dev(stem_weights_x3(sd[p + ".conv.weight"]))
+                        self._add(lib.moy_stem_conv_x3, self.input.data_ptr(), B, H, W, wsp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                  Ls.c2, o.ptr, o.ld,
+                                  meta=dict(name=f"stem_x3 M{B * (H // 2) * (W // 2)} N{Ls.c2}", bytes=B * H * W * 3 + B * (H // 2) * (W // 2) * Ls.c2 * 4,
                                             flops=2 * B * (H // 2) * (W // 2) * Ls.c2 * 27))
                     else:
                         wst = self._dev(sd[p + ".conv.weight"].permute(2, 3, 1, 0).reshape(27, Ls.c2))

@@ -147,6 +147,23 @@ def stem_weights_mfma(w):
     return out.to(torch.bfloat16).contiguous()
 
 
+def stem_weights_x3(w):
+    """[Cout, 3, 3, 3] fp32 conv weight (c_rgb) -> fp16 [2, Cout, 32] for moy_stem_conv_x3: moy_stem_l1_fused's k order (slice q < 3 = tap
+    row ky = q over the 8 bytes (kx, c_bgr) of a window row, slice 3 = the ninth byte (kx 2, red) of the three rows, then zeros);
+    plane 0 = fp16(w), plane 1 = fp16((w - plane 0) * 2^11) (the MOY_F32X3 operand form, split_weight)."""
+    cout = w.shape[0]
+    w = w.float()
+    w32 = torch.zeros(cout, 32, device=w.device, dtype=torch.float32)
+    for qq in range(3):
+        for e in range(8):
+            w32[:, qq * 8 + e] = w[:, 2 - e % 3, qq, e // 3]
+    for e in range(3):
+        w32[:, 24 + e] = w[:, 0, e, 2]
+    hi = w32.to(torch.float16)
+    lo = ((w32 - hi.float()) * 2048.0).to(torch.float16)
+    return torch.stack([hi, lo]).contiguous()
+
+
 def stem_weights_fused(w, dtype=None):
     """[32, 3, 3, 3] fp32 stem weight (c_rgb) -> IEEE half [32, 32] in moy_stem_l1_fused's k order: slice q < 3 = tap row ky = q over
     the 8 bytes (kx, c_bgr) of a window row, slice 3 = the ninth byte (kx 2, c_bgr 2 = red) of the three rows.  Halfs for BOTH engine
@@ -199,6 +216,17 @@ def stem_conv_mfma(x_u8, wpad, scale, shift):
     out = torch.empty(B * (H // 2) * (W // 2), cout, device=x_u8.device, dtype=torch.bfloat16)
     L.check(L.lib().moy_stem_conv_mfma(x_u8.data_ptr(), B, H, W, wpad.data_ptr(), scale.data_ptr(), shift.data_ptr(), cout,
                                        out.data_ptr(), cout, _st()), "moy_stem_conv_mfma")
+    return out
+
+
+def stem_conv_x3(x_u8, wsplit, scale, shift):
+    """Stem of the split-fp16 engine: uint8 [B, H, W, 3] BGR -> fp32 [B*(H/2)*(W/2), Cout] (moy_stem_conv_x3)."""
+    _need_gpu(x_u8)
+    B, H, W, _ = x_u8.shape
+    cout = wsplit.shape[1]
+    out = torch.empty(B * (H // 2) * (W // 2), cout, device=x_u8.device, dtype=torch.float32)
+    L.check(L.lib().moy_stem_conv_x3(x_u8.data_ptr(), B, H, W, wsplit.data_ptr(), scale.data_ptr(), shift.data_ptr(), cout,
+                                     out.data_ptr(), cout, _st()), "moy_stem_conv_x3")
     return out
 
 

@@ -724,6 +724,28 @@ def test_stem_conv_mfma(B, H, W, Cout):
     assert torch.allclose(got, ref, atol=2e-2), float((got - ref).abs().max())
 
 
+@pytest.mark.parametrize("B,H,W,Cout", [(2, 32, 48, 16), (1, 608, 1088, 32), (3, 34, 72, 32), (1, 18, 68, 64), (2, 50, 132, 32)])
+def test_stem_conv_split_f16(B, H, W, Cout):
+    """Round 6: the stem of the f32x3 engine (moy_stem_conv_x3): the bytes as exact fp16 values against the split weights, two products per
+    tile -- against float64 (preprocess predictor.py:125-133 + Conv/BN/SiLU conv.py:36-38) at fp32 accuracy, and against the scalar fp32
+    stem it replaces in that plan; odd tile tails, image borders, every dword misalignment of the u8 rows."""
+    g = torch.Generator().manual_seed(B + W)
+    u8 = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    x = u8.flip(-1).permute(0, 3, 1, 2).double() / 255
+    w = rnd(Cout, 3, 3, 3, seed=2, scale=0.3)
+    sc, sh = rnd(Cout, seed=3) * 0.2 + 1, rnd(Cout, seed=4, scale=0.1)
+    ref = F.silu(F.conv2d(x, w.double(), None, 2, 1) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    y = ops.stem_conv_x3(u8.to(DEV), ops.stem_weights_x3(w.to(DEV)), sc.to(DEV), sh.to(DEV))
+    assert y.dtype == torch.float32
+    got = y.double().cpu().view(B, H // 2, W // 2, Cout).permute(0, 3, 1, 2)
+    e3 = float((got - ref).abs().max())
+    y1 = ops.stem_conv(u8.to(DEV), w.permute(2, 3, 1, 0).reshape(27, Cout).contiguous().to(DEV), sc.to(DEV), sh.to(DEV), torch.float32)
+    e1 = float((y1.double().cpu().view(B, H // 2, W // 2, Cout).permute(0, 3, 1, 2) - ref).abs().max())
+    assert e3 <= 2e-6 and e3 <= max(8 * e1, 1e-6), (e3, e1)
+    with pytest.raises(RuntimeError):                # rows of whole dwords only (the engine keeps the fp32 stem otherwise)
+        ops.stem_conv_x3(u8[:, :, :W - 2].contiguous().to(DEV), ops.stem_weights_x3(w.to(DEV)), sc.to(DEV), sh.to(DEV))
+
+
 @pytest.mark.parametrize("Cc", [16, 64, 128])
 @pytest.mark.parametrize("dt", DT)
 def test_sppf_pool_and_upsample(dt, Cc):
