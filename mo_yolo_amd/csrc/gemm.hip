@@ -1119,6 +1119,9 @@ static int dispatch_tile(GemmParams& p, bool ln, hipStream_t st) {
     //   N = 64, 1x1 and 3x3 stride 2:  256 x 64 on four waves (each all 64 columns)     0.91 / 0.96-0.98
     //   N = 64, 3x3 stride 1:          stays 128 x 64 on eight waves (three resident blocks; 256 x 64 on four or eight waves 1.04-1.18,
     //                                  128 x 64 on four waves 1.0-1.04)
+    // (Measured, timing only: all three products into ONE accumulator -- the register set of the cross terms gone, so the 64 x 64 wave tiles
+    //  take a second stage in flight, 220-224 registers -- is worth 5.18 -> 5.35 k frames/s on the whole f32x3 bench; a real single-accumulator
+    //  split needs the remainders at true scale and ~1.7 x the rounding of this form: not built.)
     static const int x3tile = knob("MOY_X3_TILE", 1);
     const long rows256 = (p.M + 255) / 256;
     if (x3tile && p.N > 64 && rows256 * ((p.N + 127) / 128) >= 256) {
