@@ -428,6 +428,9 @@ def test_plan_options_are_explicit_and_the_environment_is_a_lab_input_only():
     d = PlanOptions()
     assert d.fold_proj and d.p3_raw and d.dec_tail and d.dec_mid and d.qkv_split == 1 and not d.qkv_fuse and d.qkv_fuse_small
     assert not d.query_order and d.fork_value == 0 and d.fork_small_value == 0 and d.value_planes == 2
+    assert d.fold_min_rows == 8192 and d.stem_x3                      # (round 6: the folded head from 13 frames per engine; the f32x3 stem on the matrix cores)
+    assert PlanOptions.parse("fold_min_rows=65536,stem_x3=0") == PlanOptions(fold_min_rows=65536, stem_x3=False)
+    assert PlanOptions.from_env({"MOY_FOLD_MIN_ROWS": "65536", "MOY_STEM_X3": "0"}) == PlanOptions(fold_min_rows=65536, stem_x3=False)
     p = PlanOptions.parse("p3_raw=0, qkv_split=2,query_order=1,fork_value=128")
     assert (p.p3_raw, p.qkv_split, p.query_order, p.fork_value) == (False, 2, True, 128) and p.fold_proj
     assert PlanOptions.parse("") == d and PlanOptions.parse(None) == d
