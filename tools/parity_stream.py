@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--batch", type=int, default=24)
     ap.add_argument("--oracle-every", type=int, default=50)
     ap.add_argument("--yard-frames", type=int, default=4, help="frames per batch run through the eager 16-bit oracle (0 = off)")
+    ap.add_argument("--x3", action="store_true", help="round 6: also the fp32 engine with split-fp16 products (f32x3), compared with the exact fp32 engine on every frame")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "parity_r03_c2.json"))
     a = ap.parse_args()
     torch.set_num_threads(min(16, os.cpu_count() or 1))      # (the oracle: eager CPU ops collapse with hundreds of threads)
@@ -110,12 +111,16 @@ def main():
     dts = {"bf16": torch.bfloat16, "f16": torch.float16}
     engines = {"f32": TrackEngine(arch, sd, H, W, batch=B, dtype=torch.float32)}
     engines.update({k: TrackEngine(arch, sd, H, W, batch=B, dtype=dt) for k, dt in dts.items()})
+    cmp_keys = list(dts)                                      # engines compared with the fp32 engine on every frame
+    if a.x3:
+        engines["f32x3"] = TrackEngine(arch, sd, H, W, batch=B, dtype=torch.float32, split_f16=True)
+        cmp_keys.append("f32x3")
     sd_half = {k: {n: (v.to(dev, dt) if v.is_floating_point() else v.to(dev)) for n, v in sd.items()} for k, dt in dts.items()} \
         if a.yard_frames else {}
     doc = {"config": a.config, "frames_per_sequence": a.frames, "sequences": a.seqs, "engine_batch": B,
            "note": "rows are matched by selected encoder token (mo_yolo_amd/parity.py); every engine runs free (its own top-k); "
                    "agreement_hota = the engine's tracks scored against the fp32 engine's tracks as ground truth (100 = identical)"}
-    acc = {k: Acc(arch.nq) for k in dts}
+    acc = {k: Acc(arch.nq) for k in cmp_keys}
     yard = {k: Acc(arch.nq) for k in dts}
     acc_same = {k: Acc(arch.nq) for k in dts}                 # the engines on exactly the yardstick's frames
     oracle = dict(frames=0, topk_equal=0, logits_max_err=0.0, ids_exact=0)
@@ -141,7 +146,7 @@ def main():
             for b in range(n):
                 for k in engines:
                     trk[k].append(tracks_of(outs[k], b, W, H))
-            for k in dts:
+            for k in cmp_keys:
                 acc[k].add(outs[k], outs["f32"])
             ny = min(a.yard_frames, n)
             if ny:
@@ -177,11 +182,11 @@ def main():
                 res = metric.eval_sequence({kk: (list(v) if isinstance(v, list) else v) for kk, v in data.items()})
                 hota.setdefault(k, {}).setdefault(name, {})[f"seq{sid}"] = {m: float(np.mean(res[m])) for m in ("HOTA", "DetA", "AssA")}
             hota[k].setdefault("tracks_per_frame", {})[f"seq{sid}"] = float(np.mean([len(i) for i in ti]))
-        for k in dts:
+        for k in cmp_keys:
             agree.setdefault(k, {})[f"seq{sid}"] = agreement_hota(trk[k], trk["f32"], device=dev)
-    for k in dts:
+    for k in cmp_keys:
         doc[k + "_vs_f32_engine"] = acc[k].doc()
-        if a.yard_frames:
+        if a.yard_frames and k in dts:
             doc[k + "_eager_torch_oracle_vs_f32_engine"] = dict(
                 yard[k].doc(), note=f"the oracle in {k} by eager torch on the GPU (the reference's own half switch) on the first "
                                     f"{a.yard_frames} frames of every batch; the engine on the same frames is next to it")
