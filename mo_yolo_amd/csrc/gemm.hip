@@ -1100,6 +1100,12 @@ static int try_conv_direct(GemmParams& p, int B, bool ln, hipStream_t st) {
 
 template <typename T, int KS>
 static int dispatch_tile(GemmParams& p, bool ln, hipStream_t st) {
+  if constexpr (std::is_same<T, f32x3_t>::value) {
+    // (round 6: the LayerNorm form of the split kind on 128-row tiles for launches of many rows -- the score pass over the valid tokens: 64 x 64
+    //  wave tiles, the 128 KB of split weights of a k pass fetched once per 128 rows instead of once per 64)
+    static const int x3ln = knob("MOY_X3_LN128", 1);
+    if (ln && x3ln && p.M >= 128 * 512) return launch_cfg<T, 128, 256, 2, 4, true, KS>(p, st);
+  }
   if (ln) return launch_cfg<T, 64, 256, 2, 4, true, KS>(p, st);
 #if MOY_DIAG
   static const int force = knob("MOY_TILE", 0);   // MOY_TILE: tuning knob (tools/bench_gemm.py); 0 = the measured heuristic below
