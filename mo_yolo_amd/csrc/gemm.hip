@@ -524,6 +524,9 @@ void gemm_kernel(const GemmParams p) {
         for (int j = 0; j < RA2; ++j) areg[SET][j] = add_chunks<T>(areg[SET][j], t2[j]);
       }
     } else {
+      // (round 6, measured and dropped: with Cin a multiple of the stage's k extent the tap and its byte delta are wave-uniform -- scalar unit, ~12
+      //  vector instructions fewer per stage and thread; f32x3 5.26-5.29 k against 5.28 k, exact fp32 +0.4 %, the small-batch leg equal: the
+      //  vector issue port is not what paces these loops, and the second code path cost the 256 x 64 form 12 bytes of scratch)
       const int kc = kt * BK + kc0;
       const int tap = (int)__umulhi((unsigned)kc, p.cin_magic), c = kc - tap * p.Cin;   // kc / Cin, kc % Cin (any Cin)
       const int ky = (tap * 11) >> 5, kx = tap - ky * 3;   // tap / 3 for tap < 16
